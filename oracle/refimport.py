@@ -1,0 +1,36 @@
+"""Import the live reference's hot-path modules in THIS build container.
+
+TEST INFRASTRUCTURE ONLY, and only usable where /root/reference exists (it does
+not exist on the GPU box).  `colpali_engine/__init__.py` pulls every model
+family (and through them torchvision, peft ...), which are not installed, so a
+stub top-level package is registered and only the two modules on the hot path
+are imported: utils/processing_utils.py and loss/late_interaction_losses.py.
+Used by tests/golden/make_golden.py to generate the committed fixtures and by
+tests/test_reference_live.py (skipped when the checkout is absent).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("COLPALI_REFERENCE_ROOT", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "colpali_engine"))
+
+
+def load():
+    """Returns (BaseVisualRetrieverProcessor, late_interaction_losses module)."""
+    if not available():
+        raise RuntimeError(f"reference checkout not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True
+    if "colpali_engine" not in sys.modules:
+        pkg = types.ModuleType("colpali_engine")
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "colpali_engine")]
+        sys.modules["colpali_engine"] = pkg
+    from colpali_engine.loss import late_interaction_losses  # noqa: E402
+    from colpali_engine.utils.processing_utils import BaseVisualRetrieverProcessor  # noqa: E402
+
+    return BaseVisualRetrieverProcessor, late_interaction_losses

@@ -1,0 +1,170 @@
+"""Generate the golden fixtures under tests/golden/ from the LIVE reference.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+Every fixture stores the exact inputs (bf16 as uint16 bit patterns, or fp32)
+and the outputs the reference functions returned for them:
+  colpali_engine/utils/processing_utils.py:132-187  score_multi_vector
+  colpali_engine/loss/late_interaction_losses.py:255-313  ColbertPairwiseCELoss
+(+ ColbertLoss :110-164 on the same inputs, for the shared MaxSim core).
+The fixtures are what pins oracle/ and, through it, the HIP path.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+from oracle import refimport  # noqa: E402
+
+P, L = refimport.load()
+torch.set_num_threads(8)
+
+
+def unit_rows(n, dim, g, dtype=torch.bfloat16):
+    return F.normalize(torch.randn(n, dim, generator=g), dim=-1).to(dtype)
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    assert t.dtype == torch.bfloat16
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def ref_score(qs, ps, batch_size=128):
+    """(truth = reference on fp32 upcasts, literal = reference on the raw tensors)."""
+    truth = P.score_multi_vector([q.float() for q in qs], [p.float() for p in ps],
+                                 batch_size=batch_size, device="cpu")
+    literal = P.score_multi_vector(qs, ps, batch_size=batch_size, device="cpu")
+    return truth.numpy(), literal.numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def ragged_case(seed, q_lens, p_lens, dim, batch_sizes, name):
+    g = torch.Generator().manual_seed(seed)
+    qs = [unit_rows(n, dim, g) for n in q_lens]
+    ps = [unit_rows(n, dim, g) for n in p_lens]
+    out = dict(
+        q_lens=np.array(q_lens, np.int32), p_lens=np.array(p_lens, np.int32), dim=np.int32(dim),
+        q_bits=np.concatenate([bits(q) for q in qs]), p_bits=np.concatenate([bits(p) for p in ps]),
+        batch_sizes=np.array(batch_sizes, np.int32),
+    )
+    for bs in batch_sizes:
+        truth, literal = ref_score(qs, ps, bs)
+        out[f"truth_bs{bs}"] = truth
+        out[f"literal_bs{bs}"] = literal
+    save(name, **out)
+
+
+def main():
+    # (1) small ragged lists, d=128: exercises block padding (finding 4), tails, 1-row docs
+    ragged_case(11, [5, 32, 17, 1], [64, 33, 100, 1, 47, 96, 128, 31, 32, 160], 128, [128, 4, 3, 1],
+                "score_ragged_d128.npz")
+
+    # (2) config 1 of BASELINE.json: 4 queries x 16 docs, [32,128] x [1024,128] bf16.
+    #     Inputs are regenerated from the seed by the tests; the sha256 pins them.
+    g = torch.Generator().manual_seed(1234)
+    qs = [unit_rows(32, 128, g) for _ in range(4)]
+    ps = [unit_rows(1024, 128, g) for _ in range(16)]
+    truth, literal = ref_score(qs, ps)
+    h = hashlib.sha256()
+    for t in qs + ps:
+        h.update(bits(t).tobytes())
+    save("score_config1.npz", seed=np.int64(1234), n_q=np.int32(4), n_d=np.int32(16), Lq=np.int32(32),
+         Ld=np.int32(1024), dim=np.int32(128), sha256=np.frombuffer(h.digest(), dtype=np.uint8),
+         truth=truth, literal=literal)
+
+    # (3) negative-similarity documents: alone vs sharing a block with a longer one (finding 4)
+    g = torch.Generator().manual_seed(7)
+    q = unit_rows(8, 128, g)
+    anti = -q.float().sum(0, keepdim=True)                    # negative similarity with EVERY query token
+    short = F.normalize(anti + 0.02 * torch.randn(3, 128, generator=g), dim=-1).to(torch.bfloat16)
+    assert (q.float() @ short.float().T).max() < 0
+    long_ = unit_rows(40, 128, g)
+    t_alone, l_alone = ref_score([q], [short])
+    t_block, l_block = ref_score([q], [short, long_])
+    t_split, l_split = ref_score([q], [short, long_], batch_size=1)
+    save("score_negative_clamp.npz", q_bits=bits(q), short_bits=bits(short), long_bits=bits(long_),
+         truth_alone=t_alone, truth_block=t_block, truth_split=t_split,
+         literal_alone=l_alone, literal_block=l_block, literal_split=l_split)
+
+    # (4) 3-D tensor inputs with physical zero rows (what the models emit: proj * attention_mask)
+    g = torch.Generator().manual_seed(21)
+    q3 = torch.stack([unit_rows(12, 128, g) for _ in range(3)])
+    q3[1, 9:] = 0
+    p3 = torch.stack([unit_rows(70, 128, g) for _ in range(5)])
+    p3[0, :20] = 0          # left padded (ColQwen2 style)
+    p3[3, 50:] = 0          # right padded (ColPali style)
+    truth = P.score_multi_vector(q3.float(), p3.float(), device="cpu").numpy()
+    literal = P.score_multi_vector(q3, p3, device="cpu").numpy()
+    save("score_tensor3d.npz", q_bits=bits(q3), p_bits=bits(p3), q_shape=np.array(q3.shape, np.int32),
+         p_shape=np.array(p3.shape, np.int32), truth=truth, literal=literal)
+
+    # (5) the reference's own unit-test shape: d=32 fp32 lists (tests/utils/test_processing_utils.py:15-35)
+    g = torch.Generator().manual_seed(5)
+    qs = [torch.randn(2, 32, generator=g), torch.randn(4, 32, generator=g)]
+    ps = [torch.randn(8, 32, generator=g), torch.randn(4, 32, generator=g), torch.randn(16, 32, generator=g)]
+    s_list = P.score_multi_vector(qs, ps, device="cpu").numpy()
+    s_tens = P.score_multi_vector(torch.nn.utils.rnn.pad_sequence(qs, batch_first=True),
+                                  torch.nn.utils.rnn.pad_sequence(ps, batch_first=True), device="cpu").numpy()
+    save("score_fp32_d32.npz", q_lens=np.array([2, 4], np.int32), p_lens=np.array([8, 4, 16], np.int32),
+         q=np.concatenate([q.numpy() for q in qs]), p=np.concatenate([p.numpy() for p in ps]),
+         scores_list=s_list, scores_tensor=s_tens)
+
+    # (6) losses: fp32 inputs, loss value + autograd gradients from the reference modules
+    g = torch.Generator().manual_seed(99)
+    B, C, Lq, Ld, dim = 6, 12, 9, 24, 128
+    Q = F.normalize(torch.randn(B, Lq, dim, generator=g), dim=-1)
+    Q[2, 6:] = 0  # padded query rows: lengths = (Q[:,:,0] != 0).sum(1)  (late_interaction_losses.py:296)
+    D = F.normalize(torch.randn(C, Ld, dim, generator=g), dim=-1)
+    D[5, 18:] = 0
+    # make positives actually positive so top-2 / where logic sees both branches
+    for b in range(B):
+        for off in (0, 6):
+            D[b + off, :Lq] = F.normalize(Q[b] + 0.4 * torch.randn(Lq, dim, generator=g), dim=-1) * (Q[b].abs().sum(-1, keepdim=True) > 0)
+    D[1] = F.normalize(torch.randn(Ld, dim, generator=g), dim=-1)  # query 1's positive is NOT its best doc
+    out = dict(Q=Q.numpy(), D=D.numpy())
+    variants = {
+        "default": dict(),
+        "nonorm": dict(normalize_scores=False),
+        "nonorm_T05": dict(normalize_scores=False, temperature=0.5),
+        "filter": dict(normalize_scores=False, pos_aware_negative_filtering=True),
+    }
+    for cls_name in ("ColbertPairwiseCELoss", "ColbertLoss"):
+        cls = getattr(L, cls_name)
+        for vname, kw in variants.items():
+            if cls_name == "ColbertLoss" and vname not in ("default", "nonorm"):
+                continue
+            for offset in (0, 6):
+                q = Q.clone().requires_grad_(True)
+                d = D.clone().requires_grad_(True)
+                loss = cls(**kw)(q, d, offset=offset)
+                loss.backward()
+                key = f"{cls_name}_{vname}_off{offset}"
+                out[key + "_loss"] = loss.detach().numpy()
+                out[key + "_dQ"] = q.grad.numpy()
+                out[key + "_dD"] = d.grad.numpy()
+    # bf16 forward values of the same (for the dtype contract: bf16 in -> bf16 scalar out)
+    for offset in (0, 6):
+        out[f"ColbertPairwiseCELoss_nonorm_off{offset}_loss_bf16"] = (
+            L.ColbertPairwiseCELoss(normalize_scores=False)(Q.bfloat16(), D.bfloat16(), offset=offset).float().numpy())
+    save("loss_small.npz", **out)
+
+    # (7) helper known-answer tests restated from tests/loss/test_li_losses.py:45-73,137-147
+    z = L.ColbertPairwiseCELoss(temperature=1.0, normalize_scores=False)(torch.zeros(2, 1, 3), torch.zeros(2, 1, 3))
+    save("loss_kat.npz", pairwise_zero=z.numpy(), ln2=np.float32(np.log(2.0)))
+
+
+if __name__ == "__main__":
+    main()
