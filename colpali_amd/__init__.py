@@ -1,0 +1,20 @@
+"""colpali_amd -- MI355X (gfx950) native late-interaction scorer.
+
+Drop-in for the MaxSim hot path of illuin-tech/colpali:
+  * score_multi_vector            <- BaseVisualRetrieverProcessor.score_multi_vector
+                                     (colpali_engine/utils/processing_utils.py:132-187)
+The compute lives in hand-written HIP kernels behind a C ABI (include/maxsim.h,
+colpali_amd/csrc/); this package is the thin host-side mirror of the reference interface.
+"""
+from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
+from .scoring import get_torch_device, maxsim_scores, score_multi_vector
+
+__all__ = [
+    "PackedCorpus",
+    "block_clamp0",
+    "get_torch_device",
+    "maxsim_scores",
+    "pack_passages",
+    "pack_queries",
+    "score_multi_vector",
+]

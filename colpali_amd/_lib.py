@@ -1,0 +1,63 @@
+"""ctypes binding of colpali_amd/csrc/libmaxsim_gfx950.so (C ABI: include/maxsim.h).
+
+The library is the product: there is no Python/torch/CPU fallback.  If it is not
+built, or cannot be loaded, importing a scorer raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime (libamdhip64.so) we bind to
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
+
+MSIM_FLAG_REF_BF16 = 0x1
+
+_lib = None
+
+
+class MaxSimLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MaxSimLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C colpali_amd/csrc`). colpali_amd has no CPU/torch fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, u32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_size_t
+    L.msim_abi_version.restype = i32
+    L.msim_last_error.restype = ctypes.c_char_p
+    L.msim_fwd_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.msim_fwd_workspace_bytes.restype = sz
+    L.msim_fwd_bf16.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
+    L.msim_fwd_bf16.restype = i32
+    if L.msim_abi_version() != 1:
+        raise MaxSimLibraryError(f"ABI version mismatch: library reports {L.msim_abi_version()}, binding expects 1")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().msim_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise MaxSimLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,130 @@
+"""Device-resident packed corpus: the data layout the gfx950 kernels stream.
+
+    blob    bf16 [total_rows, 128]   all passages' patch embeddings back to back
+    offsets int32 [n + 1]            passage c owns rows offsets[c] .. offsets[c+1]-1
+    clamp0  uint8 [n] or None        1 = the reference zero-pads this passage inside its
+                                     passage block, so a similarity of 0 joins every
+                                     per-token max (processing_utils.py:175-178)
+
+The reference re-pads and re-uploads every passage block for every query block
+(processing_utils.py:170-178); here a corpus is packed and uploaded once.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+EMBED_DIM = 128
+
+
+def block_clamp0(lengths: torch.Tensor, batch_size: int) -> torch.Tensor:
+    """Per-passage "sees zero padding" flag under the reference's blocking.
+
+    processing_utils.py:175-178 pads passages j .. j+batch_size-1 to the longest of
+    the block with zero rows (pad_sequence, padding_value=0): every passage shorter
+    than its block's maximum gains similarity-0 candidates.
+    """
+    if batch_size <= 0:
+        raise ValueError("batch_size must be positive")
+    n = lengths.numel()
+    lengths = lengths.to(torch.int64).cpu()
+    pad = (-n) % batch_size
+    padded = torch.cat([lengths, lengths.new_full((pad,), -1)]) if pad else lengths
+    block_max = padded.view(-1, batch_size).max(dim=1).values.repeat_interleave(batch_size)[:n]
+    return (lengths < block_max).to(torch.uint8)
+
+
+@dataclass
+class PackedCorpus:
+    blob: torch.Tensor                 # bf16 [rows, 128], on the GPU
+    offsets: torch.Tensor              # int32 [n+1], on the GPU
+    clamp0: Optional[torch.Tensor]     # uint8 [n] on the GPU, or None
+    lengths: torch.Tensor              # int64 [n], on the host
+    id_base: int = 0                   # global id of passage 0 (sharded corpora)
+
+    def __len__(self) -> int:
+        return int(self.lengths.numel())
+
+    @property
+    def device(self) -> torch.device:
+        return self.blob.device
+
+    @property
+    def nbytes(self) -> int:
+        return self.blob.numel() * 2
+
+
+def _check_embeddings(x: torch.Tensor, what: str) -> None:
+    if x.dim() not in (2, 3) or x.shape[-1] != EMBED_DIM:
+        raise NotImplementedError(
+            f"{what}: embedding dim {x.shape[-1] if x.dim() else '?'}; the gfx950 kernels are built for dim={EMBED_DIM}")
+    if x.dtype != torch.bfloat16:
+        raise NotImplementedError(
+            f"{what}: dtype {x.dtype}; the gfx950 kernels take bfloat16 embeddings (what the ColPali/ColQwen2 "
+            "forward emits). Converting silently would change the scores, so this is an error.")
+
+
+def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device,
+                  batch_size: Optional[int] = 128, id_base: int = 0) -> PackedCorpus:
+    """Pack passages for the device.  `batch_size=None` disables the reference's
+    block zero-padding semantics (every passage is scored on its own rows only)."""
+    if isinstance(ps, torch.Tensor):
+        if ps.dim() != 3:
+            raise ValueError("a passage tensor must be 3-D (n_passages, max_len, dim)")
+        _check_embeddings(ps, "passages")
+        n, L, _ = ps.shape
+        # slicing a 3-D tensor in blocks and pad_sequence over its rows is a re-stack: zero rows that are
+        # physically present take part in the max on their own, no clamp flag needed
+        blob = ps.reshape(n * L, EMBED_DIM).to(device, non_blocking=True).contiguous()
+        lengths = torch.full((n,), L, dtype=torch.int64)
+        clamp0 = None
+    else:
+        if len(ps) == 0:
+            raise ValueError("No passages provided")
+        for p in ps:
+            if p.dim() != 2:
+                raise ValueError("each passage must be 2-D (sequence_length, dim)")
+            _check_embeddings(p, "passages")
+        lengths = torch.tensor([p.shape[0] for p in ps], dtype=torch.int64)
+        blob = torch.cat([p.reshape(-1, EMBED_DIM) for p in ps], dim=0).to(device, non_blocking=True).contiguous()
+        clamp0 = None
+        if batch_size is not None:
+            flags = block_clamp0(lengths, batch_size)
+            if bool(flags.any()):
+                clamp0 = flags.to(device)
+            if bool((lengths == 0).any()):
+                # an all-empty block makes the reference's max() over an empty dim raise
+                for j in range(0, len(ps), batch_size):
+                    if int(lengths[j : j + batch_size].max()) == 0:
+                        raise RuntimeError("max(): Expected reduction dim 3 to have non-zero size.")
+    if blob.numel() == 0:  # keep a valid device pointer
+        blob = torch.zeros((1, EMBED_DIM), dtype=torch.bfloat16, device=device)
+    offsets = torch.zeros(lengths.numel() + 1, dtype=torch.int64)
+    torch.cumsum(lengths, 0, out=offsets[1:])
+    if int(offsets[-1]) >= 2**31:
+        raise NotImplementedError("more than 2^31 patch rows in one shard")
+    return PackedCorpus(blob=blob, offsets=offsets.to(torch.int32).to(device), clamp0=clamp0,
+                        lengths=lengths, id_base=id_base)
+
+
+def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device) -> torch.Tensor:
+    """[n_q, Lq, 128] bf16 on the device, zero padded.
+
+    processing_utils.py:172 pads each 128-query block to its own longest query; a zero
+    query row scores exactly 0 against everything (its max is 0), so padding all queries
+    to the global maximum returns identical values.
+    """
+    if isinstance(qs, torch.Tensor):
+        if qs.dim() != 3:
+            raise ValueError("a query tensor must be 3-D (n_queries, max_len, dim)")
+        _check_embeddings(qs, "queries")
+        return qs.to(device, non_blocking=True).contiguous()
+    if len(qs) == 0:
+        raise ValueError("No queries provided")
+    for q in qs:
+        if q.dim() != 2:
+            raise ValueError("each query must be 2-D (sequence_length, dim)")
+        _check_embeddings(q, "queries")
+    return torch.nn.utils.rnn.pad_sequence(list(qs), batch_first=True, padding_value=0).to(device, non_blocking=True).contiguous()

@@ -1,0 +1,137 @@
+// C ABI of libmaxsim_gfx950.so (see include/maxsim.h).  Host-side dispatch only: argument
+// validation, kernel selection and launch on the caller's stream.  Nothing here allocates,
+// frees or synchronises, so every entry point is hipGraph-capturable.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/maxsim.h"
+#include "maxsim_stream.hip"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct DeviceInfo {
+    int cus = 0;
+    int lds_per_cu = 0;
+};
+
+// once-initialised per-device cache (the only mutable global state of the library)
+constexpr int kMaxDevices = 64;
+DeviceInfo g_dev[kMaxDevices];
+std::atomic<int> g_dev_ready[kMaxDevices];
+
+int device_info(const DeviceInfo **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail(MSIM_ELAUNCH, "device ordinal %d out of range", dev);
+    if (!g_dev_ready[dev].load(std::memory_order_acquire)) {
+        hipDeviceProp_t p;
+        e = hipGetDeviceProperties(&p, dev);
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            return fail(MSIM_EUNSUPPORTED, "libmaxsim_gfx950 is built for gfx950 (MI355X) only; device %d is %s", dev,
+                        p.gcnArchName);
+        g_dev[dev].cus = p.multiProcessorCount;
+        g_dev[dev].lds_per_cu = 160 * 1024;
+        g_dev_ready[dev].store(1, std::memory_order_release);
+    }
+    *out = &g_dev[dev];
+    return MSIM_OK;
+}
+
+constexpr int kStreamRing = 4;  // slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup
+
+template <int QT, int TPQ>
+int launch_stream(const void *Q, const void *D, const int32_t *d_off, const uint8_t *clamp0, float *scores,
+                  const msim::StreamArgs &a, const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing>;
+    constexpr int lds = 4 * kStreamRing * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!configured[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+        configured[dev].store(1, std::memory_order_release);
+    }
+    const int wg_needed = (a.n_d + 3) / 4;
+    const int wg_cap = di.cus * (di.lds_per_cu / lds);
+    const int grid = wg_needed < wg_cap ? wg_needed : wg_cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, static_cast<const uint16_t *>(Q),
+                       static_cast<const uint16_t *>(D), d_off, clamp0, scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_stream_kernel<%d,%d> launch: %s", QT, TPQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msim_abi_version(void) { return MSIM_ABI_VERSION; }
+
+const char *msim_last_error(void) { return g_err; }
+
+size_t msim_fwd_workspace_bytes(int, int, int, int) { return 0; }
+
+int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                  int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags, void *, void *stream) {
+    if (n_q < 0 || n_d < 0 || Lq <= 0) return fail(MSIM_EINVAL, "negative size (n_q=%d n_d=%d Lq=%d)", n_q, n_d, Lq);
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!Q || !D || !d_off || !scores) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
+    if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
+        return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
+    if (flags & ~(MSIM_FLAG_REF_BF16)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+    if (tpq > 4) return fail(MSIM_EUNSUPPORTED, "Lq=%d: queries longer than 128 tokens are not supported yet", Lq);
+
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    const int group = 4 / tpq;  // queries per pass of the stream kernel
+    for (int q0 = 0; q0 < n_q; q0 += group) {
+        const int g = (n_q - q0 < group) ? (n_q - q0) : group;
+        msim::StreamArgs a;
+        a.ld = ld_scores;
+        a.n_q = g;
+        a.Lq = Lq;
+        a.n_d = n_d;
+        a.flags = flags;
+        const uint16_t *Qp = static_cast<const uint16_t *>(Q) + (size_t)q0 * Lq * dim;
+        float *Sp = scores + (size_t)q0 * ld_scores;
+        int rc = MSIM_OK;
+        switch (g * 10 + tpq) {
+            case 11: rc = launch_stream<1, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 21: rc = launch_stream<2, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 31: rc = launch_stream<3, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 41: rc = launch_stream<4, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 12: rc = launch_stream<2, 2>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 22: rc = launch_stream<4, 2>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 13: rc = launch_stream<3, 3>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            case 14: rc = launch_stream<4, 4>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
+            default: rc = fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", g, tpq);
+        }
+        if (rc) return rc;
+    }
+    return MSIM_OK;
+}
+
+}  // extern "C"

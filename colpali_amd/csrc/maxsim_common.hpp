@@ -1,0 +1,74 @@
+// Shared device helpers for the gfx950 MaxSim kernels (CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msim {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator fragment
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr int kDim = 128;                 // embedding width the kernels are built for
+constexpr int kRowBytes = kDim * 2;       // one bf16 patch row = 256 B = one LDS bank row
+constexpr int kSlabRows = 32;             // MFMA M: patches per slab
+constexpr int kSlabBytes = kSlabRows * kRowBytes;  // 8 KiB
+constexpr int kKSteps = kDim / 16;        // 8 x (32x32x16) MFMAs per 32x32 output tile
+constexpr int kTokTile = 32;              // MFMA N: query tokens per tile
+
+#define MSIM_LDS(p) ((__attribute__((address_space(3))) void *)(p))
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// max over the 16 accumulator registers of one lane, folded into a running max
+__device__ __forceinline__ float fold_max16(float m, const f32x16 &c) {
+    m = max3(m, c[0], c[1]);
+    m = max3(m, c[2], c[3]);
+    m = max3(m, c[4], c[5]);
+    m = max3(m, c[6], c[7]);
+    m = max3(m, c[8], c[9]);
+    m = max3(m, c[10], c[11]);
+    m = max3(m, c[12], c[13]);
+    m = max3(m, c[14], c[15]);
+    return m;
+}
+
+// round-to-nearest-even to bf16, result kept as fp32 (torch's float->bfloat16->float)
+__device__ __forceinline__ float bf16_round(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return __uint_as_float((u | 0x00400000u) & 0xffff0000u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+
+// sum over lanes 0..31 of each 32-lane half (result valid in every lane of the half)
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// 4-byte load through the scalar cache from a wave-uniform, 4-byte aligned address (read-only data)
+__device__ __forceinline__ uint32_t scalar_load_u32(uint64_t addr) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(addr) : "memory");
+    return v;
+}
+
+// C/D layout of v_mfma_f32_32x32x16_bf16: lane holds column (lane & 31) and the 16 rows
+//   row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// LDS image of a slab: 32 rows x 256 B, the 16-byte chunk index XOR-ed with (row & 15) so that the
+// ds_read_b128 of one MFMA operand (32 different rows, the same logical chunk) is bank-conflict free.
+// Byte offset inside the slab of logical chunk `c` of row `r`:
+__device__ __forceinline__ int slab_swizzled_off(int r, int c) { return r * kRowBytes + ((c ^ (r & 15)) << 4); }
+
+}  // namespace msim

@@ -1,0 +1,201 @@
+// K1s -- "stream" MaxSim kernel for gfx950 (MI355X), the HBM-bound regime:
+// a handful of queries (<= 4 token tiles of 32 tokens) scored against a large
+// resident corpus.  Every byte of the corpus is read from HBM exactly once.
+//
+// Reference arithmetic replaced (no [b,c,n,s] tensor is ever materialised):
+//   colpali_engine/utils/processing_utils.py:179
+//       einsum("bnd,csd->bcns", Q, D).max(dim=3)[0].sum(dim=2)
+//
+// Structure (one wave = one independent pipeline, no workgroup barriers at all):
+//   * the query token tiles live in registers for the whole kernel as the MFMA
+//     B operand (32 VGPRs per 32-token tile);
+//   * each wave walks its own documents; a document is streamed in 32-patch
+//     slabs (8 KiB) into a wave-private LDS ring by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, fully
+//     coalesced, bounds-checked by a per-document buffer descriptor);
+//   * the slab image is XOR-swizzled on the SOURCE address so the ds_read_b128
+//     operand fetches are bank-conflict free (cdna_hip_programming.md T2 /
+//     rule 21: linear destination, swizzled source, same swizzle on the read);
+//   * swapped product mfma_f32_32x32x16_bf16(D_slab, Q^T): C layout puts one
+//     query token per lane column, so the max over patches is 8 v_max3 per
+//     tile in registers; one lane<->lane+32 exchange and a 5-step butterfly
+//     sum per document finish the score.
+#include "maxsim_common.hpp"
+
+namespace msim {
+
+struct StreamArgs {
+    long long ld;   // leading dimension of scores
+    int n_q, Lq, n_d;
+    unsigned flags;
+};
+
+constexpr unsigned kFlagRefBf16 = 1u;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// QT  : token tiles (of 32 tokens) held by every wave = n_q * TPQ
+// TPQ : token tiles per query = ceil(Lq / 32)
+// RING: slabs in the wave-private LDS ring
+template <int QT, int TPQ, int RING>
+__global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
+                                                            const uint16_t *__restrict__ D,       // [rows, 128] bf16
+                                                            const int32_t *__restrict__ d_off,    // [n_d + 1]
+                                                            const uint8_t *__restrict__ clamp0,   // [n_d] or null
+                                                            float *__restrict__ scores,           // [n_q, ld]
+                                                            StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wave * (RING * kSlabBytes);
+    const int gw = blockIdx.x * 4 + wave;  // global wave id: this wave owns documents gw, gw+GW, ...
+    const int GW = gridDim.x * 4;
+
+    // ---- query fragments: B operand, lane supplies token (lane&31), k-slice (lane>>5) of each k-step
+    bf16x8 qf[QT][kKSteps];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = t / TPQ;
+        const int row = (t % TPQ) * kTokTile + (lane & 31);
+        const bool valid = row < a.Lq;
+        const uint16_t *p = Q + ((size_t)q * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 16);
+            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    // the query loads are ordinary VMEM loads: retire them before the LDS-DMA stream starts so that the
+    // compiler's own vmcnt waits for them never drain the ring later on
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+
+    // ---- per-lane address constants
+    // LDS-DMA source: wave-instruction i of a slab fills LDS rows 4i..4i+3 linearly; lane (l4 = lane>>4,
+    // l16 = lane&15) lands on physical chunk l16 of row 4i+l4, which must hold logical chunk
+    // l16 ^ (row & 15) = l16 ^ l4 ^ ((i&3)<<2).
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    // operand fetch: lane reads row (lane&31), logical chunk 2*ks + (lane>>5)
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+
+    // ---- producer cursor (wave-uniform): next slab to request
+    int p_idx = gw, p_row = 0, p_len = 0;
+    __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D, 0, 0, 0x00020000);
+    auto p_open = [&]() {  // position on the next non-empty document at or after p_idx
+        while (p_idx < a.n_d) {
+            const int r0 = d_off[p_idx], r1 = d_off[p_idx + 1];
+            p_len = r1 - r0;
+            if (p_len > 0) {
+                p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * kDim), 0,
+                                                           p_len * kRowBytes, 0x00020000);
+                p_row = 0;
+                return;
+            }
+            p_idx += GW;
+        }
+    };
+    p_open();
+    int p_slot = 0;
+    auto produce = [&]() -> bool {  // returns false when the stream is exhausted (nothing issued)
+        if (p_idx >= a.n_d) return false;
+        char *dst = ring + p_slot * kSlabBytes;
+        const int soff = p_row * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3],
+                                                     soff + i * 1024, 0, 0);
+        p_slot = (p_slot + 1 == RING) ? 0 : p_slot + 1;
+        p_row += kSlabRows;
+        if (p_row >= p_len) {
+            p_idx += GW;
+            p_open();
+        }
+        return true;
+    };
+
+    // prologue: RING-1 slabs in flight
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) produce();
+
+    const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
+    int c_slot = 0;
+
+    for (int c_idx = gw; c_idx < a.n_d; c_idx += GW) {
+        const int len = d_off[c_idx + 1] - d_off[c_idx];
+        const int nslab = (len + kSlabRows - 1) / kSlabRows;
+        float m[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) m[t] = -INFINITY;
+
+        for (int s = 0; s < nslab; ++s) {
+            // the slot consumed in the previous iteration is free again: refill it, then wait for slab s
+            const bool issued = produce();
+            if (issued)
+                wait_vmcnt<8 * (RING - 1)>();
+            else
+                wait_vmcnt<0>();
+
+            const char *src = ring + c_slot * kSlabBytes;
+            bf16x8 af[kKSteps];
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+            c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
+
+            const int rows_left = len - s * kSlabRows;  // >= 1
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[t][ks], acc, 0, 0, 0);
+                if (rows_left < kSlabRows) {  // tail slab: rows past the document end do not exist
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
+                }
+                m[t] = fold_max16(m[t], acc);
+            }
+        }
+
+        // ---- document epilogue: combine the two lane halves, clamp, sum over tokens, store
+        // clamp0 is a byte array; fetch the aligned dword around the byte with an explicit scalar load
+        // (a vector byte load would make the compiler wait vmcnt(0), i.e. drain the whole LDS-DMA ring)
+        bool clamp = false;
+        if (clamp0 != nullptr) {
+            const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
+            clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+        }
+        float tile_sum[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float v = fmaxf(m[t], __shfl_xor(m[t], 32));
+            if (clamp) v = fmaxf(v, 0.0f);
+            if (ref_bf16) v = bf16_round(v);
+            tile_sum[t] = half_wave_sum(v);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < QT / TPQ; ++q) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[q * TPQ + tt];
+                if (ref_bf16) tot = bf16_round(tot);
+                scores[(size_t)q * a.ld + c_idx] = tot;
+            }
+        }
+    }
+}
+
+}  // namespace msim

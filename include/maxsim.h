@@ -1,0 +1,135 @@
+/*
+ * include/maxsim.h -- C ABI of libmaxsim_gfx950.so, the MI355X-native MaxSim
+ * (ColBERT late-interaction) scorer.
+ *
+ * The reference (illuin-tech/colpali) has no FFI layer: its hot path is two
+ * Python call sites that delegate to torch.  These entry points are what a
+ * binding for that path binds instead; each cites the reference lines it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows
+ * the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points)
+ *   - plain C types only; device buffers are raw device pointers; `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream);
+ *   - the caller owns every buffer: nothing is allocated, freed or synchronised
+ *     inside a call, so every call is asynchronous on `stream` and can be
+ *     captured in a hipGraph;
+ *   - return 0 on success, a negative MSIM_E* code otherwise (never throws,
+ *     never aborts); msim_last_error() gives a thread-local message;
+ *   - matrices are row-major and contiguous, embeddings are 16-byte aligned.
+ *
+ * Data layout ("packed corpus")
+ *   D        bf16 [total_rows, dim]  every document's patch embeddings, back to back
+ *   d_off    int32 [n_d + 1]         document c owns rows d_off[c] .. d_off[c+1]-1
+ *   d_clamp0 uint8 [n_d] or NULL     1 = the reference would have zero-padded this
+ *                                    document inside its passage block, so a
+ *                                    similarity of exactly 0 also takes part in
+ *                                    every per-token max
+ *                                    (colpali_engine/utils/processing_utils.py:175-178,
+ *                                     pad_sequence(..., padding_value=0))
+ *   Q        bf16 [n_q, Lq, dim]     queries, zero rows = padding (they add 0)
+ */
+#ifndef COLPALI_AMD_MAXSIM_H
+#define COLPALI_AMD_MAXSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSIM_ABI_VERSION 1
+
+/* error codes */
+#define MSIM_OK 0
+#define MSIM_EINVAL (-1)      /* bad argument (null pointer, negative size, misalignment) */
+#define MSIM_EUNSUPPORTED (-2) /* shape/dtype outside what the gfx950 kernels implement */
+#define MSIM_ELAUNCH (-3)      /* HIP reported an error at launch/configuration time */
+
+/* flags for msim_fwd_bf16 / msim_topk_bf16 */
+#define MSIM_FLAG_REF_BF16 0x1u   /* reproduce the reference's bf16-input rounding:
+                                     every similarity rounded to bf16 before the max,
+                                     the token sum rounded to bf16
+                                     (processing_utils.py:179 evaluated on bf16 tensors) */
+#define MSIM_FLAG_ACCUMULATE 0x2u /* scores += result instead of scores = result */
+
+int msim_abi_version(void);
+const char *msim_last_error(void);
+
+/* Number of bytes of scratch msim_fwd_bf16 needs for this problem (0 today for
+ * every supported shape; kept in the ABI so callers size a workspace once). */
+size_t msim_fwd_workspace_bytes(int n_q, int Lq, int n_d, int dim);
+
+/*
+ * scores[q, c] = sum_{i < Lq} max_{j in doc c} <Q[q,i,:], D[j,:]>      (fp32 accumulate)
+ *
+ * Replaces the arithmetic of
+ *   colpali_engine/utils/processing_utils.py:179
+ *       torch.einsum("bnd,csd->bcns", qs_batch, ps_batch).max(dim=3)[0].sum(dim=2)
+ *   colpali_engine/loss/late_interaction_losses.py:297-298 (+ :91)
+ *       torch.einsum("bnd,csd->bcns", q, d) -> amax(dim=3) -> sum(dim=2)
+ * without materialising the [b, c, n, s] similarity tensor.
+ *
+ * scores is fp32 [n_q, ld_scores] (ld_scores >= n_d).  dim must be 128.
+ */
+int msim_fwd_bf16(const void *Q, int n_q, int Lq,
+                  const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                  int n_d, int dim,
+                  float *scores, int64_t ld_scores,
+                  uint32_t flags, void *workspace, void *stream);
+
+/*
+ * Same contraction, additionally reporting for every (q, c, i) the row (relative
+ * to the document) that attains the max; -1 when the zero padding row wins.
+ * This is the routing autograd derives for amax in
+ *   colpali_engine/loss/late_interaction_losses.py:298 -> :91 (scores_raw.amax(dim=dim_max))
+ * pairs: int32 [n_pairs, 2] = (query index, document index).
+ * out_scores: fp32 [n_pairs]; out_argmax: int32 [n_pairs, Lq].
+ */
+int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq,
+                           const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                           int n_d, int dim,
+                           const int32_t *pairs, int n_pairs,
+                           float *out_scores, int32_t *out_argmax, void *stream);
+
+/*
+ * Backward of the contraction for a sparse set of (q, c) pairs with upstream
+ * gradient g[p] = dLoss/dscores[q_p, c_p]:
+ *     dQ[q, i, :]        += g * D[d_off[c] + argmax[p, i], :]
+ *     dD[d_off[c]+a, :]  += g * Q[q, i, :]          (a = argmax[p, i] >= 0)
+ * i.e. what autograd produces for einsum -> amax -> sum
+ * (late_interaction_losses.py:297-298) restricted to the pairs whose upstream
+ * gradient is non-zero (for ColbertPairwiseCELoss, :309-313, two per query).
+ * dQ fp32 [n_q, Lq, dim], dD fp32 [total_rows, dim]; both must be zeroed by the
+ * caller (the call accumulates).  Deterministic: no floating-point atomics.
+ * `pairs` must be sorted by query index for the dQ pass; `order_by_doc` is a
+ * permutation of 0..n_pairs-1 that sorts the pairs by document index.
+ */
+int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq,
+                        const void *D, const int32_t *d_off, int n_d, int dim,
+                        const int32_t *pairs, const int32_t *order_by_doc,
+                        const float *g, const int32_t *argmax, int n_pairs,
+                        float *dQ, float *dD, void *stream);
+
+/*
+ * Row-wise top-k of a score matrix with the deterministic order
+ * (score descending, id ascending).
+ *   scores fp32 [n_q, ld]; the candidates of row q are columns 0..n-1
+ *   ids    int64 [n_q, ld] or NULL: id of column j (NULL: id = id_base + j)
+ *   out_scores fp32 [n_q, k], out_ids int64 [n_q, k]; rows with fewer than k
+ *   candidates are padded with (-inf, -1).
+ * The reference only exposes top-k through the experimental
+ *   colpali_engine/utils/processing_utils.py:189-219 (get_topk_plaid, k=10 default);
+ * retrieval users otherwise call torch.topk on score_multi_vector's output.
+ * Needs msim_topk_workspace_bytes(n_q, n, k) bytes of scratch.
+ */
+size_t msim_topk_workspace_bytes(int n_q, int64_t n, int k);
+int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, int64_t ld,
+                  int k, int64_t id_base,
+                  float *out_scores, int64_t *out_ids, void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLPALI_AMD_MAXSIM_H */

@@ -1,0 +1,136 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle / golden vectors.
+
+Tolerances (written here as the north star demands):
+  * fp32-truth tier: |got - truth| <= 1e-5 * max(|truth|, 1)   (north star allows 1e-3 relative;
+    bf16 products are exact in fp32, only the fp32 summation order differs)
+  * literal REF_BF16 tier: at most one bf16 ulp away from the reference's bf16 CPU output
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import maxsim_oracle as mo
+from tests.conftest import load_golden
+from tests.helpers import config1_inputs, ragged_from_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def close(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    return np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)) <= RTOL
+
+
+def bits_to_bf16(bits: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import colpali_amd
+
+    assert torch.cuda.is_available()
+    colpali_amd._lib.lib()  # must load: no fallback
+    return colpali_amd
+
+
+def test_golden_ragged_all_block_sizes(amd):
+    z = load_golden("score_ragged_d128.npz")
+    qs, ps = ragged_from_golden(z)
+    qs = [bits_to_bf16(q) for q in qs]
+    ps = [bits_to_bf16(p) for p in ps]
+    for bs in z["batch_sizes"]:
+        got = amd.score_multi_vector(qs, ps, batch_size=int(bs), device="cuda:0")
+        assert got.device.type == "cpu" and got.dtype == torch.float32 and got.shape == (len(qs), len(ps))
+        assert close(got.numpy(), z[f"truth_bs{bs}"]), f"batch_size={bs}"
+
+
+def test_golden_config1_truth_and_literal(amd):
+    z = load_golden("score_config1.npz")
+    qs, ps = config1_inputs(z)
+    got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    assert close(got, z["truth"])
+    dev = torch.device("cuda:0")
+    lit = amd.maxsim_scores(amd.pack_queries(qs, dev), amd.pack_passages(ps, dev), ref_bf16=True).cpu().numpy()
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(z["literal"]))) - 7)
+    assert np.all(np.abs(lit - z["literal"]) <= ulp)
+    assert np.mean(lit == z["literal"]) > 0.9
+
+
+def test_golden_negative_similarities_and_zero_padding(amd):
+    z = load_golden("score_negative_clamp.npz")
+    q, short, long_ = (bits_to_bf16(z[k]) for k in ("q_bits", "short_bits", "long_bits"))
+    assert close(amd.score_multi_vector([q], [short], device="cuda:0").numpy(), z["truth_alone"])
+    assert close(amd.score_multi_vector([q], [short, long_], device="cuda:0").numpy(), z["truth_block"])
+    assert close(amd.score_multi_vector([q], [short, long_], batch_size=1, device="cuda:0").numpy(), z["truth_split"])
+
+
+def test_golden_tensor3d_inputs(amd):
+    z = load_golden("score_tensor3d.npz")
+    q = bits_to_bf16(z["q_bits"]).reshape(*z["q_shape"])
+    p = bits_to_bf16(z["p_bits"]).reshape(*z["p_shape"])
+    assert close(amd.score_multi_vector(q, p, device="cuda:0").numpy(), z["truth"])
+
+
+def _random_case(seed, n_q, lq_max, n_d, ld_max, fixed_ld=None):
+    g = torch.Generator().manual_seed(seed)
+    def unit(n):
+        return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16)
+    q_lens = torch.randint(1, lq_max + 1, (n_q,), generator=g).tolist()
+    d_lens = [fixed_ld] * n_d if fixed_ld else torch.randint(1, ld_max + 1, (n_d,), generator=g).tolist()
+    return [unit(n) for n in q_lens], [unit(n) for n in d_lens]
+
+
+def _oracle(qs, ps, batch_size):
+    return mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps],
+                                 batch_size=batch_size, mode="f32")
+
+
+@pytest.mark.parametrize("n_q,lq_max,n_d,ld_max,bs", [
+    (1, 32, 300, 1100, 128),     # single query, ragged long documents, tails of every size
+    (3, 32, 257, 200, 128),
+    (4, 32, 64, 1024, 16),
+    (5, 20, 100, 300, 7),        # more queries than one pass holds
+    (9, 33, 40, 130, 128),       # two token tiles per query
+    (2, 100, 30, 90, 128),       # four token tiles per query
+    (3, 128, 20, 64, 128),
+])
+def test_random_ragged_against_oracle(amd, n_q, lq_max, n_d, ld_max, bs):
+    qs, ps = _random_case(1000 + n_q * 7 + n_d, n_q, lq_max, n_d, ld_max)
+    qs[0] = qs[0][: lq_max] if qs[0].shape[0] >= lq_max else torch.cat(
+        [qs[0], torch.nn.functional.normalize(torch.randn(lq_max - qs[0].shape[0], 128), dim=-1).to(torch.bfloat16)])
+    got = amd.score_multi_vector(qs, ps, batch_size=bs, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, bs))
+
+
+def test_many_documents_more_than_waves(amd):
+    # more documents than resident waves (256 CUs x 4): every wave walks several documents
+    qs, ps = _random_case(5, 2, 32, 5000, 0, fixed_ld=40)
+    got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, 128))
+
+
+def test_empty_inputs_raise_before_any_device_work(amd):
+    with pytest.raises(ValueError, match="No queries provided"):
+        amd.score_multi_vector([], [torch.zeros(2, 128, dtype=torch.bfloat16)], device="cuda:0")
+    with pytest.raises(ValueError, match="No passages provided"):
+        amd.score_multi_vector([torch.zeros(2, 128, dtype=torch.bfloat16)], [], device="cuda:0")
+
+
+def test_transpose_detecting_asymmetric_inputs(amd):
+    # one-hot style rows: a swapped operand / wrong fragment mapping cannot pass this
+    q = torch.zeros(32, 128)
+    d = torch.zeros(70, 128)
+    for i in range(32):
+        q[i, (3 * i) % 128] = 1.0 + i / 64
+        q[i, (5 * i + 1) % 128] = -0.5
+    for j in range(70):
+        d[j, (7 * j) % 128] = 0.25 + j / 128
+        d[j, (3 * j + 2) % 128] = 1.0
+    q, d = q.to(torch.bfloat16), d.to(torch.bfloat16)
+    got = amd.score_multi_vector([q], [d], device="cuda:0").numpy()
+    want = (q.float() @ d.float().T).max(dim=1).values.sum().item()
+    assert abs(got[0, 0] - want) <= 1e-5 * max(abs(want), 1)
