@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py -- MaxSim (query, doc) pairs scored per second on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` (N>1 is launched through
+torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json: "MaxSim (query,doc) pairs scored/sec; achieved HBM GB/s vs peak",
+synthetic 32-token-query x 1024-patch-doc x d=128): every rank holds a resident shard of a
+pre-embedded corpus (packed bf16 blob in HBM, generated on the device); one step scores a query
+batch against the whole shard with the fused gfx950 MaxSim kernel, selects the per-shard top-k
+and (N>1) merges the shards' top-k with one RCCL all-gather.  Weak scaling: the shard per GPU is
+fixed, the corpus grows with N.
+
+The JSON line carries
+  roofline     -- of the dominant kernel (the fused MaxSim kernel), from HIP events recorded on the
+                  launch stream inside the timed region; algorithmic bytes = docs streamed once
+                  per query block (262144/Bq + 4 B per pair)
+  cpu_baseline -- the reference's CPU scorer (oracle/torch_port.py restates
+                  processing_utils.py:163-186 with the same torch calls) timed on this box's
+                  host cores on a bounded sample of the same workload, rank 0, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md): 8.0 TB/s; 6.29 TB/s is the measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=32768, help="documents per GPU shard (1024 patches x 128 bf16 = 256 KiB each)")
+    ap.add_argument("--doc-len", type=int, default=1024)
+    ap.add_argument("--nq", type=int, default=1, help="queries per step (32 tokens each)")
+    ap.add_argument("--q-len", type=int, default=32)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also print per-regime lines (nq = 1,2,4,...) to stderr")
+    return ap.parse_args()
+
+
+def make_shard(n_docs, doc_len, device, seed):
+    """Unit-norm bf16 rows, generated on the device in chunks (no host copy of the corpus exists)."""
+    from colpali_amd.corpus import PackedCorpus
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    blob = torch.empty((n_docs * doc_len, 128), dtype=torch.bfloat16, device=device)
+    chunk = 512
+    for d0 in range(0, n_docs, chunk):
+        n = min(chunk, n_docs - d0)
+        x = torch.randn((n * doc_len, 128), generator=g, device=device, dtype=torch.float32)
+        blob[d0 * doc_len : (d0 + n) * doc_len] = torch.nn.functional.normalize(x, dim=-1).to(torch.bfloat16)
+    lengths = torch.full((n_docs,), doc_len, dtype=torch.int64)
+    offsets = (torch.arange(n_docs + 1, dtype=torch.int64) * doc_len).to(torch.int32).to(device)
+    return PackedCorpus(blob=blob, offsets=offsets, clamp0=None, lengths=lengths)
+
+
+def make_queries(n_q, q_len, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.nn.functional.normalize(torch.randn(n_q, q_len, 128, generator=g), dim=-1).to(torch.bfloat16)
+    return q.to(device)
+
+
+def parity_sample(q, corpus, scores, n_sample=48):
+    """Re-score a random sample of the shard's documents with the CPU oracle."""
+    from oracle import maxsim_oracle as mo
+
+    n = len(corpus)
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(7))[:n_sample].tolist()
+    L = int(corpus.lengths[0])
+    docs = [corpus.blob[i * L : (i + 1) * L].float().cpu().numpy() for i in idx]
+    want = mo.score_multi_vector([x.float().cpu().numpy() for x in q], docs, batch_size=10**9, mode="f32")
+    got = scores[:, idx].float().cpu().numpy()
+    import numpy as np
+
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
+
+
+def cpu_baseline(q_len, doc_len):
+    """Reference CPU scorer (torch port) on a bounded sample: 32 queries x 512 docs, bf16 and fp32."""
+    from oracle import torch_port
+
+    g = torch.Generator().manual_seed(11)
+    n_q, n_d = 32, 512
+    qs = [torch.nn.functional.normalize(torch.randn(q_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_q)]
+    ps = [torch.nn.functional.normalize(torch.randn(doc_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_d)]
+    best = {}
+    for name, cast in (("bf16", lambda t: t), ("fp32", lambda t: t.float())):
+        a, b = [cast(t) for t in qs], [cast(t) for t in ps]
+        torch_port.score_multi_vector_cpu(a[:4], b[:16])
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            torch_port.score_multi_vector_cpu(a, b)
+            ts.append(time.perf_counter() - t0)
+        best[name] = n_q * n_d / min(ts)
+    kind = max(best, key=best.get)
+    return {
+        "value": best[kind], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n_q} queries x {n_d} docs ({q_len}x128 vs {doc_len}x128), reference blocking batch_size=128, "
+                  f"best of 3, torch CPU einsum/max/sum; bf16 inputs {best['bf16']:.0f} pairs/s, fp32 inputs {best['fp32']:.0f} pairs/s",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
+    """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list)."""
+    dev = q.device
+    scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        amd.maxsim_scores(q, corpus, out=scores)
+        if ev is not None:
+            ev[1].record()
+        return amd.shard_topk(scores, topk, corpus.id_base, world, dist) if hasattr(amd, "shard_topk") else None
+
+    for _ in range(warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(evs[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+    return dt, kern_ms, scores
+
+
+def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg):
+    pairs = n_q * n_docs
+    alg_bytes = n_docs * doc_len * 256 + n_q * q_len * 256 + pairs * 4   # docs streamed once per launch
+    flops = 2.0 * n_q * q_len * n_docs * doc_len * 128
+    sec = kern_ms_avg * 1e-3
+    gbs, tf = alg_bytes / sec / 1e9, flops / sec / 1e12
+    hbm_bound_s, mfma_bound_s = alg_bytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS * 1e12)
+    if hbm_bound_s >= mfma_bound_s:
+        roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    else:
+        roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
+    roof.update({"traffic": None, "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
+                 "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops,
+                 "hbm_gbs": gbs, "mfma_tflops": tf})
+    return roof
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import colpali_amd as amd
+
+    amd._lib.lib()  # fail loudly if the HIP library is missing
+    corpus = make_shard(args.docs, args.doc_len, dev, seed=1234 + rank)
+    corpus.id_base = rank * args.docs
+    q = make_queries(args.nq, args.q_len, dev, seed=99)
+    torch.cuda.synchronize()
+
+    dt, kern_ms, scores = run_regime(amd, q, corpus, args.steps, args.warmup, args.topk, world, rank, dist)
+    kern_avg = sum(kern_ms) / len(kern_ms)
+    pairs_per_step = args.nq * args.docs * world
+    out = {
+        "metric": "MaxSim (query,doc) pairs scored/sec",
+        "value": pairs_per_step * args.steps / dt,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.nq} query x {args.q_len} tokens vs resident pre-embedded shard of {args.docs} docs x "
+                        f"{args.doc_len} patches x d=128 bf16 per GPU ({args.docs * args.doc_len * 256 / 2**30:.1f} GiB/GPU), "
+                        f"fused MaxSim + per-shard top-{args.topk}" + (" + RCCL all-gather merge" if world > 1 else ""),
+            "docs_per_gpu": args.docs, "doc_len": args.doc_len, "n_queries": args.nq, "q_len": args.q_len,
+            "top_k": args.topk, "parallelism": f"corpus-sharded x{world}",
+        },
+        "roofline": regime_numbers(args.nq, args.q_len, args.docs, args.doc_len, kern_avg),
+    }
+    if rank == 0 and not args.no_parity:
+        out["parity_max_rel_err_vs_oracle_sample"] = parity_sample(q, corpus, scores)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
+
+    if args.sweep and rank == 0 and world == 1:
+        for nq in (1, 2, 4, 8, 16, 32, 128):
+            qq = make_queries(nq, args.q_len, dev, seed=5)
+            steps = max(3, min(args.steps, 200 // nq))
+            d, km, _ = run_regime(amd, qq, corpus, steps, 2, args.topk, 1, 0, None)
+            r = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(km) / len(km))
+            print(json.dumps({"sweep_nq": nq, "pairs_per_s": nq * args.docs * steps / d, "kernel_ms": r["kernel_ms"],
+                              "hbm_gbs": r["hbm_gbs"], "mfma_tflops": r["mfma_tflops"], "bound": r["bound"], "frac": r["frac"]}),
+                  file=sys.stderr)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
