@@ -7,10 +7,16 @@ The compute lives in hand-written HIP kernels behind a C ABI (include/maxsim.h,
 colpali_amd/csrc/); this package is the thin host-side mirror of the reference interface.
 """
 from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
+from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
 from .scoring import get_torch_device, maxsim_scores, score_multi_vector
 
 __all__ = [
     "PackedCorpus",
+    "ShardedRetriever",
+    "merge_gathered",
+    "shard_range",
+    "shard_topk",
+    "topk",
     "block_clamp0",
     "get_torch_device",
     "maxsim_scores",

@@ -10,6 +10,7 @@
 
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
+#include "topk_select.hip"
 
 namespace {
 
@@ -130,6 +131,74 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *
             default: rc = fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", g, tpq);
         }
         if (rc) return rc;
+    }
+    return MSIM_OK;
+}
+
+// ---------------------------------------------------------------- top-k selection
+static inline long long topk_level_out(long long n, int k) {
+    return ((n + msim::kTopkSeg - 1) / msim::kTopkSeg) * (long long)k;
+}
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+size_t msim_topk_workspace_bytes(int n_q, int64_t n, int k) {
+    if (n_q <= 0 || n <= msim::kTopkSeg || k <= 0) return 0;
+    const long long na = topk_level_out(n, k);
+    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, k) : 0;
+    return align16((size_t)n_q * na * 4) + align16((size_t)n_q * na * 8) + align16((size_t)n_q * nb * 4) +
+           align16((size_t)n_q * nb * 8);
+}
+
+int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, int64_t ld, int k, int64_t id_base,
+                  float *out_scores, int64_t *out_ids, void *workspace, void *stream) {
+    if (n_q < 0 || n < 0 || k <= 0) return fail(MSIM_EINVAL, "bad size (n_q=%d n=%lld k=%d)", n_q, (long long)n, k);
+    if (n_q == 0) return MSIM_OK;
+    if (!out_scores || !out_ids || (n > 0 && !scores)) return fail(MSIM_EINVAL, "null pointer argument");
+    if (k > msim::kTopkMaxK) return fail(MSIM_EUNSUPPORTED, "k=%d > %d", k, msim::kTopkMaxK);
+    if (ld < n) return fail(MSIM_EINVAL, "ld=%lld < n=%lld", (long long)ld, (long long)n);
+    if (n > msim::kTopkSeg && !workspace) return fail(MSIM_EINVAL, "workspace required for n > %d", msim::kTopkSeg);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    const long long na = n > msim::kTopkSeg ? topk_level_out(n, k) : 0;
+    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, k) : 0;
+    char *w = static_cast<char *>(workspace);
+    float *bufs_s[2];
+    int64_t *bufs_i[2];
+    long long bufs_ld[2] = {na, nb};
+    bufs_s[0] = reinterpret_cast<float *>(w);
+    w += align16((size_t)n_q * na * 4);
+    bufs_i[0] = reinterpret_cast<int64_t *>(w);
+    w += align16((size_t)n_q * na * 8);
+    bufs_s[1] = reinterpret_cast<float *>(w);
+    w += align16((size_t)n_q * nb * 4);
+    bufs_i[1] = reinterpret_cast<int64_t *>(w);
+
+    const float *in_s = scores;
+    const int64_t *in_i = ids;
+    long long in_n = n, in_ld = ld, in_base = id_base;
+    int which = 0;
+    for (;;) {
+        const bool last = in_n <= msim::kTopkSeg;
+        const long long segs = last ? 1 : (in_n + msim::kTopkSeg - 1) / msim::kTopkSeg;
+        float *o_s = last ? out_scores : bufs_s[which];
+        int64_t *o_i = last ? out_ids : bufs_i[which];
+        const long long o_ld = last ? k : segs * k;
+        if (!last && o_ld > bufs_ld[which]) return fail(MSIM_ELAUNCH, "internal: top-k level does not fit its buffer");
+        for (int r0 = 0; r0 < n_q; r0 += 65535) {   // grid.y limit
+            const int rows = (n_q - r0 < 65535) ? (n_q - r0) : 65535;
+            hipLaunchKernelGGL(msim::topk_segment_kernel, dim3((unsigned)segs, (unsigned)rows), dim3(msim::kTopkThreads), 0, st,
+                               in_s + (size_t)r0 * in_ld, in_i ? in_i + (size_t)r0 * in_ld : nullptr, in_n, in_ld, in_base, k,
+                               o_s + (size_t)r0 * o_ld, o_i + (size_t)r0 * o_ld, o_ld);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "topk_segment_kernel launch: %s", hipGetErrorString(e));
+        if (last) break;
+        in_s = o_s;
+        in_i = o_i;
+        in_n = o_ld;
+        in_ld = o_ld;
+        in_base = 0;
+        which ^= 1;
     }
     return MSIM_OK;
 }

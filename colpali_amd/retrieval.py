@@ -1,0 +1,108 @@
+"""Sharded-corpus retrieval: fused MaxSim per shard, deterministic top-k, RCCL merge.
+
+The reference has no sharded retrieval (its scorer is single-device and returns the full
+[n_q, n_p] matrix on the CPU, colpali_engine/utils/processing_utils.py:180-186; its only top-k
+API is the experimental get_topk_plaid, :189-219).  This module is the MI355X-native piece
+BASELINE.json config 4 asks for: the pre-embedded corpus is sharded by contiguous id ranges, one
+process per GPU; each rank scores its resident shard and keeps its best k per query; ONE
+all-gather of [n_q, k] (score f32, id i64) over RCCL/xGMI and a k-way merge give every rank the
+global top-k.  The order is total -- (score descending, id ascending) -- so the answer does not
+depend on the number of shards.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .corpus import PackedCorpus
+from .scoring import maxsim_scores
+
+
+def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous id range [lo, hi) of `rank`; the first n_total % world ranks hold one more."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    q, r = divmod(n_total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def topk(scores: torch.Tensor, k: int, id_base: int = 0, ids: Optional[torch.Tensor] = None
+         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Row-wise top-k on the GPU, ordered by (score desc, id asc); pads with (-inf, -1).
+
+    scores: fp32 [n_q, n] (device). ids: optional int64 [n_q, n] candidate ids (default id_base + column).
+    """
+    L = _lib.lib()
+    if scores.dim() != 2 or scores.dtype != torch.float32 or scores.device.type != "cuda":
+        raise ValueError("scores must be a 2-D fp32 tensor on the GPU")
+    if scores.stride(1) != 1 and scores.shape[1] > 1:
+        scores = scores.contiguous()
+    n_q, n = scores.shape
+    ld = scores.stride(0) if n_q > 1 else max(n, 1)
+    if ids is not None:
+        if ids.shape != scores.shape or ids.dtype != torch.int64 or ids.device != scores.device:
+            raise ValueError("ids must be int64 with the shape/device of scores")
+        if not ids.is_contiguous() or ld != max(n, 1):
+            ids = ids.contiguous()
+            scores = scores.contiguous()
+            ld = max(n, 1)
+    dev = scores.device
+    out_s = torch.empty((n_q, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((n_q, k), dtype=torch.int64, device=dev)
+    ws_bytes = L.msim_topk_workspace_bytes(n_q, n, k)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+    with torch.cuda.device(dev):
+        rc = L.msim_topk_f32(_lib.ptr(scores), _lib.ptr(ids), n_q, n, ld, k, id_base, _lib.ptr(out_s), _lib.ptr(out_i),
+                             _lib.ptr(ws), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_topk_f32")
+    return out_s, out_i
+
+
+def merge_gathered(all_s: torch.Tensor, all_i: torch.Tensor, k: int,
+                   select: Callable = topk) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[world, n_q, k] gathered candidates -> global [n_q, k]."""
+    world, n_q, kk = all_s.shape
+    cand_s = all_s.permute(1, 0, 2).reshape(n_q, world * kk).contiguous()
+    cand_i = all_i.permute(1, 0, 2).reshape(n_q, world * kk).contiguous()
+    return select(cand_s, k, 0, cand_i)
+
+
+def shard_topk(scores: torch.Tensor, k: int, id_base: int, world: int = 1, dist=None, group=None,
+               select: Callable = topk) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-shard top-k of a local score matrix, then (world > 1) all-gather + merge.
+
+    `scores` [n_q, n_local]: column j is document id_base + j.  Returns the same global
+    (scores [n_q, k], ids [n_q, k]) on every rank.
+    """
+    loc_s, loc_i = select(scores, k, id_base, None)
+    if world <= 1:
+        return loc_s, loc_i
+    n_q = loc_s.shape[0]
+    all_s = torch.empty((world * n_q, k), dtype=loc_s.dtype, device=loc_s.device)   # rank-major concatenation
+    all_i = torch.empty((world * n_q, k), dtype=loc_i.dtype, device=loc_i.device)
+    dist.all_gather_into_tensor(all_s, loc_s.contiguous(), group=group)   # RCCL all-gather over xGMI (nccl backend)
+    dist.all_gather_into_tensor(all_i, loc_i.contiguous(), group=group)
+    all_s, all_i = all_s.view(world, n_q, k), all_i.view(world, n_q, k)
+    return merge_gathered(all_s, all_i, k, select)
+
+
+class ShardedRetriever:
+    """One instance per process/GPU; holds this rank's resident shard of the corpus."""
+
+    def __init__(self, shard: PackedCorpus, world: int = 1, rank: int = 0, dist=None, group=None,
+                 score_fn: Callable = maxsim_scores, select: Callable = topk):
+        self.shard, self.world, self.rank = shard, world, rank
+        self.dist, self.group = dist, group
+        self._score, self._select = score_fn, select
+        if world > 1 and dist is None:
+            import torch.distributed as dist_mod
+
+            self.dist = dist_mod
+
+    def search(self, queries: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+        """queries: bf16 [n_q, Lq, 128] on this rank's GPU (replicated on every rank)."""
+        scores = self._score(queries, self.shard)
+        return shard_topk(scores, k, self.shard.id_base, self.world, self.dist, self.group, self._select)

@@ -47,12 +47,11 @@ extern "C" {
 #define MSIM_EUNSUPPORTED (-2) /* shape/dtype outside what the gfx950 kernels implement */
 #define MSIM_ELAUNCH (-3)      /* HIP reported an error at launch/configuration time */
 
-/* flags for msim_fwd_bf16 / msim_topk_bf16 */
+/* flags for msim_fwd_bf16 */
 #define MSIM_FLAG_REF_BF16 0x1u   /* reproduce the reference's bf16-input rounding:
                                      every similarity rounded to bf16 before the max,
                                      the token sum rounded to bf16
                                      (processing_utils.py:179 evaluated on bf16 tensors) */
-#define MSIM_FLAG_ACCUMULATE 0x2u /* scores += result instead of scores = result */
 
 int msim_abi_version(void);
 const char *msim_last_error(void);
@@ -78,39 +77,6 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq,
                   int n_d, int dim,
                   float *scores, int64_t ld_scores,
                   uint32_t flags, void *workspace, void *stream);
-
-/*
- * Same contraction, additionally reporting for every (q, c, i) the row (relative
- * to the document) that attains the max; -1 when the zero padding row wins.
- * This is the routing autograd derives for amax in
- *   colpali_engine/loss/late_interaction_losses.py:298 -> :91 (scores_raw.amax(dim=dim_max))
- * pairs: int32 [n_pairs, 2] = (query index, document index).
- * out_scores: fp32 [n_pairs]; out_argmax: int32 [n_pairs, Lq].
- */
-int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq,
-                           const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
-                           int n_d, int dim,
-                           const int32_t *pairs, int n_pairs,
-                           float *out_scores, int32_t *out_argmax, void *stream);
-
-/*
- * Backward of the contraction for a sparse set of (q, c) pairs with upstream
- * gradient g[p] = dLoss/dscores[q_p, c_p]:
- *     dQ[q, i, :]        += g * D[d_off[c] + argmax[p, i], :]
- *     dD[d_off[c]+a, :]  += g * Q[q, i, :]          (a = argmax[p, i] >= 0)
- * i.e. what autograd produces for einsum -> amax -> sum
- * (late_interaction_losses.py:297-298) restricted to the pairs whose upstream
- * gradient is non-zero (for ColbertPairwiseCELoss, :309-313, two per query).
- * dQ fp32 [n_q, Lq, dim], dD fp32 [total_rows, dim]; both must be zeroed by the
- * caller (the call accumulates).  Deterministic: no floating-point atomics.
- * `pairs` must be sorted by query index for the dQ pass; `order_by_doc` is a
- * permutation of 0..n_pairs-1 that sorts the pairs by document index.
- */
-int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq,
-                        const void *D, const int32_t *d_off, int n_d, int dim,
-                        const int32_t *pairs, const int32_t *order_by_doc,
-                        const float *g, const int32_t *argmax, int n_pairs,
-                        float *dQ, float *dD, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

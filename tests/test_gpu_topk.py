@@ -1,0 +1,59 @@
+"""GPU: selection kernel and virtual-shard merge, bit-exact against the oracle ranking."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import topk_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import colpali_amd
+
+    colpali_amd._lib.lib()
+    return colpali_amd
+
+
+@pytest.mark.parametrize("n_q,n,k", [(1, 10, 3), (3, 4096, 10), (2, 4097, 100), (5, 20000, 10), (2, 200000, 100),
+                                     (1, 7, 10), (4, 1, 1), (2, 50000, 1024)])
+def test_topk_matches_oracle_with_ties(amd, n_q, n, k):
+    g = torch.Generator().manual_seed(n + k)
+    s = torch.randn(n_q, n, generator=g)
+    s = (s * 8).round() / 8 if n > 100 else s          # heavy exact ties: the id order must decide
+    s[0, n // 2] = float("-inf")
+    if n > 3:
+        s[0, 1] = 0.0
+        s[0, 2] = -0.0
+    gs, gi = amd.topk(s.cuda(), k, id_base=1000)
+    ws, wi = topk_oracle.topk(s.numpy(), k, id_base=1000)
+    np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(gs.cpu().numpy(), ws)
+
+
+def test_topk_with_explicit_ids_and_padding(amd):
+    s = torch.tensor([[1.0, 5.0, 5.0, -1.0, 5.0, 9.0]])
+    ids = torch.tensor([[70, 30, 10, -1, 20, -1]])
+    gs, gi = amd.topk(s.cuda(), 5, 0, ids.cuda())
+    assert gi.cpu().tolist() == [[10, 20, 30, 70, -1]]
+    assert gs.cpu().tolist()[0][:4] == [5.0, 5.0, 5.0, 1.0] and gs.cpu()[0, 4] == float("-inf")
+
+
+def test_virtual_shards_on_one_gpu_equal_unsharded(amd):
+    g = torch.Generator().manual_seed(3)
+    n_docs, k = 1000, 10
+    docs = [torch.nn.functional.normalize(torch.randn(64, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_docs)]
+    docs[777] = docs[5].clone()
+    q = torch.nn.functional.normalize(torch.randn(6, 32, 128, generator=g), dim=-1).to(torch.bfloat16).cuda()
+    dev = torch.device("cuda:0")
+    full = amd.pack_passages(docs, dev, batch_size=None)
+    fs, fi = amd.topk(amd.maxsim_scores(q, full), k)
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = amd.shard_range(n_docs, world, r)
+            shard = amd.pack_passages(docs[lo:hi], dev, batch_size=None, id_base=lo)
+            parts.append(amd.topk(amd.maxsim_scores(q, shard), k, id_base=lo))
+        ms, mi = amd.merge_gathered(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+        assert torch.equal(mi, fi) and torch.equal(ms, fs)

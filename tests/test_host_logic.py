@@ -1,0 +1,129 @@
+"""CPU tests of the host-side mirror: packing, blocking semantics, argument checks, ABI surface.
+
+No compute call is made here (there is no GPU); the HIP library is only loaded and its
+exported symbols compared with include/maxsim.h.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import colpali_amd
+from colpali_amd import corpus as C
+from oracle import maxsim_oracle as mo
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def bf(n, dim=128, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, dim, generator=g).to(torch.bfloat16)
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "maxsim.h")).read()
+    declared = set(re.findall(r"\b(msim_[a-z0-9_]+)\s*\(", header))
+    assert {"msim_abi_version", "msim_last_error", "msim_fwd_bf16", "msim_topk_f32"} <= declared
+    lib = ctypes.CDLL(colpali_amd._lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/maxsim.h but not exported"
+    lib.msim_abi_version.restype = ctypes.c_int
+    m = re.search(r"#define MSIM_ABI_VERSION (\d+)", header)
+    assert lib.msim_abi_version() == int(m.group(1))
+
+
+def test_abi_rejects_bad_arguments_without_touching_a_gpu():
+    L = colpali_amd._lib.lib()
+    # dim != 128 -> MSIM_EUNSUPPORTED before any device work
+    rc = L.msim_fwd_bf16(16, 1, 32, 16, 16, None, 1, 64, 16, 1, 0, None, None)
+    assert rc == -2 and b"dim" in L.msim_last_error()
+    rc = L.msim_fwd_bf16(None, 1, 32, 16, 16, None, 1, 128, 16, 1, 0, None, None)
+    assert rc == -1
+    rc = L.msim_fwd_bf16(16, 1, 32, 16, 16, None, 4, 128, 16, 2, 0, None, None)   # ld < n_d
+    assert rc == -1
+    assert L.msim_fwd_bf16(16, 0, 32, 16, 16, None, 4, 128, 16, 4, 0, None, None) == 0   # empty problem is a no-op
+    assert L.msim_topk_f32(16, None, 1, 10, 10, 2000, 0, 16, 16, None, None) == -2      # k too large
+    with pytest.raises(NotImplementedError):
+        colpali_amd._lib.check(-2, "x")
+    with pytest.raises(ValueError):
+        colpali_amd._lib.check(-1, "x")
+
+
+def test_block_clamp0_matches_oracle_definition():
+    rng = np.random.default_rng(0)
+    for n, bs in [(1, 128), (7, 3), (128, 128), (129, 128), (300, 7), (10, 1)]:
+        lens = rng.integers(1, 50, size=n)
+        got = C.block_clamp0(torch.from_numpy(lens), bs).numpy()
+        np.testing.assert_array_equal(got, mo.block_clamp0(lens, bs))
+
+
+def test_pack_passages_list_layout_and_flags():
+    ps = [bf(5, seed=1), bf(9, seed=2), bf(9, seed=3), bf(2, seed=4)]
+    pc = C.pack_passages(ps, torch.device("cpu"), batch_size=2)
+    assert len(pc) == 4 and pc.blob.shape == (25, 128) and pc.blob.dtype == torch.bfloat16
+    assert pc.offsets.tolist() == [0, 5, 14, 23, 25] and pc.offsets.dtype == torch.int32
+    assert pc.clamp0.tolist() == [1, 0, 0, 1]
+    assert torch.equal(pc.blob[5:14], ps[1])
+    # equal lengths inside every block: no flag array at all
+    assert C.pack_passages([bf(4), bf(4)], torch.device("cpu")).clamp0 is None
+    assert C.pack_passages(ps, torch.device("cpu"), batch_size=None).clamp0 is None
+
+
+def test_pack_passages_tensor_keeps_physical_zero_rows():
+    p = torch.stack([bf(6, seed=1), bf(6, seed=2)])
+    p[0, 4:] = 0
+    pc = C.pack_passages(p, torch.device("cpu"))
+    assert pc.clamp0 is None and pc.offsets.tolist() == [0, 6, 12]
+    assert torch.equal(pc.blob.view(2, 6, 128), p)
+
+
+def test_pack_queries_pads_with_zero_rows():
+    q = C.pack_queries([bf(3, seed=1), bf(7, seed=2)], torch.device("cpu"))
+    assert q.shape == (2, 7, 128) and torch.count_nonzero(q[0, 3:]) == 0
+
+
+def test_dtype_and_dim_are_errors_not_silent_conversions():
+    with pytest.raises(NotImplementedError, match="dtype"):
+        C.pack_queries([torch.randn(3, 128)], torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="dim"):
+        C.pack_passages([bf(3, dim=64)], torch.device("cpu"))
+
+
+def test_empty_inputs_and_cpu_device_errors_mirror_or_fail_loudly():
+    with pytest.raises(ValueError, match="No queries provided"):
+        colpali_amd.score_multi_vector([], [bf(2)])
+    with pytest.raises(ValueError, match="No passages provided"):
+        colpali_amd.score_multi_vector([bf(2)], [])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        colpali_amd.score_multi_vector([bf(2)], [bf(2)], device="cpu")
+
+
+def test_all_empty_passage_block_raises_like_the_reference():
+    with pytest.raises(RuntimeError, match="non-zero size"):
+        C.pack_passages([bf(0), bf(0), bf(3)], torch.device("cpu"), batch_size=2)
+
+
+def test_get_torch_device_policy():
+    assert colpali_amd.get_torch_device("cpu") == "cpu"
+    assert colpali_amd.get_torch_device("auto") == ("cuda:0" if torch.cuda.is_available() else "cpu")
+
+
+def test_shard_range_partitions_exactly():
+    for n, w in [(10, 3), (1_000_000, 8), (5, 8), (0, 2)]:
+        spans = [colpali_amd.shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "colpali_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
