@@ -10,6 +10,7 @@
 
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
+#include "maxsim_batch.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -80,6 +81,39 @@ int launch_stream(const void *Q, const void *D, const int32_t *d_off, const uint
     return MSIM_OK;
 }
 
+template <int NT, int TPQ>
+int launch_batch(const void *Q, const void *D, const int32_t *d_off, const uint8_t *clamp0, float *scores,
+                 int n_q, int Lq, int n_d, long long ld, unsigned flags, const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_batch_kernel<NT, TPQ>;
+    static std::atomic<int> configured[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!configured[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, msim::kBatchLds);
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", msim::kBatchLds, hipGetErrorString(e));
+        configured[dev].store(1, std::memory_order_release);
+    }
+    msim::BatchArgs a;
+    a.ld = ld;
+    a.n_q = n_q;
+    a.Lq = Lq;
+    a.n_d = n_d;
+    a.flags = flags;
+    const int q_per_block = msim::kBatchWaves * NT / TPQ;
+    a.n_qblocks = (n_q + q_per_block - 1) / q_per_block;
+    // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
+    const int cus_per_xcd = di.cus / 8 > 0 ? di.cus / 8 : 1;
+    const int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
+    a.n_ranges = 8 * sub;
+    const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
+    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), msim::kBatchLds, st, static_cast<const uint16_t *>(Q),
+                       static_cast<const uint16_t *>(D), d_off, clamp0, scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", NT, TPQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -107,32 +141,44 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *
     if (int rc = device_info(&di)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    const int group = 4 / tpq;  // queries per pass of the stream kernel
-    for (int q0 = 0; q0 < n_q; q0 += group) {
-        const int g = (n_q - q0 < group) ? (n_q - q0) : group;
-        msim::StreamArgs a;
-        a.ld = ld_scores;
-        a.n_q = g;
-        a.Lq = Lq;
-        a.n_d = n_d;
-        a.flags = flags;
-        const uint16_t *Qp = static_cast<const uint16_t *>(Q) + (size_t)q0 * Lq * dim;
-        float *Sp = scores + (size_t)q0 * ld_scores;
-        int rc = MSIM_OK;
-        switch (g * 10 + tpq) {
-            case 11: rc = launch_stream<1, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 21: rc = launch_stream<2, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 31: rc = launch_stream<3, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 41: rc = launch_stream<4, 1>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 12: rc = launch_stream<2, 2>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 22: rc = launch_stream<4, 2>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 13: rc = launch_stream<3, 3>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            case 14: rc = launch_stream<4, 4>(Qp, D, d_off, d_clamp0, Sp, a, *di, st); break;
-            default: rc = fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", g, tpq);
+    if (n_q * tpq > 4) {
+        // MFMA-bound regime: K1b, a workgroup holds 8 waves x NT token tiles
+        int rc;
+        if (tpq == 1) {
+            const int nt = (n_q + 7) / 8;
+            if (nt <= 1)      rc = launch_batch<1, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+            else if (nt == 2) rc = launch_batch<2, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+            else if (nt == 3) rc = launch_batch<3, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+            else              rc = launch_batch<4, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+        } else if (tpq == 2) {
+            if (n_q <= 8) rc = launch_batch<2, 2>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+            else          rc = launch_batch<4, 2>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+        } else if (tpq == 3) {
+            rc = launch_batch<3, 3>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
+        } else {
+            rc = launch_batch<4, 4>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
         }
-        if (rc) return rc;
+        return rc;
     }
-    return MSIM_OK;
+
+    // HBM-bound regime: K1s, every wave holds all (<= 4) token tiles and streams its own documents
+    msim::StreamArgs a;
+    a.ld = ld_scores;
+    a.n_q = n_q;
+    a.Lq = Lq;
+    a.n_d = n_d;
+    a.flags = flags;
+    switch (n_q * 10 + tpq) {
+        case 11: return launch_stream<1, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 21: return launch_stream<2, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 31: return launch_stream<3, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 41: return launch_stream<4, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 12: return launch_stream<2, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 22: return launch_stream<4, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 13: return launch_stream<3, 3>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 14: return launch_stream<4, 4>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
+    }
 }
 
 // ---------------------------------------------------------------- top-k selection

@@ -1,0 +1,226 @@
+// K1b -- "batch" MaxSim kernel for gfx950 (MI355X), the MFMA-bound regime:
+// many queries (>= 5 token tiles) scored against a corpus.  Same arithmetic as K1s
+// (colpali_engine/utils/processing_utils.py:179 and
+//  colpali_engine/loss/late_interaction_losses.py:297-298), different blocking.
+//
+// Structure
+//   * workgroup = 8 waves (2 per SIMD); every wave keeps NT <= 4 query token tiles (32 tokens x 128
+//     each) in registers as MFMA B operands -> a workgroup scores a block of up to 32 token tiles
+//     (32 queries of <= 32 tokens) against its document range;
+//   * documents are streamed in chunks of 4 slabs (128 patches, 32 KiB) into a 3-deep LDS ring
+//     shared by the 8 waves: each wave issues 4 of the chunk's 32 LDS-DMA wave-instructions
+//     (buffer_load_dwordx4 ... lds, per-document bounds-checked descriptor, XOR-swizzled source);
+//     ONE raw s_barrier per chunk, LDS-DMA stays in flight across it (counted vmcnt, never 0);
+//   * every wave reads every slab (ds_read_b128, conflict free) and runs 8 MFMAs per (slab, tile);
+//     per-token running max in registers (v_max3), no cross-wave reduction at all;
+//   * arithmetic intensity vs HBM/L2: 32 token tiles per streamed byte -> 1024 FLOP/B.
+//   * grid: blockIdx -> (XCD, slot); the workgroups resident on one XCD stream the SAME document
+//     range for different query blocks, so a document is pulled from HBM once per XCD and served
+//     to the other CUs from that XCD's L2 (placement only affects speed, never results).
+#pragma once
+#include "maxsim_common.hpp"
+#include "maxsim_stream.hip"
+
+namespace msim {
+
+constexpr int kBatchWaves = 8;
+constexpr int kChunkSlabs = 4;
+constexpr int kChunkRows = kChunkSlabs * kSlabRows;      // 128 patches
+constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;    // 32 KiB
+constexpr int kBatchRing = 3;
+constexpr int kBatchLds = kBatchRing * kChunkBytes;      // 96 KiB
+
+struct BatchArgs {
+    long long ld;        // leading dimension of scores
+    int n_q, Lq, n_d;
+    int n_qblocks;       // query blocks (of 8 * NT / TPQ queries)
+    int n_ranges;        // document ranges (multiple of 8: XCD x owns ranges x*sub .. x*sub+sub-1)
+    unsigned flags;
+};
+
+// first document whose start row is >= row (d_off is non-decreasing)
+__device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off, int n_d, long long row) {
+    int lo = 0, hi = n_d;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)d_off[mid] < row) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// NT : token tiles (32 tokens) per wave, 1..4.  TPQ: token tiles per query (NT % TPQ == 0): a wave holds
+// NT/TPQ whole queries, a workgroup 8*NT/TPQ.
+template <int NT, int TPQ>
+__global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
+                                                               const uint16_t *__restrict__ D,
+                                                               const int32_t *__restrict__ d_off,
+                                                               const uint8_t *__restrict__ clamp0,
+                                                               float *__restrict__ scores, BatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- which (query block, document range) is this workgroup?
+    const int sub = a.n_ranges >> 3;                       // ranges per XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int qblock, range;
+    if (sub > 1) { qblock = slot % a.n_qblocks; range = xcd * sub + slot / a.n_qblocks; }
+    else         { qblock = slot;               range = xcd; }
+    if (qblock >= a.n_qblocks || range >= a.n_ranges) return;
+    const long long total_rows = d_off[a.n_d];
+    const int d_lo = lower_bound_doc(d_off, a.n_d, (total_rows * range) / a.n_ranges);
+    const int d_hi = (range + 1 == a.n_ranges) ? a.n_d
+                                                : lower_bound_doc(d_off, a.n_d, (total_rows * (range + 1)) / a.n_ranges);
+    if (d_lo >= d_hi) return;
+
+    // ---- this wave's 4 token tiles
+    static_assert(NT >= 1 && NT <= 4 && NT % TPQ == 0, "a wave holds whole queries");
+    constexpr int q_per_wave = NT / TPQ;
+    const int q_first = (qblock * kBatchWaves + wave) * q_per_wave;   // first query of this wave
+    bf16x8 qf[NT][kKSteps];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = q_first + t / TPQ;
+        const int row = (t % TPQ) * kTokTile + (lane & 31);
+        const bool valid = q < a.n_q && row < a.Lq;
+        const uint16_t *p = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 16);
+            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+    const bool wave_has_queries = q_first < a.n_q;
+
+    // ---- per-lane address constants (same slab image as K1s)
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+    // this wave fills rows 16*(wave&1) .. +15 of slab (wave>>1) of every chunk: 4 wave-instructions of 4 rows
+    const int my_lds_off = (wave >> 1) * kSlabBytes + (wave & 1) * 4096;
+    const int my_row_off = (wave >> 1) * kSlabRows + (wave & 1) * 16;
+
+    // ---- producer cursor over the flattened (document, chunk) sequence of [d_lo, d_hi)
+    int p_idx = d_lo, p_row = 0, p_len = 0;
+    __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D, 0, 0, 0x00020000);
+    auto p_open = [&]() {
+        while (p_idx < d_hi) {
+            const int r0 = d_off[p_idx], r1 = d_off[p_idx + 1];
+            p_len = r1 - r0;
+            if (p_len > 0) {
+                p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * kDim), 0, p_len * kRowBytes,
+                                                           0x00020000);
+                p_row = 0;
+                return;
+            }
+            ++p_idx;
+        }
+    };
+    p_open();
+    int p_slot = 0;
+    auto produce = [&]() -> bool {
+        if (p_idx >= d_hi) return false;
+        char *dst = smem + p_slot * kChunkBytes + my_lds_off;
+        const int soff = (p_row + my_row_off) * kRowBytes;   // rows past the document end read as zeros (bounds check)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, 0);
+        p_slot = (p_slot + 1 == kBatchRing) ? 0 : p_slot + 1;
+        p_row += kChunkRows;
+        if (p_row >= p_len) {
+            ++p_idx;
+            p_open();
+        }
+        return true;
+    };
+
+#pragma unroll
+    for (int i = 0; i < kBatchRing - 1; ++i) produce();
+
+    const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
+    int c_slot = 0;
+
+    for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
+        const int len = d_off[c_idx + 1] - d_off[c_idx];
+        const int nchunk = (len + kChunkRows - 1) / kChunkRows;
+        float m[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m[t] = -INFINITY;
+
+        for (int ch = 0; ch < nchunk; ++ch) {
+            // my share of chunk `ch` has landed once at most (ring-2) later chunks of mine are still in flight
+            if (p_idx < d_hi) wait_vmcnt<4 * (kBatchRing - 2)>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done reading the previous chunk
+            produce();                      // refill the buffer that was read in the previous iteration
+
+            const char *cbuf = smem + c_slot * kChunkBytes;
+            c_slot = (c_slot + 1 == kBatchRing) ? 0 : c_slot + 1;
+            const int rows_in_chunk = len - ch * kChunkRows;   // >= 1
+            if (wave_has_queries) {
+#pragma unroll 1
+                for (int sl = 0; sl < kChunkSlabs; ++sl) {
+                    const int rows_left = rows_in_chunk - sl * kSlabRows;
+                    if (rows_left <= 0) break;
+                    const char *src = cbuf + sl * kSlabBytes;
+                    f32x16 acc[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < kKSteps; ++ks) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[t][ks], acc[t], 0, 0, 0);
+                    }
+                    if (rows_left < kSlabRows) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (acc_row(r, lane) >= rows_left) acc[t][r] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) m[t] = fold_max16(m[t], acc[t]);
+                }
+            }
+        }
+
+        // ---- document epilogue (per wave, its own queries)
+        if (wave_has_queries) {
+            bool clamp = false;
+            if (clamp0 != nullptr) {
+                const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
+                clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+            }
+            float tile_sum[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v = fmaxf(m[t], __shfl_xor(m[t], 32));
+                if (clamp) v = fmaxf(v, 0.0f);
+                if (ref_bf16) v = bf16_round(v);
+                tile_sum[t] = half_wave_sum(v);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int qq = 0; qq < q_per_wave; ++qq) {
+                    float tot = 0.0f;
+#pragma unroll
+                    for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[qq * TPQ + tt];
+                    if (ref_bf16) tot = bf16_round(tot);
+                    if (q_first + qq < a.n_q) scores[(size_t)(q_first + qq) * a.ld + c_idx] = tot;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace msim

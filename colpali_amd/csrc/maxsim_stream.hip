@@ -20,6 +20,7 @@
 //     query token per lane column, so the max over patches is 8 v_max3 per
 //     tile in registers; one lane<->lane+32 exchange and a 5-step butterfly
 //     sum per document finish the score.
+#pragma once
 #include "maxsim_common.hpp"
 
 namespace msim {

@@ -97,6 +97,15 @@ def _oracle(qs, ps, batch_size):
     (9, 33, 40, 130, 128),       # two token tiles per query
     (2, 100, 30, 90, 128),       # four token tiles per query
     (3, 128, 20, 64, 128),
+    (8, 32, 300, 500, 128),      # K1b<1,1>: one token tile per wave
+    (13, 32, 300, 500, 128),     # K1b<2,1>
+    (20, 32, 100, 400, 128),     # K1b<3,1>
+    (33, 32, 500, 300, 128),     # K1b<4,1>, two query blocks, partial last block
+    (100, 32, 200, 1100, 5),     # many queries, long ragged documents, small reference blocks (clamp0 everywhere)
+    (17, 64, 90, 260, 128),      # K1b<4,2>
+    (6, 50, 120, 200, 128),      # K1b<2,2>
+    (10, 96, 60, 200, 128),      # K1b<3,3>
+    (12, 128, 40, 150, 128),     # K1b<4,4>
 ])
 def test_random_ragged_against_oracle(amd, n_q, lq_max, n_d, ld_max, bs):
     qs, ps = _random_case(1000 + n_q * 7 + n_d, n_q, lq_max, n_d, ld_max)
@@ -111,6 +120,31 @@ def test_many_documents_more_than_waves(amd):
     qs, ps = _random_case(5, 2, 32, 5000, 0, fixed_ld=40)
     got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
     assert close(got, _oracle(qs, ps, 128))
+
+
+def test_batch_regime_fixed_length_corpus_and_literal_mode(amd):
+    # 64 queries x 400 pages of 1030 patches (ColPali-v1.2 geometry), truth tier + REF_BF16 tier
+    qs, ps = _random_case(77, 64, 32, 400, 0, fixed_ld=1030)
+    got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, 128))
+    dev = torch.device("cuda:0")
+    lit = amd.maxsim_scores(amd.pack_queries(qs, dev), amd.pack_passages(ps, dev), ref_bf16=True).cpu().numpy()
+    want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], mode="bf16ref")
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-3))) - 7)
+    assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
+
+
+def test_stream_and_batch_kernels_agree_bitwise_on_shared_queries(amd):
+    # the same query scored alone (K1s) and inside a 40-query batch (K1b) must give the same fp32 value:
+    # both kernels run the identical MFMA chain per (token tile, slab) and the same reduction tree
+    qs, ps = _random_case(9, 40, 32, 300, 700)
+    dev = torch.device("cuda:0")
+    corpus = amd.pack_passages(ps, dev)
+    big = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()
+    lq = max(q.shape[0] for q in qs)
+    for i in (0, 7, 39):
+        one = amd.maxsim_scores(amd.pack_queries([torch.cat([qs[i], qs[i].new_zeros(lq - qs[i].shape[0], 128)])], dev), corpus).cpu()
+        assert torch.equal(one[0], big[i])
 
 
 def test_empty_inputs_raise_before_any_device_work(amd):
