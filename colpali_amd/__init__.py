@@ -3,15 +3,25 @@
 Drop-in for the MaxSim hot path of illuin-tech/colpali:
   * score_multi_vector            <- BaseVisualRetrieverProcessor.score_multi_vector
                                      (colpali_engine/utils/processing_utils.py:132-187)
+  * ColbertPairwiseCELoss (+ ColbertLoss, ColbertSigmoidLoss, ColbertModule)
+                                  <- colpali_engine/loss/late_interaction_losses.py:255-313 (:110-164, :401-465, :6-107)
+  * ShardedRetriever / topk       -- sharded-corpus top-k with an RCCL all-gather merge (no reference equivalent)
 The compute lives in hand-written HIP kernels behind a C ABI (include/maxsim.h,
 colpali_amd/csrc/); this package is the thin host-side mirror of the reference interface.
 """
 from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
+from . import loss
+from .loss import ColbertLoss, ColbertModule, ColbertPairwiseCELoss, ColbertSigmoidLoss, maxsim
 from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
 from .scoring import get_torch_device, maxsim_scores, score_multi_vector
 
 __all__ = [
+    "ColbertLoss",
+    "ColbertModule",
+    "ColbertPairwiseCELoss",
+    "ColbertSigmoidLoss",
     "PackedCorpus",
+    "maxsim",
     "ShardedRetriever",
     "merge_gathered",
     "shard_range",

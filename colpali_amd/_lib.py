@@ -39,6 +39,10 @@ def lib() -> ctypes.CDLL:
     L.msim_fwd_workspace_bytes.restype = sz
     L.msim_fwd_bf16.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
     L.msim_fwd_bf16.restype = i32
+    L.msim_pairs_argmax_bf16.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.msim_pairs_argmax_bf16.restype = i32
+    L.msim_pairs_bwd_bf16.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.msim_pairs_bwd_bf16.restype = i32
     L.msim_topk_workspace_bytes.argtypes = [i32, i64, i32]
     L.msim_topk_workspace_bytes.restype = sz
     L.msim_topk_f32.argtypes = [vp, vp, i32, i64, i64, i32, i64, vp, vp, vp, vp]

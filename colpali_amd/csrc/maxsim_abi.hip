@@ -11,6 +11,7 @@
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
+#include "maxsim_pairs.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -114,6 +115,31 @@ int launch_batch(const void *Q, const void *D, const int32_t *d_off, const uint8
     return MSIM_OK;
 }
 
+template <int TPQ>
+int launch_pairs_argmax(const void *Q, const void *D, const int32_t *d_off, const uint8_t *clamp0,
+                               const int32_t *pairs, float *out_scores, int32_t *out_argmax,
+                               const msim::PairsArgs &a, const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ>;
+    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!configured[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+        configured[dev].store(1, std::memory_order_release);
+    }
+    const int wg_needed = (a.n_pairs + 3) / 4;
+    const int wg_cap = di.cus * (di.lds_per_cu / lds);
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, st,
+                       static_cast<const uint16_t *>(Q), static_cast<const uint16_t *>(D), d_off, clamp0, pairs,
+                       out_scores, out_argmax, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_argmax_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -179,6 +205,52 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *
         case 14: return launch_stream<4, 4>(Q, D, d_off, d_clamp0, scores, a, *di, st);
         default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
     }
+}
+
+// ---------------------------------------------------------------- pair lists (training losses)
+int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off,
+                           const uint8_t *d_clamp0, int n_d, int dim, const int32_t *pairs, int n_pairs,
+                           float *out_scores, int32_t *out_argmax, void *stream) {
+    if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0) return fail(MSIM_EINVAL, "negative size");
+    if (n_pairs == 0) return MSIM_OK;
+    if (!Q || !D || !d_off || !pairs) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
+        return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+    if (tpq > 4) return fail(MSIM_EUNSUPPORTED, "Lq=%d: queries longer than 128 tokens are not supported yet", Lq);
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
+    switch (tpq) {
+        case 1: return launch_pairs_argmax<1>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
+        case 2: return launch_pairs_argmax<2>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
+        case 3: return launch_pairs_argmax<3>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
+        default: return launch_pairs_argmax<4>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
+    }
+}
+
+int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
+                        int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g,
+                        const int32_t *argmax, int n_pairs, float *dQ, float *dD, void *stream) {
+    if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
+    if (!Q || !D || !d_off || !dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
+    if (n_pairs > 0 && (!pairs || !order_by_doc || !g || !argmax)) return fail(MSIM_EINVAL, "null pair-list argument");
+    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
+    if (n_q > 0)
+        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dq_kernel, dim3(n_q), dim3(256), 0, st,
+                           static_cast<const uint16_t *>(D), d_off, pairs, g, argmax, dQ, a);
+    const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
+    if (ry > 65535) return fail(MSIM_EUNSUPPORTED, "max_doc_rows=%d too large", max_doc_rows);
+    if (n_d > 0 && ry > 0)
+        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dd_kernel, dim3(n_d, ry), dim3(256), 0, st,
+                           static_cast<const uint16_t *>(Q), d_off, pairs, order_by_doc, g, argmax, dD, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_bwd launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
 }
 
 // ---------------------------------------------------------------- top-k selection

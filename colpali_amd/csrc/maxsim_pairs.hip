@@ -1,0 +1,226 @@
+// Pair-list kernels: MaxSim with arg-max for an explicit list of (query, document) pairs, and the
+// backward of the contraction for such a list.  They serve the training losses:
+//
+//   colpali_engine/loss/late_interaction_losses.py:297-298 (+ :91)
+//       raw = einsum("bnd,csd->bcns", Q, D); scores = raw.amax(dim=3).sum(dim=2)
+//   autograd of that expression: d scores[b,c] / d raw[b,c,n,s] = [s == argmax_s raw[b,c,n,:]]
+//       dQ[b,n,:] = sum_c G[b,c] * D[c, a(b,c,n), :]
+//       dD[c,s,:] = sum_b sum_{n : a(b,c,n) = s} G[b,c] * Q[b,n,:]
+//   ColbertPairwiseCELoss (:309-313) has exactly two non-zero G entries per query (the positive and
+//   the hardest negative), so the backward recomputes the arg-max for those 2B pairs instead of
+//   saving the [B,C,Lq,Ld] similarity tensor the reference keeps alive for autograd.
+//   The paired variants (:235-238, :381-384: "bnd,bsd->bns", "bnd,blsd->blns") are pair lists too.
+//
+// Determinism: no floating-point atomics anywhere; every output element has one owner thread that
+// accumulates in a fixed order.
+// Ties: the first maximal patch wins (the reference's amax backward splits the gradient evenly
+// among exact ties; exact ties only occur at all-zero padding rows, whose gradient the model's
+// `proj * attention_mask` multiplies by zero -- modeling_colpali.py:72, modeling_colqwen2.py:69).
+#pragma once
+#include "maxsim_common.hpp"
+#include "maxsim_stream.hip"
+
+namespace msim {
+
+constexpr int kPairsRing = 4;
+
+struct PairsArgs {
+    int n_q, Lq, n_d, n_pairs;
+};
+
+// One wave per pair (4 pairs per workgroup, wave-private LDS ring as in K1s).
+// TPQ = ceil(Lq / 32) token tiles of the pair's query live in registers.
+template <int TPQ>
+__global__ __launch_bounds__(256) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
+                                                                  const uint16_t *__restrict__ D,
+                                                                  const int32_t *__restrict__ d_off,
+                                                                  const uint8_t *__restrict__ clamp0,
+                                                                  const int32_t *__restrict__ pairs,   // [n_pairs, 2]
+                                                                  float *__restrict__ out_scores,      // [n_pairs] or null
+                                                                  int32_t *__restrict__ out_argmax,    // [n_pairs, Lq] or null
+                                                                  PairsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wave * (kPairsRing * kSlabBytes);
+    const int gw = blockIdx.x * 4 + wave;
+    const int GW = gridDim.x * 4;
+
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+
+    for (int p = gw; p < a.n_pairs; p += GW) {
+        const int q = pairs[2 * p], c = pairs[2 * p + 1];
+        if (q < 0 || q >= a.n_q || c < 0 || c >= a.n_d) continue;   // caller error: leave the outputs untouched
+        // ---- query fragments of this pair
+        bf16x8 qf[TPQ][kKSteps];
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+            const int row = t * kTokTile + (lane & 31);
+            const bool valid = row < a.Lq;
+            const uint16_t *qp = Q + ((size_t)q * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                bf16x8 v = *reinterpret_cast<const bf16x8 *>(qp + ks * 16);
+                qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        wait_vmcnt<0>();   // also retires every LDS-DMA / store of the previous pair
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+
+        const int r0 = d_off[c];
+        const int len = d_off[c + 1] - r0;
+        const int nslab = (len + kSlabRows - 1) / kSlabRows;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * kDim), 0, len * kRowBytes, 0x00020000);
+        int p_s = 0, p_slot = 0, c_slot = 0;
+        auto produce = [&]() -> bool {
+            if (p_s >= nslab) return false;
+            char *dst = ring + p_slot * kSlabBytes;
+            const int soff = p_s * kSlabBytes;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
+            p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
+            ++p_s;
+            return true;
+        };
+#pragma unroll
+        for (int i = 0; i < kPairsRing - 1; ++i) produce();
+
+        float m[TPQ];
+        int am[TPQ];
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) { m[t] = -INFINITY; am[t] = -1; }
+
+        for (int s = 0; s < nslab; ++s) {
+            if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
+            const char *src = ring + c_slot * kSlabBytes;
+            c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
+            bf16x8 af[kKSteps];
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+            const int row0 = s * kSlabRows;
+#pragma unroll
+            for (int t = 0; t < TPQ; ++t) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[t][ks], acc, 0, 0, 0);
+                // rows are visited in increasing order inside a lane, strict '>' keeps the first maximum
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + acc_row(r, lane);
+                    const float v = (row < len) ? acc[r] : -INFINITY;
+                    if (v > m[t]) { m[t] = v; am[t] = row; }
+                }
+            }
+        }
+
+        bool clamp = false;
+        if (clamp0 != nullptr) {
+            const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c;
+            clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+        }
+        float total = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+            const float om = __shfl_xor(m[t], 32);
+            const int oam = __shfl_xor(am[t], 32);
+            float v = m[t];
+            int arg = am[t];
+            if (om > v || (om == v && (unsigned)oam < (unsigned)arg)) { v = om; arg = oam; }
+            if (clamp && !(v >= 0.0f)) { v = 0.0f; arg = -1; }   // the reference's zero padding row wins
+            const int tok = t * kTokTile + (lane & 31);
+            if (out_argmax != nullptr && lane < 32 && tok < a.Lq) out_argmax[(size_t)p * a.Lq + tok] = arg;
+            total += half_wave_sum(v);
+        }
+        if (out_scores != nullptr && lane == 0) out_scores[p] = total;
+    }
+}
+
+// first index k in [0, n) with key(k) >= v, key non-decreasing
+template <class KeyFn>
+__device__ __forceinline__ int lower_bound_idx(int n, int v, KeyFn key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key(mid) < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// dQ[b, i, :] = sum over this query's pairs of g * D[c, argmax, :].  One workgroup per query, one wave per
+// token (strided); lane owns dims 2*lane, 2*lane+1.  `pairs` sorted by query index.
+__global__ __launch_bounds__(256) void maxsim_pairs_bwd_dq_kernel(const uint16_t *__restrict__ D,
+                                                                  const int32_t *__restrict__ d_off,
+                                                                  const int32_t *__restrict__ pairs,
+                                                                  const float *__restrict__ g,
+                                                                  const int32_t *__restrict__ argmax,
+                                                                  float *__restrict__ dQ, PairsArgs a) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lower_bound_idx(a.n_pairs, b, [&](int k) { return pairs[2 * k]; });
+    const int e = lower_bound_idx(a.n_pairs, b + 1, [&](int k) { return pairs[2 * k]; });
+    for (int i = wave; i < a.Lq; i += 4) {
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (int p = s; p < e; ++p) {
+            const int arg = argmax[(size_t)p * a.Lq + i];
+            if (arg < 0) continue;
+            const int c = pairs[2 * p + 1];
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(D + ((size_t)d_off[c] + arg) * kDim + 2 * lane);
+            const float gp = g[p];
+            acc0 += gp * __uint_as_float(w << 16);
+            acc1 += gp * __uint_as_float(w & 0xffff0000u);
+        }
+        *reinterpret_cast<float2 *>(dQ + ((size_t)b * a.Lq + i) * kDim + 2 * lane) = make_float2(acc0, acc1);
+    }
+}
+
+// dD[rows of document c, :]: one workgroup per (document, 64-row range).  The tile is accumulated in LDS;
+// thread t owns column (t & 127) of the rows with parity (t >> 7), and walks this document's
+// (pair, token) entries in a fixed order.  `order_by_doc` lists pair indices sorted by document.
+constexpr int kBwdRows = 64;
+__global__ __launch_bounds__(256) void maxsim_pairs_bwd_dd_kernel(const uint16_t *__restrict__ Q,
+                                                                  const int32_t *__restrict__ d_off,
+                                                                  const int32_t *__restrict__ pairs,
+                                                                  const int32_t *__restrict__ order_by_doc,
+                                                                  const float *__restrict__ g,
+                                                                  const int32_t *__restrict__ argmax,
+                                                                  float *__restrict__ dD, PairsArgs a) {
+    __shared__ float tile[kBwdRows][kDim];
+    const int c = blockIdx.x;
+    const int r_lo = blockIdx.y * kBwdRows;
+    const int len = d_off[c + 1] - d_off[c];
+    if (r_lo >= len) return;
+    const int rows = (len - r_lo < kBwdRows) ? (len - r_lo) : kBwdRows;
+    const int t = threadIdx.x, dim = t & (kDim - 1), half = t >> 7;
+    for (int r = half; r < kBwdRows; r += 2) tile[r][dim] = 0.0f;
+    auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
+    const int s = lower_bound_idx(a.n_pairs, c, doc_of);
+    const int e = lower_bound_idx(a.n_pairs, c + 1, doc_of);
+    for (int k = s; k < e; ++k) {
+        const int p = order_by_doc[k];
+        const int b = pairs[2 * p];
+        const float gp = g[p];
+        for (int i = 0; i < a.Lq; ++i) {
+            const int r = argmax[(size_t)p * a.Lq + i] - r_lo;
+            if (r < 0 || r >= rows || (r & 1) != half) continue;
+            const uint16_t qv = Q[((size_t)b * a.Lq + i) * kDim + dim];
+            tile[r][dim] += gp * __uint_as_float((uint32_t)qv << 16);
+        }
+    }
+    // every row of the tile is owned by one half: no barrier needed between accumulate and write-out
+    float *out = dD + ((size_t)d_off[c] + r_lo) * kDim;
+    for (int r = half; r < rows; r += 2) out[(size_t)r * kDim + dim] = tile[r][dim];
+}
+
+}  // namespace msim

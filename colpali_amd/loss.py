@@ -1,0 +1,225 @@
+"""MI355X-native drop-ins for the reference's late-interaction (ColBERT) losses.
+
+Mirrors colpali_engine/loss/late_interaction_losses.py: `ColbertModule` (:6-107),
+`ColbertLoss` (:110-164), `ColbertPairwiseCELoss` (:255-313), `ColbertSigmoidLoss` (:401-465)
+-- same constructor arguments, same forward signature, no persistent state (checkpoints stay
+interchangeable).  The MaxSim core every one of them starts with,
+
+    raw = einsum("bnd,csd->bcns", Q, D); scores = raw.amax(dim=3).sum(dim=2)      (:297-298, :91)
+
+runs in the fused gfx950 kernels (no [B,C,Lq,Ld] tensor is materialised, forward or backward);
+the [B, C]-sized epilogues (normalisation, filtering, diagonal/topk/softplus, :300-313) are a
+handful of tiny torch ops on the GPU and go through torch autograd.  The backward recomputes the
+per-token arg-max only for the (query, doc) pairs whose upstream gradient is non-zero -- two per
+query for the pairwise loss -- instead of keeping the similarity tensor alive.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F  # noqa: N812
+
+from . import _lib
+from .corpus import PackedCorpus
+from .scoring import maxsim_scores
+
+
+def _dense_corpus(d: torch.Tensor) -> PackedCorpus:
+    """View a dense [C, Ld, 128] tensor as a packed corpus (no copy; zero rows stay physical rows)."""
+    C, Ld, _ = d.shape
+    offsets = torch.arange(C + 1, dtype=torch.int32, device=d.device) * Ld
+    return PackedCorpus(blob=d.view(C * Ld, d.shape[2]), offsets=offsets, clamp0=None,
+                        lengths=torch.full((C,), Ld, dtype=torch.int64))
+
+
+def _check_embeddings(q: torch.Tensor, d: torch.Tensor) -> None:
+    if q.dim() != 3 or d.dim() != 3 or q.shape[2] != d.shape[2]:
+        raise ValueError("expected query_embeddings [B, Lq, dim] and doc_embeddings [C, Ld, dim]")
+    if q.dtype != d.dtype:
+        raise RuntimeError(f"expected query and doc embeddings of one dtype, got {q.dtype} and {d.dtype}")
+    if q.device.type != "cuda" or d.device != q.device:
+        raise RuntimeError("colpali_amd losses run on an MI355X only (no CPU fallback): move the embeddings to the GPU")
+    if q.dtype != torch.bfloat16 or q.shape[2] != 128:
+        raise NotImplementedError(
+            f"colpali_amd losses take bf16 embeddings of dim 128 (got {q.dtype}, dim {q.shape[2]}); "
+            "converting silently would change the loss, so this is an error")
+
+
+class _MaxSim(torch.autograd.Function):
+    """scores[b, c] = sum_n max_s <Q[b,n], D[c,s]> with a sparse recompute backward."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+        qc, dc = q.contiguous(), d.contiguous()
+        corpus = _dense_corpus(dc)
+        scores = maxsim_scores(qc, corpus)
+        ctx.save_for_backward(qc, dc, corpus.offsets)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores: torch.Tensor):
+        qc, dc, offsets = ctx.saved_tensors
+        dq, dd = maxsim_backward(qc, dc, offsets, grad_scores)
+        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None)
+
+
+def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pairs: torch.Tensor,
+                 want_scores: bool = True, want_argmax: bool = True):
+    """MaxSim (+ arg-max routing) for an int32 [n_pairs, 2] list of (query, doc) index pairs."""
+    L = _lib.lib()
+    B, Lq, dim = qc.shape
+    C = offsets.numel() - 1
+    n_pairs = pairs.shape[0]
+    dev = qc.device
+    scores = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if want_scores else None
+    argmax = torch.empty((n_pairs, Lq), dtype=torch.int32, device=dev) if want_argmax else None
+    with torch.cuda.device(dev):
+        rc = L.msim_pairs_argmax_bf16(_lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), None, C, dim,
+                                      _lib.ptr(pairs), n_pairs, _lib.ptr(scores), _lib.ptr(argmax),
+                                      _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_pairs_argmax_bf16")
+    return scores, argmax
+
+
+def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor):
+    """(dQ fp32 [B,Lq,128], dD fp32 [C,Ld,128]) for upstream dLoss/dscores [B, C]."""
+    L = _lib.lib()
+    B, Lq, dim = qc.shape
+    C, Ld, _ = dc.shape
+    dev = qc.device
+    g = grad_scores.to(torch.float32)
+    pairs64 = torch.nonzero(g)                        # row-major order = sorted by query, then doc (one host sync)
+    n_pairs = pairs64.shape[0]
+    dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
+    dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
+    if n_pairs == 0:
+        return dq.zero_(), dd.zero_()
+    gp = g[pairs64[:, 0], pairs64[:, 1]].contiguous()
+    pairs = pairs64.to(torch.int32).contiguous()
+    order = torch.sort(pairs64[:, 1], stable=True).indices.to(torch.int32).contiguous()
+    _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
+    with torch.cuda.device(dev):
+        rc = L.msim_pairs_bwd_bf16(_lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
+                                   _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), n_pairs,
+                                   _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_pairs_bwd_bf16")
+    return dq, dd
+
+
+def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torch.Tensor:
+    """Differentiable fused MaxSim: fp32 [B, C] (late_interaction_losses.py:297-298 without the 4-D tensor)."""
+    _check_embeddings(query_embeddings, doc_embeddings)
+    return _MaxSim.apply(query_embeddings, doc_embeddings)
+
+
+class ColbertModule(torch.nn.Module):
+    """Shared hyper-parameters and [B, C]-sized helpers (late_interaction_losses.py:6-107)."""
+
+    def __init__(self, max_batch_size: int = 1024, tau: float = 0.1, norm_tol: float = 1e-3,
+                 filter_threshold: float = 0.95, filter_factor: float = 0.5):
+        super().__init__()
+        # non-persistent, like the reference (:27): the module contributes nothing to a state_dict
+        self.register_buffer("idx_buffer", torch.arange(max_batch_size), persistent=False)
+        self.tau = tau
+        self.norm_tol = norm_tol
+        self.filter_threshold = filter_threshold
+        self.filter_factor = filter_factor
+
+    def _get_idx(self, batch_size: int, offset: int, device: torch.device):
+        rows = self.idx_buffer[:batch_size].to(device)
+        return rows, rows + offset
+
+    def _smooth_max(self, scores: torch.Tensor, dim: int) -> torch.Tensor:
+        return torch.logsumexp(scores / self.tau, dim=dim) * self.tau
+
+    def _apply_normalization(self, scores: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        out = scores / (lengths.unsqueeze(1) if scores.ndim == 2 else lengths)
+        lo, hi = torch.aminmax(out)
+        if lo < -self.norm_tol or hi > 1 + self.norm_tol:   # the reference only prints here (:64-70)
+            print(f"Scores out of bounds after normalization: min={lo.item():.4f}, max={hi.item():.4f}, tol={self.norm_tol}")
+        return out
+
+    def _aggregate(self, scores_raw: torch.Tensor, use_smooth_max: bool, dim_max: int, dim_sum: int) -> torch.Tensor:
+        reduced = self._smooth_max(scores_raw, dim=dim_max) if use_smooth_max else scores_raw.amax(dim=dim_max)
+        return reduced.sum(dim=dim_sum)
+
+    def _filter_high_negatives(self, scores: torch.Tensor, pos_idx: torch.Tensor) -> None:
+        rows = self.idx_buffer[: scores.size(0)].to(scores.device)
+        limit = self.filter_threshold * scores[rows, pos_idx].unsqueeze(1)
+        too_high = scores > limit
+        too_high[rows, pos_idx] = False
+        scores[too_high] *= self.filter_factor
+
+    # -- shared front end of every in-batch loss: lengths, fused MaxSim, optional normalisation / filtering
+    def _inbatch_scores(self, query_embeddings, doc_embeddings, offset):
+        if self.use_smooth_max:
+            raise NotImplementedError("use_smooth_max=True (tau * logsumexp over patches) has no gfx950 kernel yet")
+        lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)          # :296 -- first component, not a norm test
+        scores = maxsim(query_embeddings, doc_embeddings)
+        if self.normalize_scores:
+            scores = self._apply_normalization(scores, lengths)
+        rows, pos_idx = self._get_idx(scores.size(0), offset, scores.device)
+        if self.pos_aware_negative_filtering:
+            self._filter_high_negatives(scores, pos_idx)
+        return scores, rows, pos_idx
+
+
+class ColbertPairwiseCELoss(ColbertModule):
+    """Pairwise softplus loss on the hardest in-batch negative (late_interaction_losses.py:255-313)."""
+
+    def __init__(self, temperature: float = 1.0, normalize_scores: bool = True, use_smooth_max: bool = False,
+                 pos_aware_negative_filtering: bool = False, max_batch_size: int = 1024, tau: float = 0.1,
+                 norm_tol: float = 1e-3, filter_threshold: float = 0.95, filter_factor: float = 0.5):
+        super().__init__(max_batch_size, tau, norm_tol, filter_threshold, filter_factor)
+        self.temperature = temperature
+        self.normalize_scores = normalize_scores
+        self.use_smooth_max = use_smooth_max
+        self.pos_aware_negative_filtering = pos_aware_negative_filtering
+
+    def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
+        scores, _, _ = self._inbatch_scores(query_embeddings, doc_embeddings, offset)
+        pos = scores.diagonal(offset=offset)                            # :309
+        best2 = scores.topk(2, dim=1).values                            # :310
+        neg = torch.where(best2[:, 0] == pos, best2[:, 1], best2[:, 0])  # :311 exact-equality selection
+        loss = F.softplus((neg - pos) / self.temperature).mean()        # :313
+        return loss.to(query_embeddings.dtype)
+
+
+class ColbertLoss(ColbertModule):
+    """InfoNCE over in-batch documents (late_interaction_losses.py:110-164)."""
+
+    def __init__(self, temperature: float = 0.02, normalize_scores: bool = True, use_smooth_max: bool = False,
+                 pos_aware_negative_filtering: bool = False, max_batch_size: int = 1024, tau: float = 0.1,
+                 norm_tol: float = 1e-3, filter_threshold: float = 0.95, filter_factor: float = 0.5):
+        super().__init__(max_batch_size, tau, norm_tol, filter_threshold, filter_factor)
+        self.temperature = temperature
+        self.normalize_scores = normalize_scores
+        self.use_smooth_max = use_smooth_max
+        self.pos_aware_negative_filtering = pos_aware_negative_filtering
+        self.ce_loss = torch.nn.CrossEntropyLoss()
+
+    def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
+        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset)
+        return self.ce_loss(scores / self.temperature, pos_idx).to(query_embeddings.dtype)   # :164
+
+
+class ColbertSigmoidLoss(ColbertModule):
+    """Sigmoid loss over the in-batch square (late_interaction_losses.py:401-465)."""
+
+    def __init__(self, temperature: float = 0.02, normalize_scores: bool = True, use_smooth_max: bool = False,
+                 pos_aware_negative_filtering: bool = False, max_batch_size: int = 1024, tau: float = 0.1,
+                 norm_tol: float = 1e-3, filter_threshold: float = 0.95, filter_factor: float = 0.5):
+        super().__init__(max_batch_size, tau, norm_tol, filter_threshold, filter_factor)
+        self.temperature = temperature
+        self.normalize_scores = normalize_scores
+        self.use_smooth_max = use_smooth_max
+        self.pos_aware_negative_filtering = pos_aware_negative_filtering
+        self.ce_loss = torch.nn.CrossEntropyLoss()
+
+    def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
+        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset)
+        n = scores.size(0)
+        sign = -torch.ones(n * n, device=scores.device)                 # :457-459: +1 on the positives of the flattened square
+        sign[pos_idx * (n + 1)] = 1.0
+        flat = scores.view(-1) / self.temperature                       # :462 (requires C == B, like the reference)
+        return F.softplus(-flat * sign).mean().to(query_embeddings.dtype)

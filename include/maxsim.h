@@ -79,6 +79,41 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq,
                   uint32_t flags, void *workspace, void *stream);
 
 /*
+ * MaxSim for an explicit list of (query, document) pairs, optionally reporting for every
+ * (pair, query token) the document row (relative to the document) that attains the max;
+ * -1 when the reference's zero padding row wins (d_clamp0).  First maximum wins on ties.
+ * This is the routing autograd derives for amax in
+ *   colpali_engine/loss/late_interaction_losses.py:298 -> :91 (scores_raw.amax(dim=dim_max)),
+ * and the forward of the paired contractions "bnd,bsd->bns" / "bnd,blsd->blns" (:235-238, :381-384).
+ * pairs: int32 [n_pairs, 2] = (query index, document index).
+ * out_scores: fp32 [n_pairs] or NULL; out_argmax: int32 [n_pairs, Lq] or NULL.  Lq <= 128.
+ */
+int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq,
+                           const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                           int n_d, int dim,
+                           const int32_t *pairs, int n_pairs,
+                           float *out_scores, int32_t *out_argmax, void *stream);
+
+/*
+ * Backward of the contraction for a sparse set of (q, c) pairs with upstream gradient
+ * g[p] = dLoss/dscores[q_p, c_p]:
+ *     dQ[q, i, :]        = sum_p g[p] * D[d_off[c_p] + argmax[p, i], :]
+ *     dD[d_off[c]+r, :]  = sum_{p, i : c_p = c, argmax[p, i] = r} g[p] * Q[q_p, i, :]
+ * i.e. what autograd produces for einsum -> amax -> sum
+ * (late_interaction_losses.py:297-298) restricted to the pairs whose upstream gradient is
+ * non-zero (for ColbertPairwiseCELoss, :309-313, two per query).
+ * dQ fp32 [n_q, Lq, dim] and dD fp32 [total_rows, dim] are fully overwritten (rows without a
+ * contribution are set to 0).  Deterministic: no floating-point atomics.
+ * `pairs` must be sorted by query index; `order_by_doc` is a permutation of 0..n_pairs-1 that
+ * sorts the pairs by document index (stable); `max_doc_rows` >= the longest document.
+ */
+int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq,
+                        const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
+                        const int32_t *pairs, const int32_t *order_by_doc,
+                        const float *g, const int32_t *argmax, int n_pairs,
+                        float *dQ, float *dD, void *stream);
+
+/*
  * Row-wise top-k of a score matrix with the deterministic order
  * (score descending, id ascending).
  *   scores fp32 [n_q, ld]; the candidates of row q are columns 0..n-1

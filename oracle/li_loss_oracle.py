@@ -1,0 +1,61 @@
+"""float64 torch restatement of the reference's in-batch late-interaction losses -- TEST INFRASTRUCTURE ONLY.
+
+Restates colpali_engine/loss/late_interaction_losses.py
+    :296-313  ColbertPairwiseCELoss.forward
+    :152-164  ColbertLoss.forward
+    :444-465  ColbertSigmoidLoss.forward
+    :40-107   helper semantics (normalisation, pos-aware filtering)
+with the materialised einsum exactly as the reference writes it, in float64 so that it can serve as
+truth for both fp32 (golden vectors) and bf16-valued inputs.  Gradients come from torch autograd on
+this restatement.  Pinned by tests/test_loss_oracle_golden.py against tests/golden/loss_small.npz
+(outputs of the live reference modules).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F  # noqa: N812
+
+
+def _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter_threshold, filter_factor):
+    lengths = (q[:, :, 0] != 0).sum(dim=1)                                   # :296
+    raw = torch.einsum("bnd,csd->bcns", q, d)                                # :297
+    scores = raw.amax(dim=3).sum(dim=2)                                      # :298 -> :91
+    if normalize_scores:
+        scores = scores / lengths.unsqueeze(1)                               # :58
+    B = scores.size(0)
+    idx = torch.arange(B)
+    pos_idx = idx + offset                                                   # :37
+    if pos_aware_negative_filtering:                                         # :100-107
+        pos = scores[idx, pos_idx]
+        mask = scores > filter_threshold * pos.unsqueeze(1)
+        mask[idx, pos_idx] = False
+        scores = torch.where(mask, scores * filter_factor, scores)
+    return scores, pos_idx
+
+
+def loss_and_grads(kind: str, Q: torch.Tensor, D: torch.Tensor, offset: int = 0, temperature=None,
+                   normalize_scores: bool = True, pos_aware_negative_filtering: bool = False,
+                   filter_threshold: float = 0.95, filter_factor: float = 0.5):
+    """kind in {"pairwise", "infonce", "sigmoid"} -> (loss, dQ, dD) as float64 tensors."""
+    q = Q.detach().double().requires_grad_(True)
+    d = D.detach().double().requires_grad_(True)
+    scores, pos_idx = _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter_threshold, filter_factor)
+    if kind == "pairwise":
+        T = 1.0 if temperature is None else temperature
+        pos = scores.diagonal(offset=offset)                                 # :309
+        top2 = scores.topk(2, dim=1).values                                  # :310
+        neg = torch.where(top2[:, 0] == pos, top2[:, 1], top2[:, 0])         # :311
+        loss = F.softplus((neg - pos) / T).mean()                            # :313
+    elif kind == "infonce":
+        T = 0.02 if temperature is None else temperature
+        loss = F.cross_entropy(scores / T, pos_idx)                          # :164
+    elif kind == "sigmoid":
+        T = 0.02 if temperature is None else temperature
+        n = scores.size(0)
+        sign = -torch.ones(n * n, dtype=scores.dtype)
+        sign[pos_idx * (n + 1)] = 1.0                                        # :456-459
+        loss = F.softplus(-(scores.reshape(-1) / T) * sign).mean()           # :462-465
+    else:
+        raise ValueError(kind)
+    loss.backward()
+    return loss.detach(), q.grad, d.grad

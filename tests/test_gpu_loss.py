@@ -1,0 +1,125 @@
+"""GPU: the loss drop-ins (fused MaxSim forward + sparse recompute backward) against the float64 oracle.
+
+Inputs are bf16 (what the models emit under HF bf16 training); the oracle runs on the exact fp32
+upcast in float64.  Tolerances: loss 1e-5 relative; gradients are returned in bf16 like autograd
+would, so they are compared after the same rounding with one bf16 ulp of slack (2^-8 relative) plus
+1e-6 absolute.  Gradients at all-zero padding rows are excluded: the reference splits a gradient
+evenly among exact ties, which only occur there, and the model masks those positions
+(modeling_colpali.py:72) -- see DESIGN.md "tie semantics".
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import li_loss_oracle as lo
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import colpali_amd
+
+    colpali_amd._lib.lib()
+    return colpali_amd
+
+
+def grads_close(got, want, mask=None):
+    got = got.float().cpu()
+    want = want.float()
+    want_bf = want.to(torch.bfloat16).float()
+    tol = want.abs() * 2.0**-7 + 1e-6
+    bad = (got - want_bf).abs() > tol
+    if mask is not None:
+        bad &= mask
+    return int(bad.sum()) == 0
+
+
+VARIANTS = {
+    "default": dict(),
+    "nonorm": dict(normalize_scores=False),
+    "nonorm_T05": dict(normalize_scores=False, temperature=0.5),
+    "filter": dict(normalize_scores=False, pos_aware_negative_filtering=True),
+}
+
+
+@pytest.mark.parametrize("cls,kind", [("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")])
+@pytest.mark.parametrize("offset", [0, 6])
+def test_small_golden_shapes_loss_and_grads(amd, cls, kind, offset):
+    z = load_golden("loss_small.npz")
+    Qb = torch.from_numpy(z["Q"]).to(torch.bfloat16)
+    Db = torch.from_numpy(z["D"]).to(torch.bfloat16)
+    q_real = (Qb.float().abs().sum(-1, keepdim=True) > 0)
+    d_real = (Db.float().abs().sum(-1, keepdim=True) > 0)
+    for vname, kw in VARIANTS.items():
+        want_loss, want_dq, want_dd = lo.loss_and_grads(kind, Qb.float(), Db.float(), offset=offset, **kw)
+        q = Qb.cuda().requires_grad_(True)
+        d = Db.cuda().requires_grad_(True)
+        loss = getattr(amd, cls)(**kw)(q, d, offset=offset)
+        assert loss.dtype == torch.bfloat16 and loss.dim() == 0
+        assert abs(float(loss) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6, (cls, vname)
+        loss.backward()
+        assert q.grad.dtype == torch.bfloat16 and q.grad.shape == q.shape and d.grad.shape == d.shape
+        assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq)), (cls, vname, "dQ")
+        assert grads_close(d.grad, want_dd, d_real.expand_as(want_dd)), (cls, vname, "dD")
+
+
+def test_fp32_scores_of_the_fused_forward_match_oracle_tightly(amd):
+    z = load_golden("loss_small.npz")
+    Qb = torch.from_numpy(z["Q"]).to(torch.bfloat16)
+    Db = torch.from_numpy(z["D"]).to(torch.bfloat16)
+    s = amd.loss.maxsim(Qb.cuda(), Db.cuda()).cpu().double()
+    want = torch.einsum("bnd,csd->bcns", Qb.double(), Db.double()).amax(3).sum(2)
+    assert torch.max((s - want).abs() / want.abs().clamp_min(1.0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,Lq,Ld,offset", [(16, 64, 32, 780, 0), (16, 64, 32, 780, 32), (8, 40, 45, 300, 16)])
+def test_training_shapes_pairwise(amd, B, C, Lq, Ld, offset):
+    g = torch.Generator().manual_seed(B * 1000 + C + offset)
+    Q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1)
+    for b in range(B):   # plant the positives
+        D[offset + b, 5 : 5 + Lq] = torch.nn.functional.normalize(Q[b] + 0.5 * torch.randn(Lq, 128, generator=g), dim=-1)
+    Qb, Db = Q.to(torch.bfloat16), D.to(torch.bfloat16)
+    want_loss, want_dq, want_dd = lo.loss_and_grads("pairwise", Qb.float(), Db.float(), offset=offset, normalize_scores=False)
+    q, d = Qb.cuda().requires_grad_(True), Db.cuda().requires_grad_(True)
+    loss = amd.ColbertPairwiseCELoss(normalize_scores=False)(query_embeddings=q, doc_embeddings=d, offset=offset)
+    assert abs(float(loss) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6
+    loss.backward()
+    assert grads_close(q.grad, want_dq) and grads_close(d.grad, want_dd)
+    # 2-sparse upstream gradient: at most 2 documents per query receive any gradient
+    touched = (d.grad.float().abs().sum(dim=(1, 2)) > 0).sum().item()
+    assert touched <= 2 * B
+
+
+def test_pairs_argmax_matches_oracle_routing(amd):
+    from oracle import maxsim_oracle as mo
+
+    g = torch.Generator().manual_seed(4)
+    Q = torch.nn.functional.normalize(torch.randn(5, 40, 128, generator=g), dim=-1).to(torch.bfloat16)
+    D = torch.nn.functional.normalize(torch.randn(7, 100, 128, generator=g), dim=-1).to(torch.bfloat16)
+    pairs = torch.tensor([[0, 0], [0, 6], [1, 3], [4, 2], [4, 3], [4, 6]], dtype=torch.int32)
+    offs = (torch.arange(8, dtype=torch.int32) * 100)
+    s, am = amd.loss.maxsim_pairs(Q.cuda(), D.cuda(), offs.cuda(), pairs.cuda())
+    ws, wam = mo.maxsim_argmax_f32(Q.float().numpy(), D.float().numpy().reshape(-1, 128), offs.numpy(), None)
+    for k, (b, c) in enumerate(pairs.tolist()):
+        assert abs(float(s[k]) - ws[b, c]) < 1e-5 * max(1.0, abs(ws[b, c]))
+        np.testing.assert_array_equal(am[k].cpu().numpy(), wam[b, c])
+
+
+def test_reference_known_answers_on_gpu(amd):
+    # tests/loss/test_li_losses.py:137-147 and :76-88 restated with dim=128 bf16 tensors on the GPU
+    q = torch.zeros(2, 1, 128, dtype=torch.bfloat16, device="cuda")
+    loss = amd.ColbertPairwiseCELoss(temperature=1.0, normalize_scores=False)(q, q.clone())
+    assert abs(float(loss) - np.log(2.0)) < 4e-3
+    q3 = torch.zeros(3, 1, 128, dtype=torch.bfloat16, device="cuda")
+    loss = amd.ColbertLoss(temperature=1.0, normalize_scores=False)(q3, q3.clone())
+    assert abs(float(loss) - np.log(3.0)) < 8e-3
+
+
+def test_loss_modules_have_no_state_and_reject_cpu(amd):
+    m = amd.ColbertPairwiseCELoss()
+    assert len(m.state_dict()) == 0 and len(list(m.parameters())) == 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 1, 128, dtype=torch.bfloat16), torch.zeros(2, 1, 128, dtype=torch.bfloat16))

@@ -1,0 +1,40 @@
+"""Pin oracle/li_loss_oracle.py against the golden outputs of the live reference loss modules (CPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import li_loss_oracle as lo
+from tests.conftest import load_golden
+
+VARIANTS = {
+    "default": dict(),
+    "nonorm": dict(normalize_scores=False),
+    "nonorm_T05": dict(normalize_scores=False, temperature=0.5),
+    "filter": dict(normalize_scores=False, pos_aware_negative_filtering=True),
+}
+
+
+@pytest.mark.parametrize("cls,kind", [("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")])
+@pytest.mark.parametrize("offset", [0, 6])
+def test_loss_value_and_gradients_match_the_reference(cls, kind, offset):
+    z = load_golden("loss_small.npz")
+    Q, D = torch.from_numpy(z["Q"]), torch.from_numpy(z["D"])
+    for vname, kw in VARIANTS.items():
+        key = f"{cls}_{vname}_off{offset}"
+        if key + "_loss" not in z.files:
+            continue
+        loss, dQ, dD = lo.loss_and_grads(kind, Q, D, offset=offset, **kw)
+        assert abs(float(loss) - float(z[key + "_loss"])) < 2e-6 * max(1.0, abs(float(loss))), key
+        np.testing.assert_allclose(dQ.numpy(), z[key + "_dQ"], rtol=2e-4, atol=2e-6, err_msg=key)
+        np.testing.assert_allclose(dD.numpy(), z[key + "_dD"], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
+def test_known_answers_from_the_reference_unit_tests():
+    # tests/loss/test_li_losses.py:137-147 (pairwise, zeros -> ln 2) and :76-88 (InfoNCE, zeros -> ln B)
+    z = load_golden("loss_kat.npz")
+    q = torch.zeros(2, 1, 3)
+    loss, _, _ = lo.loss_and_grads("pairwise", q, q.clone(), normalize_scores=False, temperature=1.0)
+    assert abs(float(loss) - float(z["ln2"])) < 1e-7 and abs(float(z["pairwise_zero"]) - float(z["ln2"])) < 1e-7
+    q3 = torch.zeros(3, 1, 4)
+    loss, _, _ = lo.loss_and_grads("infonce", q3, q3.clone(), normalize_scores=False, temperature=1.0)
+    assert abs(float(loss) - np.log(3.0)) < 1e-7
