@@ -41,14 +41,17 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--docs", type=int, default=32768, help="documents per GPU shard (1024 patches x 128 bf16 = 256 KiB each)")
+    ap.add_argument("--docs", type=int, default=125000,
+                    help="documents per GPU shard (1024 patches x 128 bf16 = 256 KiB each); 125000 = the 1M-doc corpus of "
+                         "BASELINE config 4 over 8 GPUs")
     ap.add_argument("--doc-len", type=int, default=1024)
-    ap.add_argument("--nq", type=int, default=1, help="queries per step (32 tokens each)")
+    ap.add_argument("--nq", type=int, default=4, help="queries per step (32 tokens each); 4 = BASELINE config 1's query batch")
+    ap.add_argument("--regimes", type=str, default="1,32,1000",
+                    help="other query-batch sizes measured after the headline and reported under 'regimes' ('' = none)")
     ap.add_argument("--q-len", type=int, default=32)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="also print per-regime lines (nq = 1,2,4,...) to stderr")
     return ap.parse_args()
 
 
@@ -150,6 +153,19 @@ def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
     return dt, kern_ms, scores
 
 
+def pmc_traffic(n_q, n_docs, doc_len):
+    """HBM bytes per launch measured with rocprofv3 PMC counters for this exact workload (committed under
+    profiles/ by tools/summarize_profile.py; FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section), else None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    return table.get(f"nq{n_q}_docs{n_docs}_len{doc_len}")
+
+
 def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg):
     pairs = n_q * n_docs
     alg_bytes = n_docs * doc_len * 256 + n_q * q_len * 256 + pairs * 4   # docs streamed once per launch
@@ -161,7 +177,7 @@ def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg):
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
     else:
         roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
-    roof.update({"traffic": None, "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
+    roof.update({"traffic": pmc_traffic(n_q, n_docs, doc_len), "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
                  "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops,
                  "hbm_gbs": gbs, "mfma_tflops": tf})
     return roof
@@ -220,15 +236,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
 
-    if args.sweep and rank == 0 and world == 1:
-        for nq in (1, 2, 4, 8, 16, 32, 128):
-            qq = make_queries(nq, args.q_len, dev, seed=5)
-            steps = max(3, min(args.steps, 200 // nq))
-            d, km, _ = run_regime(amd, qq, corpus, steps, 2, args.topk, 1, 0, None)
-            r = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(km) / len(km))
-            print(json.dumps({"sweep_nq": nq, "pairs_per_s": nq * args.docs * steps / d, "kernel_ms": r["kernel_ms"],
-                              "hbm_gbs": r["hbm_gbs"], "mfma_tflops": r["mfma_tflops"], "bound": r["bound"], "frac": r["frac"]}),
-                  file=sys.stderr)
+    # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
+    regimes = []
+    for nq in [int(x) for x in args.regimes.split(",") if x]:
+        qq = make_queries(nq, args.q_len, dev, seed=5 + nq)
+        steps = max(3, min(args.steps, 2000 // max(nq, 1)))
+        d, km, _ = run_regime(amd, qq, corpus, steps, 2, args.topk, world, rank, dist)
+        r = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(km) / len(km))
+        regimes.append({"n_queries": nq, "steps": steps, "pairs_per_s": nq * args.docs * world * steps / d,
+                        "ms_per_step": d / steps * 1e3, "kernel_ms": r["kernel_ms"], "bound": r["bound"],
+                        "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"]})
+        del qq
+    out["regimes"] = regimes
 
     if rank == 0:
         print(json.dumps(out))

@@ -1,33 +1,58 @@
 #!/usr/bin/env python
 """Condense a gpurun_out/prof_<tag>/ directory (written by tools/prof.sh on the GPU box) into the small,
-committed evidence under profiles/: the rocprofv3 --kernel-trace --stats rows of our kernels and the
-per-launch PMC counters, with the gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md, HBM section:
-FETCH_SIZE reads exactly half of a wide coalesced stream on gfx950 -> doubled; unit is KiB... see below).
+committed evidence under profiles/:
+  <name>_kernel_stats.csv   the top rows of rocprofv3 --kernel-trace --stats
+  <name>_summary.json       per (kernel, launch shape) cluster: launches, mean duration, PMC counters per launch
+  pmc_traffic.json          HBM bytes per launch keyed by bench workload (read back by bench.py -> roofline.traffic)
+
+Counter handling follows MI355X_MICROARCH.md (HBM / rocprofv3 sections): counters are collected in separate
+--pmc passes; FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE reads exactly half of the bytes of
+a wide (16 B/lane) coalesced stream, so the read side is doubled; WRITE_SIZE is uncalibrated (kept as reported).
 
 usage: python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>
 """
 import csv
 import json
+import math
 import os
 import sys
 from collections import defaultdict
 
 
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
 def main(src, dst_prefix):
-    out = {"source": src}
+    out = {"source": src, "clusters": []}
     stats_path = os.path.join(src, "trace", "trace_kernel_stats.csv")
     rows = list(csv.DictReader(open(stats_path)))
-    ours = [r for r in rows if "msim::" in r["Name"]]
-    out["kernel_stats"] = [{k: (r[k] if k == "Name" else float(r[k])) for k in r} for r in ours]
     with open(dst_prefix + "_kernel_stats.csv", "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys())
         w.writeheader()
-        for r in rows[:12]:
+        for r in rows[:14]:
             r = dict(r)
-            r["Name"] = r["Name"][:160]
+            r["Name"] = r["Name"][:140]
             w.writerow(r)
-    counters = defaultdict(lambda: defaultdict(list))
-    meta = {}
+
+    # per-dispatch durations from the plain kernel trace
+    clusters = defaultdict(lambda: {"dur": [], "counters": defaultdict(list), "cfg": None})
+
+    def key_of(r, dur_ns):
+        if "Grid_Size" in r:
+            grid, wg = int(r["Grid_Size"]), int(r["Workgroup_Size"])
+        else:   # the plain kernel trace splits the sizes per dimension
+            grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+        return (short(r["Kernel_Name"]), grid, wg, round(math.log(max(dur_ns, 1.0), 2.5)))
+
+    trace = os.path.join(src, "trace", "trace_kernel_trace.csv")
+    for r in csv.DictReader(open(trace)):
+        if "msim::" not in r["Kernel_Name"]:
+            continue
+        d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        clusters[key_of(r, d)]["dur"].append(d)
+
     for sub in sorted(os.listdir(src)):
         p = os.path.join(src, sub, "pmc_counter_collection.csv")
         if not os.path.exists(p):
@@ -35,36 +60,63 @@ def main(src, dst_prefix):
         for r in csv.DictReader(open(p)):
             if "msim::" not in r["Kernel_Name"]:
                 continue
-            name = r["Kernel_Name"].split("(")[0]
-            counters[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta[name] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
-    pmc = {}
-    for name, cs in counters.items():
-        d = {"launch_config": meta[name]}
-        for c, vals in cs.items():
-            vals = vals[3:] if len(vals) > 6 else vals       # skip warm-up launches
-            d[c] = sum(vals) / len(vals)
-        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB... the values match bytes/1024 of the known stream;
-        # gfx950 correction: FETCH_SIZE x2 for 16 B/lane coalesced streams (guide, HBM section)
-        if "FETCH_SIZE" in d:
-            d["hbm_read_bytes_per_launch_corrected"] = d["FETCH_SIZE"] * 1024 * 2
-        if "WRITE_SIZE" in d:
-            d["hbm_write_bytes_per_launch_uncalibrated"] = d["WRITE_SIZE"] * 1024
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
-            d["note_mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * CUs*4 SIMDs) ~ MFMA pipe utilisation"
-        pmc[name] = d
-    out["pmc"] = pmc
-    for b in ("bench_trace.json", "bench_pmc_fetch.json"):
-        p = os.path.join(src, b)
-        if os.path.exists(p) and os.path.getsize(p):
-            try:
-                out[b] = json.loads(open(p).read().strip().splitlines()[-1])
-            except Exception as e:  # noqa
-                out[b] = f"unparsed: {e}"
+            d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            # counter passes run slower than the plain trace: match on name/grid and the nearest duration bucket
+            k = key_of(r, d)
+            if k not in clusters:
+                cands = [c for c in clusters if c[:3] == k[:3]]
+                if not cands:
+                    continue
+                k = min(cands, key=lambda c: abs(c[3] - k[3]))
+            clusters[k]["counters"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            clusters[k]["cfg"] = {x: r[x] for x in ("LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+
+    for k, c in sorted(clusters.items()):
+        if not c["dur"]:
+            continue
+        ent = {"kernel": k[0], "grid_threads": int(k[1]), "workgroup": int(k[2]), "launches": len(c["dur"]),
+               "mean_ms": sum(c["dur"]) / len(c["dur"]) / 1e6, "min_ms": min(c["dur"]) / 1e6, "registers": c["cfg"]}
+        for name, vals in c["counters"].items():
+            ent[name] = sum(vals) / len(vals)
+        if "FETCH_SIZE" in ent:
+            ent["hbm_read_bytes_per_launch"] = ent["FETCH_SIZE"] * 1024 * 2      # gfx950: x2 (guide, HBM section)
+        if "WRITE_SIZE" in ent:
+            ent["hbm_write_bytes_per_launch_uncalibrated"] = ent["WRITE_SIZE"] * 1024
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in ent and "GRBM_GUI_ACTIVE" in ent and ent["GRBM_GUI_ACTIVE"]:
+            cycles = ent["GRBM_GUI_ACTIVE"] / 8.0                                # counter is summed over the 8 XCDs
+            ent["effective_clock_ghz_during_pmc_pass"] = None
+            ent["mfma_pipe_busy_frac"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0)   # 256 CUs x 4 SIMDs
+        out["clusters"].append(ent)
+
+    # match clusters to the bench regimes by kernel duration and emit the traffic table
+    bench = None
+    bp = os.path.join(src, "bench_trace.json")
+    if os.path.exists(bp) and os.path.getsize(bp):
+        try:
+            bench = json.loads(open(bp).read().strip().splitlines()[-1])
+        except Exception:
+            bench = None
+    traffic_path = os.path.join(os.path.dirname(dst_prefix), "pmc_traffic.json")
+    table = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+    if bench:
+        out["bench_line_under_trace"] = bench
+        cfg = bench["config"]
+        regs = [(cfg["n_queries"], bench["roofline"]["kernel_ms"])] + [(r["n_queries"], r["kernel_ms"]) for r in bench.get("regimes", [])]
+        for nq, ms in regs:
+            cands = [e for e in out["clusters"] if "maxsim_" in e["kernel"] and "hbm_read_bytes_per_launch" in e
+                     and abs(e["mean_ms"] - ms) / ms < 0.2]
+            if cands:
+                e = min(cands, key=lambda e: abs(e["mean_ms"] - ms))
+                tot = e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch_uncalibrated", 0.0)
+                table[f"nq{nq}_docs{cfg['docs_per_gpu']}_len{cfg['doc_len']}"] = tot
+                e["matched_bench_regime_n_queries"] = nq
+    with open(traffic_path, "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
     with open(dst_prefix + "_summary.json", "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps(out["kernel_stats"], indent=1))
-    print(json.dumps(pmc, indent=1))
+    for e in out["clusters"]:
+        print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items() if k != "registers"})
+    print("traffic table:", table)
 
 
 if __name__ == "__main__":
