@@ -12,6 +12,7 @@ colpali_amd/csrc/); this package is the thin host-side mirror of the reference i
 from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
 from . import loss
 from .loss import ColbertLoss, ColbertModule, ColbertPairwiseCELoss, ColbertSigmoidLoss, maxsim
+from .patch import patch_colpali_engine, unpatch_colpali_engine
 from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
 from .scoring import get_torch_device, maxsim_scores, score_multi_vector
 
@@ -31,6 +32,8 @@ __all__ = [
     "get_torch_device",
     "maxsim_scores",
     "pack_passages",
+    "patch_colpali_engine",
+    "unpatch_colpali_engine",
     "pack_queries",
     "score_multi_vector",
 ]

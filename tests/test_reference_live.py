@@ -44,3 +44,51 @@ def test_reference_own_scorer_unit_tests_pass_here():
     b = P.score_multi_vector(torch.nn.utils.rnn.pad_sequence(qs, batch_first=True),
                              torch.nn.utils.rnn.pad_sequence(ps, batch_first=True), device="cpu")
     assert a.shape == (2, 3) and torch.allclose(a, b)
+
+
+def test_patch_routes_the_reference_entry_points_to_the_native_implementations():
+    import colpali_amd
+
+    P, L = refimport.load()
+    orig = P.score_multi_vector
+    colpali_amd.patch_colpali_engine()
+    try:
+        assert P.score_multi_vector is colpali_amd.score_multi_vector
+        assert L.ColbertPairwiseCELoss is colpali_amd.ColbertPairwiseCELoss
+        import colpali_engine.loss as pkg
+
+        assert pkg.ColbertPairwiseCELoss is colpali_amd.ColbertPairwiseCELoss
+        # same constructor surface as the reference class (late_interaction_losses.py:266-277)
+        import inspect
+
+        colpali_amd.unpatch_colpali_engine()
+        def surface(fn):   # parameter names, order and defaults (annotations may be strings on one side)
+            return [(p.name, p.default, p.kind) for p in inspect.signature(fn).parameters.values()]
+
+        assert surface(colpali_amd.ColbertPairwiseCELoss.__init__) == surface(L.ColbertPairwiseCELoss.__init__)
+        assert surface(colpali_amd.ColbertPairwiseCELoss.forward) == surface(L.ColbertPairwiseCELoss.forward)
+        assert surface(colpali_amd.ColbertLoss.__init__) == surface(L.ColbertLoss.__init__)
+        assert surface(colpali_amd.ColbertSigmoidLoss.__init__) == surface(L.ColbertSigmoidLoss.__init__)
+        assert surface(colpali_amd.score_multi_vector) == surface(orig)
+    finally:
+        colpali_amd.unpatch_colpali_engine()
+    assert P.score_multi_vector is orig
+
+
+def test_helper_known_answers_of_the_reference_hold_for_the_native_module():
+    """tests/loss/test_li_losses.py:15-73 restated against colpali_amd.ColbertModule (CPU-sized helpers)."""
+    import colpali_amd
+
+    m = colpali_amd.ColbertModule(max_batch_size=5)
+    idx, pos = m._get_idx(batch_size=3, offset=2, device=torch.device("cpu"))
+    assert idx.tolist() == [0, 1, 2] and pos.tolist() == [2, 3, 4]
+    m = colpali_amd.ColbertModule(tau=2.0)
+    assert torch.allclose(m._smooth_max(torch.tensor([[0.0, 2.0]]), dim=1), 2.0 * torch.log(1 + torch.exp(torch.tensor(1.0))))
+    m = colpali_amd.ColbertModule()
+    raw = torch.tensor([[[1.0, 2.0], [3.0, 4.0]], [[5.0, 6.0], [7.0, 8.0]]])
+    assert torch.allclose(m._aggregate(raw, use_smooth_max=False, dim_max=2, dim_sum=1), torch.tensor([6.0, 14.0]))
+    s = torch.tensor([[1.0, 0.96], [0.5, 1.0]])
+    m._filter_high_negatives(s, torch.tensor([0, 1]))
+    assert abs(float(s[0, 1]) - 0.48) < 1e-6 and float(s[1, 0]) == 0.5
+    n = m._apply_normalization(torch.tensor([[0.5, 1.0], [0.2, 0.8]]), torch.tensor([2.0, 4.0]))
+    assert torch.allclose(n, torch.tensor([[0.25, 0.5], [0.05, 0.2]]))
