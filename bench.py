@@ -190,13 +190,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_SHARE_GPU=1 + BENCH_DIST_BACKEND=gloo: plumbing test of the N>1 path on a 1-GPU box (not a measurement)
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
-        import torch.distributed as dist  # RCCL
+        import torch.distributed as dist  # "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import colpali_amd as amd
 
