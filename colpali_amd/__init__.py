@@ -11,7 +11,8 @@ colpali_amd/csrc/); this package is the thin host-side mirror of the reference i
 """
 from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
 from . import loss
-from .loss import ColbertLoss, ColbertModule, ColbertPairwiseCELoss, ColbertSigmoidLoss, maxsim
+from .loss import (ColbertLoss, ColbertModule, ColbertNegativeCELoss, ColbertPairwiseCELoss,
+                   ColbertPairwiseNegativeCELoss, ColbertSigmoidLoss, maxsim, maxsim_paired)
 from .patch import patch_colpali_engine, unpatch_colpali_engine
 from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
 from .scoring import get_torch_device, maxsim_scores, score_multi_vector
@@ -19,6 +20,9 @@ from .scoring import get_torch_device, maxsim_scores, score_multi_vector
 __all__ = [
     "ColbertLoss",
     "ColbertModule",
+    "ColbertNegativeCELoss",
+    "ColbertPairwiseNegativeCELoss",
+    "maxsim_paired",
     "ColbertPairwiseCELoss",
     "ColbertSigmoidLoss",
     "PackedCorpus",

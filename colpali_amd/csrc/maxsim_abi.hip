@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/maxsim.h"
@@ -167,7 +168,14 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *
     if (int rc = device_info(&di)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    if (n_q * tpq > 4) {
+    // up to kStreamMaxTiles token tiles are held by every wave of K1s; above that K1b's workgroup blocking wins.
+    // (MSIM_STREAM_MAX_TILES is a tuning knob for A/B measurements, not part of the ABI.)
+    static const int stream_max_tiles = [] {
+        const char *e = getenv("MSIM_STREAM_MAX_TILES");
+        const int v = e ? atoi(e) : 8;
+        return v < 4 ? 4 : (v > 8 ? 8 : v);
+    }();
+    if (n_q * tpq > stream_max_tiles) {
         // MFMA-bound regime: K1b, a workgroup holds 8 waves x NT token tiles
         int rc;
         if (tpq == 1) {
@@ -203,6 +211,14 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *
         case 22: return launch_stream<4, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
         case 13: return launch_stream<3, 3>(Q, D, d_off, d_clamp0, scores, a, *di, st);
         case 14: return launch_stream<4, 4>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 51: return launch_stream<5, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 61: return launch_stream<6, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 71: return launch_stream<7, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 81: return launch_stream<8, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 32: return launch_stream<6, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 42: return launch_stream<8, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 23: return launch_stream<6, 3>(Q, D, d_off, d_clamp0, scores, a, *di, st);
+        case 24: return launch_stream<8, 4>(Q, D, d_off, d_clamp0, scores, a, *di, st);
         default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
     }
 }
@@ -254,15 +270,24 @@ int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int
 }
 
 // ---------------------------------------------------------------- top-k selection
-static inline long long topk_level_out(long long n, int k) {
-    return ((n + msim::kTopkSeg - 1) / msim::kTopkSeg) * (long long)k;
-}
+// Level plan: level 0 splits each row into segments of `seg0` candidates (a power of two chosen so that the
+// launch has enough workgroups to fill the chip even for a single row); later levels use full segments.
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+static int topk_first_segment(int n_q, long long n, int k) {
+    int seg = 512;
+    while (seg < 4 * k) seg <<= 1;                       // every level must shrink its input at least 4x
+    while (seg < msim::kTopkSeg && (long long)n_q * ((n + seg - 1) / seg) > 1024) seg <<= 1;   // ~4 workgroups per CU is plenty
+    return seg;
+}
+static inline long long topk_level_out(long long n, int seg, int k) { return ((n + seg - 1) / seg) * (long long)k; }
+
 size_t msim_topk_workspace_bytes(int n_q, int64_t n, int k) {
-    if (n_q <= 0 || n <= msim::kTopkSeg || k <= 0) return 0;
-    const long long na = topk_level_out(n, k);
-    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, k) : 0;
+    if (n_q <= 0 || k <= 0 || k > msim::kTopkMaxK) return 0;
+    const int seg0 = topk_first_segment(n_q, n, k);
+    if (n <= seg0) return 0;
+    const long long na = topk_level_out(n, seg0, k);
+    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, msim::kTopkSeg, k) : 0;
     return align16((size_t)n_q * na * 4) + align16((size_t)n_q * na * 8) + align16((size_t)n_q * nb * 4) +
            align16((size_t)n_q * nb * 8);
 }
@@ -274,11 +299,12 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
     if (!out_scores || !out_ids || (n > 0 && !scores)) return fail(MSIM_EINVAL, "null pointer argument");
     if (k > msim::kTopkMaxK) return fail(MSIM_EUNSUPPORTED, "k=%d > %d", k, msim::kTopkMaxK);
     if (ld < n) return fail(MSIM_EINVAL, "ld=%lld < n=%lld", (long long)ld, (long long)n);
-    if (n > msim::kTopkSeg && !workspace) return fail(MSIM_EINVAL, "workspace required for n > %d", msim::kTopkSeg);
+    const int seg0 = topk_first_segment(n_q, n, k);
+    if (n > seg0 && !workspace) return fail(MSIM_EINVAL, "workspace required (msim_topk_workspace_bytes)");
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    const long long na = n > msim::kTopkSeg ? topk_level_out(n, k) : 0;
-    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, k) : 0;
+    const long long na = n > seg0 ? topk_level_out(n, seg0, k) : 0;
+    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, msim::kTopkSeg, k) : 0;
     char *w = static_cast<char *>(workspace);
     float *bufs_s[2];
     int64_t *bufs_i[2];
@@ -294,10 +320,10 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
     const float *in_s = scores;
     const int64_t *in_i = ids;
     long long in_n = n, in_ld = ld, in_base = id_base;
-    int which = 0;
+    int which = 0, seg = seg0;
     for (;;) {
-        const bool last = in_n <= msim::kTopkSeg;
-        const long long segs = last ? 1 : (in_n + msim::kTopkSeg - 1) / msim::kTopkSeg;
+        const bool last = in_n <= seg;
+        const long long segs = last ? 1 : (in_n + seg - 1) / seg;
         float *o_s = last ? out_scores : bufs_s[which];
         int64_t *o_i = last ? out_ids : bufs_i[which];
         const long long o_ld = last ? k : segs * k;
@@ -306,7 +332,7 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
             const int rows = (n_q - r0 < 65535) ? (n_q - r0) : 65535;
             hipLaunchKernelGGL(msim::topk_segment_kernel, dim3((unsigned)segs, (unsigned)rows), dim3(msim::kTopkThreads), 0, st,
                                in_s + (size_t)r0 * in_ld, in_i ? in_i + (size_t)r0 * in_ld : nullptr, in_n, in_ld, in_base, k,
-                               o_s + (size_t)r0 * o_ld, o_i + (size_t)r0 * o_ld, o_ld);
+                               last ? msim::kTopkSeg : seg, o_s + (size_t)r0 * o_ld, o_i + (size_t)r0 * o_ld, o_ld);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(MSIM_ELAUNCH, "topk_segment_kernel launch: %s", hipGetErrorString(e));
@@ -317,6 +343,7 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
         in_ld = o_ld;
         in_base = 0;
         which ^= 1;
+        seg = msim::kTopkSeg;
     }
     return MSIM_OK;
 }

@@ -18,6 +18,8 @@
 //     range for different query blocks, so a document is pulled from HBM once per XCD and served
 //     to the other CUs from that XCD's L2 (placement only affects speed, never results).
 #pragma once
+#include <type_traits>
+
 #include "maxsim_common.hpp"
 #include "maxsim_stream.hip"
 
@@ -155,6 +157,74 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
         float m[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) m[t] = -INFINITY;
+        // Tiles are processed in two passes per slab (A = tiles 0..NA-1, B = the rest); the 16 -> 1 max fold of a
+        // pass is deferred so that its v_max3 run underneath the NEXT pass's MFMAs instead of stalling the matrix
+        // pipe: `pend` holds the accumulators of the last pass of the previous slab (all -inf = nothing pending).
+        constexpr int NA = NT < 2 ? NT : 2, NB = NT - NA, NP = NB > 0 ? NB : NA;
+        f32x16 pend[NP];
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pend[t][r] = -INFINITY;
+
+        auto slab = [&](int src_lds, auto tail, int rows_left) {   // src_lds: LDS byte address of the slab (wave-uniform)
+            constexpr bool kTail = decltype(tail)::value;
+            // ---- region 1: pass A MFMAs, with the previous slab's pending fold underneath them
+            f32x16 accA[NA];
+#pragma unroll
+            for (int t = 0; t < NA; ++t) accA[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
+#pragma unroll
+                for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[t][ks], accA[t], 0, 0, 0);
+            }
+            if constexpr (NB > 0) {
+#pragma unroll
+                for (int t = 0; t < NB; ++t) m[NA + t] = fold_max16(m[NA + t], pend[t]);   // previous slab's pass B
+            } else {
+#pragma unroll
+                for (int t = 0; t < NA; ++t) m[t] = fold_max16(m[t], pend[t]);              // previous slab's pass A
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kTail) {
+#pragma unroll
+                for (int t = 0; t < NA; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc_row(r, lane) >= rows_left) accA[t][r] = -INFINITY;
+            }
+            if constexpr (NB > 0) {
+                // ---- region 2: pass B MFMAs (operands re-read from LDS: cheaper than 32 live VGPRs), pass A's fold underneath
+                int src_b = src_lds;
+                asm volatile("" : "+s"(src_b));   // keep the compiler from merging the two passes back into one
+                f32x16 accB[NB];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) accB[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(smem + src_b + rd_off[ks]);
+#pragma unroll
+                    for (int t = 0; t < NB; ++t)
+                        accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[NA + t][ks], accB[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NA; ++t) m[t] = fold_max16(m[t], accA[t]);             // this slab's pass A
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kTail) {
+#pragma unroll
+                    for (int t = 0; t < NB; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (acc_row(r, lane) >= rows_left) accB[t][r] = -INFINITY;
+                }
+#pragma unroll
+                for (int t = 0; t < NB; ++t) pend[t] = accB[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NA; ++t) pend[t] = accA[t];
+            }
+        };
 
         for (int ch = 0; ch < nchunk; ++ch) {
             // my share of chunk `ch` has landed once at most (ring-2) later chunks of mine are still in flight
@@ -162,37 +232,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
             __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done reading the previous chunk
             produce();                      // refill the buffer that was read in the previous iteration
 
-            const char *cbuf = smem + c_slot * kChunkBytes;
+            const int cbuf = c_slot * kChunkBytes;
             c_slot = (c_slot + 1 == kBatchRing) ? 0 : c_slot + 1;
             const int rows_in_chunk = len - ch * kChunkRows;   // >= 1
             if (wave_has_queries) {
+                const int n_full = rows_in_chunk >= kChunkRows ? kChunkSlabs : rows_in_chunk / kSlabRows;
 #pragma unroll 1
-                for (int sl = 0; sl < kChunkSlabs; ++sl) {
-                    const int rows_left = rows_in_chunk - sl * kSlabRows;
-                    if (rows_left <= 0) break;
-                    const char *src = cbuf + sl * kSlabBytes;
-                    f32x16 acc[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int ks = 0; ks < kKSteps; ++ks) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[t][ks], acc[t], 0, 0, 0);
-                    }
-                    if (rows_left < kSlabRows) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if (acc_row(r, lane) >= rows_left) acc[t][r] = -INFINITY;
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) m[t] = fold_max16(m[t], acc[t]);
-                }
+                for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
+                const int rem = rows_in_chunk - n_full * kSlabRows;
+                if (n_full < kChunkSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem);
             }
         }
+        // fold what is still pending from the document's last slab
+#pragma unroll
+        for (int t = 0; t < NP; ++t) m[(NB > 0 ? NA : 0) + t] = fold_max16(m[(NB > 0 ? NA : 0) + t], pend[t]);
 
         // ---- document epilogue (per wave, its own queries)
         if (wave_has_queries) {

@@ -16,7 +16,7 @@
 
 namespace msim {
 
-constexpr int kTopkSeg = 4096;      // candidates per workgroup
+constexpr int kTopkSeg = 4096;      // most candidates one workgroup sorts (the host may choose a smaller power of two)
 constexpr int kTopkThreads = 256;
 constexpr int kTopkMaxK = 1024;     // k <= kTopkSeg / 4 keeps every level shrinking by >= 4x
 
@@ -40,19 +40,22 @@ __device__ __forceinline__ bool ranks_before(uint32_t ka, uint64_t ia, uint32_t 
 __global__ __launch_bounds__(kTopkThreads) void topk_segment_kernel(const float *__restrict__ scores,
                                                                     const int64_t *__restrict__ ids,  // or null
                                                                     long long n, long long ld, long long id_base, int k,
+                                                                    int seg,   // candidates per workgroup: power of two, 4k <= seg <= kTopkSeg
                                                                     float *__restrict__ out_scores,
                                                                     int64_t *__restrict__ out_ids, long long out_ld) {
     __shared__ uint32_t skey[kTopkSeg];
     __shared__ uint64_t sid[kTopkSeg];
     const int tid = threadIdx.x;
     const long long row = blockIdx.y;
-    const long long base = (long long)blockIdx.x * kTopkSeg;
+    const long long base = (long long)blockIdx.x * seg;
     const long long remaining = n - base;
-    const int cnt = remaining < kTopkSeg ? (int)remaining : kTopkSeg;
+    const int cnt = remaining < seg ? (int)remaining : seg;
+    int npow2 = 64;                       // sort only the next power of two above the live candidates
+    while (npow2 < cnt) npow2 <<= 1;
     const float *srow = scores + row * ld + base;
     const int64_t *irow = ids ? ids + row * ld + base : nullptr;
 
-    for (int i = tid; i < kTopkSeg; i += kTopkThreads) {
+    for (int i = tid; i < npow2; i += kTopkThreads) {
         uint32_t key = 0u;                 // below every real score (even -inf and NaN images are > 0)
         uint64_t id = ~0ull;
         if (i < cnt) {
@@ -64,10 +67,10 @@ __global__ __launch_bounds__(kTopkThreads) void topk_segment_kernel(const float 
         sid[i] = id;
     }
 
-    for (int size = 2; size <= kTopkSeg; size <<= 1) {
+    for (int size = 2; size <= npow2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = tid; t < kTopkSeg / 2; t += kTopkThreads) {
+            for (int t = tid; t < npow2 / 2; t += kTopkThreads) {
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
                 const bool first_wins = (lo & size) == 0;   // this block is sorted best-first

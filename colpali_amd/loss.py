@@ -1,7 +1,8 @@
 """MI355X-native drop-ins for the reference's late-interaction (ColBERT) losses.
 
 Mirrors colpali_engine/loss/late_interaction_losses.py: `ColbertModule` (:6-107),
-`ColbertLoss` (:110-164), `ColbertPairwiseCELoss` (:255-313), `ColbertSigmoidLoss` (:401-465)
+`ColbertLoss` (:110-164), `ColbertNegativeCELoss` (:167-252), `ColbertPairwiseCELoss` (:255-313),
+`ColbertPairwiseNegativeCELoss` (:316-398), `ColbertSigmoidLoss` (:401-465)
 -- same constructor arguments, same forward signature, no persistent state (checkpoints stay
 interchangeable).  The MaxSim core every one of them starts with,
 
@@ -104,6 +105,47 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
                                    _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
     _lib.check(rc, "msim_pairs_bwd_bf16")
     return dq, dd
+
+
+class _MaxSimPairs(torch.autograd.Function):
+    """scores[p] = MaxSim(Q[pairs[p,0]], D[pairs[p,1]]) for an explicit pair list sorted by query index."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor, pairs: torch.Tensor) -> torch.Tensor:
+        qc, dc = q.contiguous(), d.contiguous()
+        corpus = _dense_corpus(dc)
+        scores, _ = maxsim_pairs(qc, dc, corpus.offsets, pairs, want_argmax=False)
+        ctx.save_for_backward(qc, dc, corpus.offsets, pairs)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores: torch.Tensor):
+        qc, dc, offsets, pairs = ctx.saved_tensors
+        L = _lib.lib()
+        B, Lq, dim = qc.shape
+        C, Ld, _ = dc.shape
+        dev = qc.device
+        gp = grad_scores.to(torch.float32).contiguous()
+        order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
+        _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
+        dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
+        dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.msim_pairs_bwd_bf16(_lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
+                                       _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
+                                       _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+        _lib.check(rc, "msim_pairs_bwd_bf16")
+        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
+
+
+def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, pairs: torch.Tensor) -> torch.Tensor:
+    """Differentiable MaxSim of listed (query, doc) pairs: fp32 [n_pairs].  `pairs` int32 [n,2], sorted by query.
+
+    Fused form of the paired contractions "bnd,bsd->bns" / "bnd,blsd->blns" followed by amax/sum
+    (late_interaction_losses.py:235-240, :381-386)."""
+    _check_embeddings(query_embeddings, doc_embeddings)
+    return _MaxSimPairs.apply(query_embeddings, doc_embeddings, pairs)
 
 
 def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torch.Tensor:
@@ -223,3 +265,88 @@ class ColbertSigmoidLoss(ColbertModule):
         sign[pos_idx * (n + 1)] = 1.0
         flat = scores.view(-1) / self.temperature                       # :462 (requires C == B, like the reference)
         return F.softplus(-flat * sign).mean().to(query_embeddings.dtype)
+
+
+class _ExplicitNegativesMixin:
+    """Shared forward of the two explicit-negative losses (late_interaction_losses.py:215-252 and :361-398):
+    both compute softplus((neg - pos) / T).mean() over the listed negatives and optionally blend an in-batch term."""
+
+    def _explicit_negative_term(self, query_embeddings, doc_embeddings, neg_doc_embeddings, offset):
+        if self.use_smooth_max:
+            raise NotImplementedError("use_smooth_max=True (tau * logsumexp over patches) has no gfx950 kernel yet")
+        B = query_embeddings.size(0)
+        n_neg = neg_doc_embeddings.size(1)
+        dev = query_embeddings.device
+        lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)
+        rows = torch.arange(B, dtype=torch.int32, device=dev)
+        pos_pairs = torch.stack([rows, rows + offset], dim=1).contiguous()                 # (b, offset + b)
+        pos_scores = maxsim_paired(query_embeddings, doc_embeddings, pos_pairs)            # "bnd,bsd->bns" -> amax -> sum
+        neg_flat = neg_doc_embeddings.reshape(B * n_neg, neg_doc_embeddings.size(2), neg_doc_embeddings.size(3))
+        neg_pairs = torch.stack([rows.repeat_interleave(n_neg),
+                                 torch.arange(B * n_neg, dtype=torch.int32, device=dev)], dim=1).contiguous()
+        neg_scores = maxsim_paired(query_embeddings, neg_flat, neg_pairs).view(B, n_neg)  # "bnd,blsd->blns" -> amax -> sum
+        if self.normalize_scores:
+            pos_scores = self._apply_normalization(pos_scores, lengths)
+            neg_scores = self._apply_normalization(neg_scores, lengths)
+        return F.softplus((neg_scores - pos_scores.unsqueeze(1)) / self.temperature).mean()
+
+
+class ColbertNegativeCELoss(_ExplicitNegativesMixin, ColbertModule):
+    """Explicit-negative loss with an optional in-batch InfoNCE term (late_interaction_losses.py:167-252)."""
+
+    def __init__(self, temperature: float = 0.02, normalize_scores: bool = True, use_smooth_max: bool = False,
+                 pos_aware_negative_filtering: bool = False, in_batch_term_weight: float = 0.5,
+                 max_batch_size: int = 1024, tau: float = 0.1, norm_tol: float = 1e-3,
+                 filter_threshold: float = 0.95, filter_factor: float = 0.5):
+        super().__init__(max_batch_size, tau, norm_tol, filter_threshold, filter_factor)
+        self.temperature = temperature
+        self.normalize_scores = normalize_scores
+        self.use_smooth_max = use_smooth_max
+        self.pos_aware_negative_filtering = pos_aware_negative_filtering
+        self.in_batch_term_weight = in_batch_term_weight
+        self.ce_loss = torch.nn.CrossEntropyLoss()
+        assert in_batch_term_weight >= 0, "in_batch_term_weight must be non-negative"
+        assert in_batch_term_weight <= 1, "in_batch_term_weight must be less than 1"
+        self.inner_loss = ColbertLoss(temperature=temperature, normalize_scores=normalize_scores,
+                                      use_smooth_max=use_smooth_max,
+                                      pos_aware_negative_filtering=pos_aware_negative_filtering,
+                                      max_batch_size=max_batch_size, tau=tau, norm_tol=norm_tol,
+                                      filter_threshold=filter_threshold, filter_factor=filter_factor)
+
+    def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor,
+                neg_doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
+        loss = self._explicit_negative_term(query_embeddings, doc_embeddings, neg_doc_embeddings, offset)
+        if self.in_batch_term_weight > 0:                                                   # :248-250
+            loss_ib = self.inner_loss(query_embeddings, doc_embeddings, offset).to(loss.dtype)
+            loss = loss * (1 - self.in_batch_term_weight) + loss_ib * self.in_batch_term_weight
+        return loss.to(query_embeddings.dtype)
+
+
+class ColbertPairwiseNegativeCELoss(_ExplicitNegativesMixin, ColbertModule):
+    """Explicit-negative loss with an optional in-batch pairwise term (late_interaction_losses.py:316-398)."""
+
+    def __init__(self, temperature: float = 0.02, normalize_scores: bool = True, use_smooth_max: bool = False,
+                 pos_aware_negative_filtering: bool = False, in_batch_term_weight: float = 0.5,
+                 max_batch_size: int = 1024, tau: float = 0.1, norm_tol: float = 1e-3,
+                 filter_threshold: float = 0.95, filter_factor: float = 0.5):
+        super().__init__(max_batch_size, tau, norm_tol, filter_threshold, filter_factor)
+        self.temperature = temperature
+        self.normalize_scores = normalize_scores
+        self.use_smooth_max = use_smooth_max
+        self.pos_aware_negative_filtering = pos_aware_negative_filtering
+        self.in_batch_term_weight = in_batch_term_weight
+        assert in_batch_term_weight >= 0, "in_batch_term_weight must be non-negative"
+        assert in_batch_term_weight <= 1, "in_batch_term_weight must be less than 1"
+        self.inner_pairwise = ColbertPairwiseCELoss(temperature=temperature, normalize_scores=normalize_scores,
+                                                    use_smooth_max=use_smooth_max,
+                                                    pos_aware_negative_filtering=pos_aware_negative_filtering,
+                                                    max_batch_size=max_batch_size, tau=tau, norm_tol=norm_tol,
+                                                    filter_threshold=filter_threshold, filter_factor=filter_factor)
+
+    def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor,
+                neg_doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
+        loss = self._explicit_negative_term(query_embeddings, doc_embeddings, neg_doc_embeddings, offset)
+        if self.in_batch_term_weight > 0:                                                   # :394-396
+            loss_ib = self.inner_pairwise(query_embeddings, doc_embeddings, offset).to(loss.dtype)
+            loss = loss * (1 - self.in_batch_term_weight) + loss_ib * self.in_batch_term_weight
+        return loss.to(query_embeddings.dtype)

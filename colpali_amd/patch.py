@@ -20,7 +20,8 @@ import sys
 from . import loss as _loss
 from .scoring import score_multi_vector
 
-_LOSS_NAMES = ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss")
+_LOSS_NAMES = ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss", "ColbertNegativeCELoss",
+               "ColbertPairwiseNegativeCELoss")
 _saved = {}
 
 

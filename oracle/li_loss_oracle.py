@@ -59,3 +59,34 @@ def loss_and_grads(kind: str, Q: torch.Tensor, D: torch.Tensor, offset: int = 0,
         raise ValueError(kind)
     loss.backward()
     return loss.detach(), q.grad, d.grad
+
+
+def negatives_loss_and_grads(kind: str, Q, D, N, offset: int = 0, temperature: float = 0.02,
+                             normalize_scores: bool = True, in_batch_term_weight: float = 0.5):
+    """Explicit-negative variants (:215-252 "negative_ce", :361-398 "pairwise_negative_ce").
+    N: [B, n_neg, Lneg, dim].  Returns (loss, dQ, dD, dN) in float64."""
+    q = Q.detach().double().requires_grad_(True)
+    d = D.detach().double().requires_grad_(True)
+    n = N.detach().double().requires_grad_(True)
+    B = q.size(0)
+    lengths = (q[:, :, 0] != 0).sum(dim=1)
+    pos_raw = torch.einsum("bnd,bsd->bns", q, d[offset : offset + B])          # :235-237 / :381-383
+    neg_raw = torch.einsum("bnd,blsd->blns", q, n)                             # :238 / :384
+    pos = pos_raw.amax(dim=2).sum(dim=1)
+    neg = neg_raw.amax(dim=3).sum(dim=2)
+    if normalize_scores:
+        pos = pos / lengths
+        neg = neg / lengths.unsqueeze(1)
+    loss = F.softplus((neg - pos.unsqueeze(1)) / temperature).mean()           # :246 / :392
+    if in_batch_term_weight > 0:
+        scores, pos_idx = _scores(q, d, offset, normalize_scores, False, 0.95, 0.5)
+        if kind == "negative_ce":
+            ib = F.cross_entropy(scores / temperature, pos_idx)
+        else:
+            p = scores.diagonal(offset=offset)
+            top2 = scores.topk(2, dim=1).values
+            ng = torch.where(top2[:, 0] == p, top2[:, 1], top2[:, 0])
+            ib = F.softplus((ng - p) / temperature).mean()
+        loss = loss * (1 - in_batch_term_weight) + ib * in_batch_term_weight
+    loss.backward()
+    return loss.detach(), q.grad, d.grad, n.grad

@@ -161,6 +161,24 @@ def main():
             L.ColbertPairwiseCELoss(normalize_scores=False)(Q.bfloat16(), D.bfloat16(), offset=offset).float().numpy())
     save("loss_small.npz", **out)
 
+    # (6b) explicit-negative variants on the same Q/D plus 2 negatives per query
+    g = torch.Generator().manual_seed(123)
+    N = F.normalize(torch.randn(B, 2, 20, dim, generator=g), dim=-1)
+    N[0, 1, 15:] = 0
+    outn = dict(Q=Q.numpy(), D=D.numpy(), N=N.numpy())
+    for cls_name in ("ColbertNegativeCELoss", "ColbertPairwiseNegativeCELoss"):
+        for vname, kw in {"default": dict(), "nonorm_w0": dict(normalize_scores=False, in_batch_term_weight=0.0),
+                          "T1_w03": dict(temperature=1.0, in_batch_term_weight=0.3)}.items():
+            for offset in (0, 6):
+                q = Q.clone().requires_grad_(True); d = D.clone().requires_grad_(True); n = N.clone().requires_grad_(True)
+                loss = getattr(L, cls_name)(**kw)(q, d, n, offset=offset)
+                loss.backward()
+                key = f"{cls_name}_{vname}_off{offset}"
+                outn[key + "_loss"] = loss.detach().numpy()
+                outn[key + "_dQ"] = q.grad.numpy()
+                outn[key + "_dN"] = n.grad.numpy()
+    save("loss_negatives.npz", **outn)
+
     # (7) helper known-answer tests restated from tests/loss/test_li_losses.py:45-73,137-147
     z = L.ColbertPairwiseCELoss(temperature=1.0, normalize_scores=False)(torch.zeros(2, 1, 3), torch.zeros(2, 1, 3))
     save("loss_kat.npz", pairwise_zero=z.numpy(), ln2=np.float32(np.log(2.0)))

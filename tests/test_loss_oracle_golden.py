@@ -38,3 +38,18 @@ def test_known_answers_from_the_reference_unit_tests():
     q3 = torch.zeros(3, 1, 4)
     loss, _, _ = lo.loss_and_grads("infonce", q3, q3.clone(), normalize_scores=False, temperature=1.0)
     assert abs(float(loss) - np.log(3.0)) < 1e-7
+
+
+@pytest.mark.parametrize("cls,kind", [("ColbertNegativeCELoss", "negative_ce"), ("ColbertPairwiseNegativeCELoss", "pairwise_negative_ce")])
+def test_explicit_negative_variants_match_the_reference(cls, kind):
+    z = load_golden("loss_negatives.npz")
+    Q, D, N = (torch.from_numpy(z[k]) for k in ("Q", "D", "N"))
+    variants = {"default": dict(), "nonorm_w0": dict(normalize_scores=False, in_batch_term_weight=0.0),
+                "T1_w03": dict(temperature=1.0, in_batch_term_weight=0.3)}
+    for vname, kw in variants.items():
+        for offset in (0, 6):
+            key = f"{cls}_{vname}_off{offset}"
+            loss, dQ, dD, dN = lo.negatives_loss_and_grads(kind, Q, D, N, offset=offset, **kw)
+            assert abs(float(loss) - float(z[key + "_loss"])) < 5e-6 * max(1.0, abs(float(loss))), key
+            np.testing.assert_allclose(dQ.numpy(), z[key + "_dQ"], rtol=5e-4, atol=1e-5, err_msg=key)
+            np.testing.assert_allclose(dN.numpy(), z[key + "_dN"], rtol=5e-4, atol=1e-5, err_msg=key)
