@@ -119,6 +119,28 @@ def cpu_baseline(q_len, doc_len):
     }
 
 
+def torch_gpu_reference(q_len, doc_len):
+    """What the unmodified reference does on this same GPU (its torch einsum/max/sum with host-side padding and
+    H2D per block, processing_utils.py:170-180): informational, not the optimisation target."""
+    from oracle import torch_port
+
+    g = torch.Generator().manual_seed(12)
+    n_q, n_d = 128, 1024
+    qs = [torch.nn.functional.normalize(torch.randn(q_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_q)]
+    ps = [torch.nn.functional.normalize(torch.randn(doc_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_d)]
+    torch_port.score_multi_vector_cpu(qs[:8], ps[:128], device="cuda:0")
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0")
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return {"value": n_q * n_d / min(ts), "unit": "pairs/s",
+            "sample": f"{n_q} queries x {n_d} docs from host lists through the reference's blocked einsum on cuda:0 "
+                      f"(includes its per-block pad_sequence + H2D), best of 3"}
+
+
 def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
     """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list)."""
     dev = q.device
@@ -242,6 +264,7 @@ def main():
         out["parity_max_rel_err_vs_oracle_sample"] = parity_sample(q, corpus, scores)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
+        out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
