@@ -13,7 +13,17 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime (
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
-MSIM_FLAG_REF_BF16 = 0x1
+MSIM_FLAG_REF_ROUNDING = 0x1
+ABI_VERSION = 2
+
+
+def dtype_code(dtype) -> int:
+    """MSIM_DTYPE_* code of a torch dtype the kernels take natively."""
+    if dtype == torch.bfloat16:
+        return 0
+    if dtype == torch.float16:
+        return 1
+    raise NotImplementedError(f"dtype {dtype}: the gfx950 kernels take bfloat16 or float16 embeddings")
 
 _lib = None
 
@@ -35,20 +45,21 @@ def lib() -> ctypes.CDLL:
     vp, i32, i64, u32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_size_t
     L.msim_abi_version.restype = i32
     L.msim_last_error.restype = ctypes.c_char_p
-    L.msim_fwd_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.msim_fwd_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.msim_fwd_workspace_bytes.restype = sz
-    L.msim_fwd_bf16.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
-    L.msim_fwd_bf16.restype = i32
-    L.msim_pairs_argmax_bf16.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
-    L.msim_pairs_argmax_bf16.restype = i32
-    L.msim_pairs_bwd_bf16.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]
-    L.msim_pairs_bwd_bf16.restype = i32
+    L.msim_fwd.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
+    L.msim_fwd.restype = i32
+    L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.msim_pairs_argmax.restype = i32
+    L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.msim_pairs_bwd.restype = i32
     L.msim_topk_workspace_bytes.argtypes = [i32, i64, i32]
     L.msim_topk_workspace_bytes.restype = sz
     L.msim_topk_f32.argtypes = [vp, vp, i32, i64, i64, i32, i64, vp, vp, vp, vp]
     L.msim_topk_f32.restype = i32
-    if L.msim_abi_version() != 1:
-        raise MaxSimLibraryError(f"ABI version mismatch: library reports {L.msim_abi_version()}, binding expects 1")
+    if L.msim_abi_version() != ABI_VERSION:
+        raise MaxSimLibraryError(f"ABI version mismatch: library reports {L.msim_abi_version()}, binding expects {ABI_VERSION} "
+                                 "(rebuild: make -C colpali_amd/csrc)")
     _lib = L
     return L
 

@@ -38,7 +38,7 @@ def block_clamp0(lengths: torch.Tensor, batch_size: int) -> torch.Tensor:
 
 @dataclass
 class PackedCorpus:
-    blob: torch.Tensor                 # bf16 [rows, 128], on the GPU
+    blob: torch.Tensor                 # bf16 | f16 [rows, 128], on the GPU
     offsets: torch.Tensor              # int32 [n+1], on the GPU
     clamp0: Optional[torch.Tensor]     # uint8 [n] on the GPU, or None
     lengths: torch.Tensor              # int64 [n], on the host
@@ -60,10 +60,10 @@ def _check_embeddings(x: torch.Tensor, what: str) -> None:
     if x.dim() not in (2, 3) or x.shape[-1] != EMBED_DIM:
         raise NotImplementedError(
             f"{what}: embedding dim {x.shape[-1] if x.dim() else '?'}; the gfx950 kernels are built for dim={EMBED_DIM}")
-    if x.dtype != torch.bfloat16:
+    if x.dtype not in (torch.bfloat16, torch.float16):
         raise NotImplementedError(
-            f"{what}: dtype {x.dtype}; the gfx950 kernels take bfloat16 embeddings (what the ColPali/ColQwen2 "
-            "forward emits). Converting silently would change the scores, so this is an error.")
+            f"{what}: dtype {x.dtype}; the gfx950 kernels take bfloat16 (what the ColPali/ColQwen2 forward emits) or "
+            "float16 embeddings. Converting silently would change the scores, so this is an error.")
 
 
 def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device,
@@ -87,6 +87,8 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
             if p.dim() != 2:
                 raise ValueError("each passage must be 2-D (sequence_length, dim)")
             _check_embeddings(p, "passages")
+            if p.dtype != ps[0].dtype:
+                raise RuntimeError(f"expected passages of one dtype, got {ps[0].dtype} and {p.dtype}")
         lengths = torch.tensor([p.shape[0] for p in ps], dtype=torch.int64)
         blob = torch.cat([p.reshape(-1, EMBED_DIM) for p in ps], dim=0).to(device, non_blocking=True).contiguous()
         clamp0 = None
@@ -100,7 +102,7 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
                     if int(lengths[j : j + batch_size].max()) == 0:
                         raise RuntimeError("max(): Expected reduction dim 3 to have non-zero size.")
     if blob.numel() == 0:  # keep a valid device pointer
-        blob = torch.zeros((1, EMBED_DIM), dtype=torch.bfloat16, device=device)
+        blob = torch.zeros((1, EMBED_DIM), dtype=blob.dtype, device=device)
     offsets = torch.zeros(lengths.numel() + 1, dtype=torch.int64)
     torch.cumsum(lengths, 0, out=offsets[1:])
     if int(offsets[-1]) >= 2**31:
@@ -110,7 +112,7 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
 
 
 def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device) -> torch.Tensor:
-    """[n_q, Lq, 128] bf16 on the device, zero padded.
+    """[n_q, Lq, 128] (bf16 | f16) on the device, zero padded.
 
     processing_utils.py:172 pads each 128-query block to its own longest query; a zero
     query row scores exactly 0 against everything (its max is 0), so padding all queries
@@ -127,4 +129,6 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
         if q.dim() != 2:
             raise ValueError("each query must be 2-D (sequence_length, dim)")
         _check_embeddings(q, "queries")
+        if q.dtype != qs[0].dtype:
+            raise RuntimeError(f"expected queries of one dtype, got {qs[0].dtype} and {q.dtype}")
     return torch.nn.utils.rnn.pad_sequence(list(qs), batch_first=True, padding_value=0).to(device, non_blocking=True).contiguous()

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
@@ -57,88 +58,178 @@ int device_info(const DeviceInfo **out) {
     return MSIM_OK;
 }
 
-constexpr int kStreamRing = 4;  // slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup
-
-template <int QT, int TPQ>
-int launch_stream(const void *Q, const void *D, const int32_t *d_off, const uint8_t *clamp0, float *scores,
-                  const msim::StreamArgs &a, const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing>;
-    constexpr int lds = 4 * kStreamRing * msim::kSlabBytes;
-    static std::atomic<int> configured[kMaxDevices];
+// kernels that ask for more than 64 KiB of dynamic LDS need the attribute raised once per (kernel, device)
+template <class Kern>
+int allow_lds(Kern kern, int bytes, std::atomic<int> *configured) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!configured[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
         configured[dev].store(1, std::memory_order_release);
     }
-    const int wg_needed = (a.n_d + 3) / 4;
-    const int wg_cap = di.cus * (di.lds_per_cu / lds);
-    const int grid = wg_needed < wg_cap ? wg_needed : wg_cap;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, static_cast<const uint16_t *>(Q),
-                       static_cast<const uint16_t *>(D), d_off, clamp0, scores, a);
+    return MSIM_OK;
+}
+
+int check_common(const void *Q, const void *D, const int32_t *d_off, int dtype, int dim, int Lq) {
+    if (!Q || !D || !d_off) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16)
+        return fail(MSIM_EUNSUPPORTED, "dtype code %d: the gfx950 kernels take bfloat16 (0) or float16 (1) embeddings", dtype);
+    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
+        return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
+    if ((Lq + msim::kTokTile - 1) / msim::kTokTile > 4)
+        return fail(MSIM_EUNSUPPORTED, "Lq=%d: queries longer than 128 tokens are not supported yet", Lq);
+    return MSIM_OK;
+}
+
+struct FwdCall {
+    const uint16_t *Q, *D;
+    const int32_t *d_off;
+    const uint8_t *clamp0;
+    float *scores;
+    long long ld;
+    int n_q, Lq, n_d;
+    unsigned flags;
+    const DeviceInfo *di;
+    hipStream_t st;
+};
+
+constexpr int kStreamRing = 4;  // slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup
+
+template <int QT, int TPQ, bool F16>
+int launch_stream(const FwdCall &c) {
+    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing, F16>;
+    constexpr int lds = 4 * kStreamRing * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    msim::StreamArgs a;
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.flags = c.flags;
+    const int wg_needed = (c.n_d + 3) / 4;
+    const int wg_cap = c.di->cus * (c.di->lds_per_cu / lds);
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, c.st, c.Q, c.D, c.d_off,
+                       c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_stream_kernel<%d,%d> launch: %s", QT, TPQ, hipGetErrorString(e));
     return MSIM_OK;
 }
 
-template <int NT, int TPQ>
-int launch_batch(const void *Q, const void *D, const int32_t *d_off, const uint8_t *clamp0, float *scores,
-                 int n_q, int Lq, int n_d, long long ld, unsigned flags, const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_batch_kernel<NT, TPQ>;
+template <int NT, int TPQ, bool F16>
+int launch_batch(const FwdCall &c) {
+    auto kern = msim::maxsim_batch_kernel<NT, TPQ, F16>;
     static std::atomic<int> configured[kMaxDevices];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!configured[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, msim::kBatchLds);
-        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", msim::kBatchLds, hipGetErrorString(e));
-        configured[dev].store(1, std::memory_order_release);
-    }
+    if (int rc = allow_lds(kern, msim::kBatchLds, configured)) return rc;
     msim::BatchArgs a;
-    a.ld = ld;
-    a.n_q = n_q;
-    a.Lq = Lq;
-    a.n_d = n_d;
-    a.flags = flags;
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.flags = c.flags;
     const int q_per_block = msim::kBatchWaves * NT / TPQ;
-    a.n_qblocks = (n_q + q_per_block - 1) / q_per_block;
+    a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
-    const int cus_per_xcd = di.cus / 8 > 0 ? di.cus / 8 : 1;
+    const int cus_per_xcd = c.di->cus / 8 > 0 ? c.di->cus / 8 : 1;
     const int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
     a.n_ranges = 8 * sub;
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
-    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), msim::kBatchLds, st, static_cast<const uint16_t *>(Q),
-                       static_cast<const uint16_t *>(D), d_off, clamp0, scores, a);
+    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), msim::kBatchLds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", NT, TPQ, hipGetErrorString(e));
     return MSIM_OK;
 }
 
-template <int TPQ>
-int launch_pairs_argmax(const void *Q, const void *D, const int32_t *d_off, const uint8_t *clamp0,
-                               const int32_t *pairs, float *out_scores, int32_t *out_argmax,
-                               const msim::PairsArgs &a, const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ>;
+// up to kStreamMaxTiles token tiles are held by every wave of K1s (HBM-bound regime, one pass over the corpus, no
+// barriers); above that K1b's workgroup blocking wins.  MSIM_STREAM_MAX_TILES is a tuning knob for A/B
+// measurements, not part of the ABI.
+int stream_max_tiles() {
+    static const int v = [] {
+        const char *e = getenv("MSIM_STREAM_MAX_TILES");
+        const int x = e ? atoi(e) : 8;
+        return x < 4 ? 4 : (x > 8 ? 8 : x);
+    }();
+    return v;
+}
+
+template <bool F16>
+int fwd_dispatch(const FwdCall &c) {
+    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    const int n_q = c.n_q;
+    if (n_q * tpq > stream_max_tiles()) {
+        if (tpq == 1) {
+            const int nt = (n_q + 7) / 8;
+            if (nt <= 1) return launch_batch<1, 1, F16>(c);
+            if (nt == 2) return launch_batch<2, 1, F16>(c);
+            if (nt == 3) return launch_batch<3, 1, F16>(c);
+            return launch_batch<4, 1, F16>(c);
+        }
+        if (tpq == 2) return n_q <= 8 ? launch_batch<2, 2, F16>(c) : launch_batch<4, 2, F16>(c);
+        if (tpq == 3) return launch_batch<3, 3, F16>(c);
+        return launch_batch<4, 4, F16>(c);
+    }
+    switch (n_q * 10 + tpq) {
+        case 11: return launch_stream<1, 1, F16>(c);
+        case 21: return launch_stream<2, 1, F16>(c);
+        case 31: return launch_stream<3, 1, F16>(c);
+        case 41: return launch_stream<4, 1, F16>(c);
+        case 51: return launch_stream<5, 1, F16>(c);
+        case 61: return launch_stream<6, 1, F16>(c);
+        case 71: return launch_stream<7, 1, F16>(c);
+        case 81: return launch_stream<8, 1, F16>(c);
+        case 12: return launch_stream<2, 2, F16>(c);
+        case 22: return launch_stream<4, 2, F16>(c);
+        case 32: return launch_stream<6, 2, F16>(c);
+        case 42: return launch_stream<8, 2, F16>(c);
+        case 13: return launch_stream<3, 3, F16>(c);
+        case 23: return launch_stream<6, 3, F16>(c);
+        case 14: return launch_stream<4, 4, F16>(c);
+        case 24: return launch_stream<8, 4, F16>(c);
+        default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
+    }
+}
+
+template <int TPQ, bool F16>
+int launch_pairs_argmax(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
+                        const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
+                        const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ, F16>;
     constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!configured[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-        configured[dev].store(1, std::memory_order_release);
-    }
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
     const int wg_needed = (a.n_pairs + 3) / 4;
     const int wg_cap = di.cus * (di.lds_per_cu / lds);
-    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, st,
-                       static_cast<const uint16_t *>(Q), static_cast<const uint16_t *>(D), d_off, clamp0, pairs,
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, st, Q, D, d_off, clamp0, pairs,
                        out_scores, out_argmax, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_argmax_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
     return MSIM_OK;
+}
+
+template <bool F16>
+int pairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
+                          const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
+                          const DeviceInfo &di, hipStream_t st) {
+    switch (tpq) {
+        case 1: return launch_pairs_argmax<1, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 2: return launch_pairs_argmax<2, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 3: return launch_pairs_argmax<3, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        default: return launch_pairs_argmax<4, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+    }
+}
+
+template <bool F16>
+void launch_pairs_bwd(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
+                      const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
+                      const msim::PairsArgs &a, hipStream_t st) {
+    if (a.n_q > 0)
+        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dq_kernel<F16>, dim3(a.n_q), dim3(256), 0, st, D, d_off, pairs, g, argmax, dQ, a);
+    const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
+    if (a.n_d > 0 && ry > 0)
+        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dd_kernel<F16>, dim3(a.n_d, ry), dim3(256), 0, st, Q, d_off, pairs,
+                           order_by_doc, g, argmax, dD, a);
 }
 
 }  // namespace
@@ -149,121 +240,68 @@ int msim_abi_version(void) { return MSIM_ABI_VERSION; }
 
 const char *msim_last_error(void) { return g_err; }
 
-size_t msim_fwd_workspace_bytes(int, int, int, int) { return 0; }
+size_t msim_fwd_workspace_bytes(int, int, int, int, int) { return 0; }
 
-int msim_fwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
-                  int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags, void *, void *stream) {
+int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+             int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags, void *, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0) return fail(MSIM_EINVAL, "negative size (n_q=%d n_d=%d Lq=%d)", n_q, n_d, Lq);
     if (n_q == 0 || n_d == 0) return MSIM_OK;
-    if (!Q || !D || !d_off || !scores) return fail(MSIM_EINVAL, "null pointer argument");
-    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
+    if (!scores) return fail(MSIM_EINVAL, "null pointer argument");
+    if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
     if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
-    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
-        return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
-    if (flags & ~(MSIM_FLAG_REF_BF16)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
-    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
-    if (tpq > 4) return fail(MSIM_EUNSUPPORTED, "Lq=%d: queries longer than 128 tokens are not supported yet", Lq);
-
-    const DeviceInfo *di = nullptr;
-    if (int rc = device_info(&di)) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-
-    // up to kStreamMaxTiles token tiles are held by every wave of K1s; above that K1b's workgroup blocking wins.
-    // (MSIM_STREAM_MAX_TILES is a tuning knob for A/B measurements, not part of the ABI.)
-    static const int stream_max_tiles = [] {
-        const char *e = getenv("MSIM_STREAM_MAX_TILES");
-        const int v = e ? atoi(e) : 8;
-        return v < 4 ? 4 : (v > 8 ? 8 : v);
-    }();
-    if (n_q * tpq > stream_max_tiles) {
-        // MFMA-bound regime: K1b, a workgroup holds 8 waves x NT token tiles
-        int rc;
-        if (tpq == 1) {
-            const int nt = (n_q + 7) / 8;
-            if (nt <= 1)      rc = launch_batch<1, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-            else if (nt == 2) rc = launch_batch<2, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-            else if (nt == 3) rc = launch_batch<3, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-            else              rc = launch_batch<4, 1>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-        } else if (tpq == 2) {
-            if (n_q <= 8) rc = launch_batch<2, 2>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-            else          rc = launch_batch<4, 2>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-        } else if (tpq == 3) {
-            rc = launch_batch<3, 3>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-        } else {
-            rc = launch_batch<4, 4>(Q, D, d_off, d_clamp0, scores, n_q, Lq, n_d, ld_scores, flags, *di, st);
-        }
-        return rc;
-    }
-
-    // HBM-bound regime: K1s, every wave holds all (<= 4) token tiles and streams its own documents
-    msim::StreamArgs a;
-    a.ld = ld_scores;
-    a.n_q = n_q;
-    a.Lq = Lq;
-    a.n_d = n_d;
-    a.flags = flags;
-    switch (n_q * 10 + tpq) {
-        case 11: return launch_stream<1, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 21: return launch_stream<2, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 31: return launch_stream<3, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 41: return launch_stream<4, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 12: return launch_stream<2, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 22: return launch_stream<4, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 13: return launch_stream<3, 3>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 14: return launch_stream<4, 4>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 51: return launch_stream<5, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 61: return launch_stream<6, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 71: return launch_stream<7, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 81: return launch_stream<8, 1>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 32: return launch_stream<6, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 42: return launch_stream<8, 2>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 23: return launch_stream<6, 3>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        case 24: return launch_stream<8, 4>(Q, D, d_off, d_clamp0, scores, a, *di, st);
-        default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
-    }
+    if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
+    FwdCall c;
+    if (int rc = device_info(&c.di)) return rc;
+    c.Q = static_cast<const uint16_t *>(Q);
+    c.D = static_cast<const uint16_t *>(D);
+    c.d_off = d_off;
+    c.clamp0 = d_clamp0;
+    c.scores = scores;
+    c.ld = ld_scores;
+    c.n_q = n_q;
+    c.Lq = Lq;
+    c.n_d = n_d;
+    c.flags = flags;
+    c.st = static_cast<hipStream_t>(stream);
+    return dtype == MSIM_DTYPE_F16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c);
 }
 
 // ---------------------------------------------------------------- pair lists (training losses)
-int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off,
-                           const uint8_t *d_clamp0, int n_d, int dim, const int32_t *pairs, int n_pairs,
-                           float *out_scores, int32_t *out_argmax, void *stream) {
+int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off,
+                      const uint8_t *d_clamp0, int n_d, int dim, const int32_t *pairs, int n_pairs,
+                      float *out_scores, int32_t *out_argmax, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0) return fail(MSIM_EINVAL, "negative size");
     if (n_pairs == 0) return MSIM_OK;
-    if (!Q || !D || !d_off || !pairs) return fail(MSIM_EINVAL, "null pointer argument");
-    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
-    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
-        return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
-    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
-    if (tpq > 4) return fail(MSIM_EUNSUPPORTED, "Lq=%d: queries longer than 128 tokens are not supported yet", Lq);
+    if (!pairs) return fail(MSIM_EINVAL, "null pointer argument");
+    if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
     const DeviceInfo *di = nullptr;
     if (int rc = device_info(&di)) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
-    switch (tpq) {
-        case 1: return launch_pairs_argmax<1>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
-        case 2: return launch_pairs_argmax<2>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
-        case 3: return launch_pairs_argmax<3>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
-        default: return launch_pairs_argmax<4>(Q, D, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
-    }
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == MSIM_DTYPE_F16
+               ? pairs_argmax_dispatch<true>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st)
+               : pairs_argmax_dispatch<false>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
 }
 
-int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
-                        int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g,
-                        const int32_t *argmax, int n_pairs, float *dQ, float *dD, void *stream) {
+int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
+                   int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g,
+                   const int32_t *argmax, int n_pairs, float *dQ, float *dD, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
-    if (!Q || !D || !d_off || !dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
+    if (!dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
     if (n_pairs > 0 && (!pairs || !order_by_doc || !g || !argmax)) return fail(MSIM_EINVAL, "null pair-list argument");
-    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
+    if ((max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows > 65535)
+        return fail(MSIM_EUNSUPPORTED, "max_doc_rows=%d too large", max_doc_rows);
+    if (n_d > 0x7fffffff / 2) return fail(MSIM_EUNSUPPORTED, "too many documents");
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
-    if (n_q > 0)
-        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dq_kernel, dim3(n_q), dim3(256), 0, st,
-                           static_cast<const uint16_t *>(D), d_off, pairs, g, argmax, dQ, a);
-    const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
-    if (ry > 65535) return fail(MSIM_EUNSUPPORTED, "max_doc_rows=%d too large", max_doc_rows);
-    if (n_d > 0 && ry > 0)
-        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dd_kernel, dim3(n_d, ry), dim3(256), 0, st,
-                           static_cast<const uint16_t *>(Q), d_off, pairs, order_by_doc, g, argmax, dD, a);
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == MSIM_DTYPE_F16)
+        launch_pairs_bwd<true>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);
+    else
+        launch_pairs_bwd<false>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_bwd launch: %s", hipGetErrorString(e));
     return MSIM_OK;

@@ -52,7 +52,7 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 
 // NT : token tiles (32 tokens) per wave, 1..4.  TPQ: token tiles per query (NT % TPQ == 0): a wave holds
 // NT/TPQ whole queries, a workgroup 8*NT/TPQ.
-template <int NT, int TPQ>
+template <int NT, int TPQ, bool F16>
 __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
             for (int ks = 0; ks < kKSteps; ++ks) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
 #pragma unroll
-                for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[t][ks], accA[t], 0, 0, 0);
+                for (int t = 0; t < NA; ++t) accA[t] = mfma32<F16>(af, qf[t][ks], accA[t]);
             }
             if constexpr (NB > 0) {
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
                     const bf16x8 af = *reinterpret_cast<const bf16x8 *>(smem + src_b + rd_off[ks]);
 #pragma unroll
                     for (int t = 0; t < NB; ++t)
-                        accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[NA + t][ks], accB[t], 0, 0, 0);
+                        accB[t] = mfma32<F16>(af, qf[NA + t][ks], accB[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < NA; ++t) m[t] = fold_max16(m[t], accA[t]);             // this slab's pass A
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
             for (int t = 0; t < NT; ++t) {
                 float v = fmaxf(m[t], __shfl_xor(m[t], 32));
                 if (clamp) v = fmaxf(v, 0.0f);
-                if (ref_bf16) v = bf16_round(v);
+                if (ref_bf16) v = round_to_input<F16>(v);
                 tile_sum[t] = half_wave_sum(v);
             }
             if (lane == 0) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
                     float tot = 0.0f;
 #pragma unroll
                     for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[qq * TPQ + tt];
-                    if (ref_bf16) tot = bf16_round(tot);
+                    if (ref_bf16) tot = round_to_input<F16>(tot);
                     if (q_first + qq < a.n_q) scores[(size_t)(q_first + qq) * a.ld + c_idx] = tot;
                 }
             }

@@ -8,6 +8,11 @@ namespace msim {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator fragment
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// Embedding element types the kernels are instantiated for (16-bit, MFMA K=16).  The register/LDS images are
+// identical (8 elements = 16 B per lane), only the MFMA opcode and the scalar conversions differ.
+constexpr int kDtypeBf16 = 0, kDtypeF16 = 1;
 
 constexpr int kDim = 128;                 // embedding width the kernels are built for
 constexpr int kRowBytes = kDim * 2;       // one bf16 patch row = 256 B = one LDS bank row
@@ -43,6 +48,29 @@ __device__ __forceinline__ float bf16_round(float x) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return __uint_as_float((u | 0x00400000u) & 0xffff0000u);
     u += 0x7fffu + ((u >> 16) & 1u);
     return __uint_as_float(u & 0xffff0000u);
+}
+
+// D = A * B + C on one 32x32x16 tile; operands travel as 8 x 16-bit lanes whatever the element type
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// round an fp32 value to the embedding dtype and back (what torch does when it stores an intermediate in that dtype)
+template <bool F16>
+__device__ __forceinline__ float round_to_input(float x) {
+    if constexpr (F16) return (float)(_Float16)x;
+    else return bf16_round(x);
+}
+
+// one stored 16-bit element -> fp32
+template <bool F16>
+__device__ __forceinline__ float elem_to_float(uint16_t v) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+    else return __uint_as_float((uint32_t)v << 16);
 }
 
 // sum over lanes 0..31 of each 32-lane half (result valid in every lane of the half)

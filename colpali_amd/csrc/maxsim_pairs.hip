@@ -30,7 +30,7 @@ struct PairsArgs {
 
 // One wave per pair (4 pairs per workgroup, wave-private LDS ring as in K1s).
 // TPQ = ceil(Lq / 32) token tiles of the pair's query live in registers.
-template <int TPQ>
+template <int TPQ, bool F16>
 __global__ __launch_bounds__(256) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
                                                                   const uint16_t *__restrict__ D,
                                                                   const int32_t *__restrict__ d_off,
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void maxsim_pairs_argmax_kernel(const uint16_t
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < kKSteps; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[t][ks], acc, 0, 0, 0);
+                    acc = mfma32<F16>(af[ks], qf[t][ks], acc);
                 // rows are visited in increasing order inside a lane, strict '>' keeps the first maximum
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -160,6 +160,7 @@ __device__ __forceinline__ int lower_bound_idx(int n, int v, KeyFn key) {
 
 // dQ[b, i, :] = sum over this query's pairs of g * D[c, argmax, :].  One workgroup per query, one wave per
 // token (strided); lane owns dims 2*lane, 2*lane+1.  `pairs` sorted by query index.
+template <bool F16>
 __global__ __launch_bounds__(256) void maxsim_pairs_bwd_dq_kernel(const uint16_t *__restrict__ D,
                                                                   const int32_t *__restrict__ d_off,
                                                                   const int32_t *__restrict__ pairs,
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void maxsim_pairs_bwd_dq_kernel(const uint16_t
             const int c = pairs[2 * p + 1];
             const uint32_t w = *reinterpret_cast<const uint32_t *>(D + ((size_t)d_off[c] + arg) * kDim + 2 * lane);
             const float gp = g[p];
-            acc0 += gp * __uint_as_float(w << 16);
-            acc1 += gp * __uint_as_float(w & 0xffff0000u);
+            acc0 += gp * elem_to_float<F16>((uint16_t)(w & 0xffffu));
+            acc1 += gp * elem_to_float<F16>((uint16_t)(w >> 16));
         }
         *reinterpret_cast<float2 *>(dQ + ((size_t)b * a.Lq + i) * kDim + 2 * lane) = make_float2(acc0, acc1);
     }
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void maxsim_pairs_bwd_dq_kernel(const uint16_t
 // thread t owns column (t & 127) of the rows with parity (t >> 7), and walks this document's
 // (pair, token) entries in a fixed order.  `order_by_doc` lists pair indices sorted by document.
 constexpr int kBwdRows = 64;
+template <bool F16>
 __global__ __launch_bounds__(256) void maxsim_pairs_bwd_dd_kernel(const uint16_t *__restrict__ Q,
                                                                   const int32_t *__restrict__ d_off,
                                                                   const int32_t *__restrict__ pairs,
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void maxsim_pairs_bwd_dd_kernel(const uint16_t
             const int r = argmax[(size_t)p * a.Lq + i] - r_lo;
             if (r < 0 || r >= rows || (r & 1) != half) continue;
             const uint16_t qv = Q[((size_t)b * a.Lq + i) * kDim + dim];
-            tile[r][dim] += gp * __uint_as_float((uint32_t)qv << 16);
+            tile[r][dim] += gp * elem_to_float<F16>(qv);
         }
     }
     // every row of the tile is owned by one half: no barrier needed between accumulate and write-out

@@ -41,7 +41,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // QT  : token tiles (of 32 tokens) held by every wave = n_q * TPQ
 // TPQ : token tiles per query = ceil(Lq / 32)
 // RING: slabs in the wave-private LDS ring
-template <int QT, int TPQ, int RING>
+// F16 : embeddings are IEEE half instead of bfloat16
+template <int QT, int TPQ, int RING, bool F16>
 __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
                                                             const uint16_t *__restrict__ D,       // [rows, 128] bf16
                                                             const int32_t *__restrict__ d_off,    // [n_d + 1]
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < kKSteps; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[t][ks], acc, 0, 0, 0);
+                    acc = mfma32<F16>(af[ks], qf[t][ks], acc);
                 if (rows_left < kSlabRows) {  // tail slab: rows past the document end do not exist
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
         for (int t = 0; t < QT; ++t) {
             float v = fmaxf(m[t], __shfl_xor(m[t], 32));
             if (clamp) v = fmaxf(v, 0.0f);
-            if (ref_bf16) v = bf16_round(v);
+            if (ref_bf16) v = round_to_input<F16>(v);
             tile_sum[t] = half_wave_sum(v);
         }
         if (lane == 0) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
                 float tot = 0.0f;
 #pragma unroll
                 for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[q * TPQ + tt];
-                if (ref_bf16) tot = bf16_round(tot);
+                if (ref_bf16) tot = round_to_input<F16>(tot);
                 scores[(size_t)q * a.ld + c_idx] = tot;
             }
         }

@@ -39,10 +39,11 @@ def _check_embeddings(q: torch.Tensor, d: torch.Tensor) -> None:
         raise RuntimeError(f"expected query and doc embeddings of one dtype, got {q.dtype} and {d.dtype}")
     if q.device.type != "cuda" or d.device != q.device:
         raise RuntimeError("colpali_amd losses run on an MI355X only (no CPU fallback): move the embeddings to the GPU")
-    if q.dtype != torch.bfloat16 or q.shape[2] != 128:
+    if q.dtype not in (torch.bfloat16, torch.float16) or q.shape[2] != 128:
         raise NotImplementedError(
-            f"colpali_amd losses take bf16 embeddings of dim 128 (got {q.dtype}, dim {q.shape[2]}); "
-            "converting silently would change the loss, so this is an error")
+            f"colpali_amd losses take bf16/fp16 embeddings of dim 128 (got {q.dtype}, dim {q.shape[2]}); fp32 embeddings "
+            "are accepted under torch.autocast (where the reference's einsum runs in the autocast dtype as well). "
+            "Converting silently would change the loss, so this is an error")
 
 
 class _MaxSim(torch.autograd.Function):
@@ -75,10 +76,10 @@ def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
     scores = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if want_scores else None
     argmax = torch.empty((n_pairs, Lq), dtype=torch.int32, device=dev) if want_argmax else None
     with torch.cuda.device(dev):
-        rc = L.msim_pairs_argmax_bf16(_lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), None, C, dim,
-                                      _lib.ptr(pairs), n_pairs, _lib.ptr(scores), _lib.ptr(argmax),
-                                      _lib.current_stream_handle(dev))
-    _lib.check(rc, "msim_pairs_argmax_bf16")
+        rc = L.msim_pairs_argmax(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), None, C,
+                                 dim, _lib.ptr(pairs), n_pairs, _lib.ptr(scores), _lib.ptr(argmax),
+                                 _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_pairs_argmax")
     return scores, argmax
 
 
@@ -100,10 +101,10 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
     order = torch.sort(pairs64[:, 1], stable=True).indices.to(torch.int32).contiguous()
     _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
     with torch.cuda.device(dev):
-        rc = L.msim_pairs_bwd_bf16(_lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
-                                   _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), n_pairs,
-                                   _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
-    _lib.check(rc, "msim_pairs_bwd_bf16")
+        rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
+                              _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), n_pairs,
+                              _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_pairs_bwd")
     return dq, dd
 
 
@@ -131,10 +132,10 @@ class _MaxSimPairs(torch.autograd.Function):
         dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
         dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = L.msim_pairs_bwd_bf16(_lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
-                                       _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
-                                       _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
-        _lib.check(rc, "msim_pairs_bwd_bf16")
+            rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
+                                  _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
+                                  _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+        _lib.check(rc, "msim_pairs_bwd")
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
                 dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
 
@@ -144,12 +145,29 @@ def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, 
 
     Fused form of the paired contractions "bnd,bsd->bns" / "bnd,blsd->blns" followed by amax/sum
     (late_interaction_losses.py:235-240, :381-386)."""
+    query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
     return _MaxSimPairs.apply(query_embeddings, doc_embeddings, pairs)
 
 
+def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
+    """Under torch.autocast the reference's einsum (late_interaction_losses.py:297) is an autocast-to-lower-precision
+    op: fp32 embeddings are cast to the autocast dtype before the contraction (models emit fp32 there because
+    `proj / proj.norm()` promotes, modeling_colqwen2.py:68).  Do exactly that cast -- it is differentiable, so the
+    gradients arrive in the embeddings' own dtype -- and only then hand over to the kernels."""
+    if torch.is_autocast_enabled("cuda"):
+        lowp = torch.get_autocast_dtype("cuda")
+        if lowp in (torch.bfloat16, torch.float16):
+            if q.dtype in (torch.float32, torch.bfloat16, torch.float16) and q.dtype != lowp:
+                q = q.to(lowp)
+            if d.dtype in (torch.float32, torch.bfloat16, torch.float16) and d.dtype != lowp:
+                d = d.to(lowp)
+    return q, d
+
+
 def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torch.Tensor:
     """Differentiable fused MaxSim: fp32 [B, C] (late_interaction_losses.py:297-298 without the 4-D tensor)."""
+    query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
     return _MaxSim.apply(query_embeddings, doc_embeddings)
 

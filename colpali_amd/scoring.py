@@ -43,16 +43,22 @@ def _require_gpu(device: Union[str, torch.device]) -> torch.device:
     return dev
 
 
-def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_bf16: bool = False,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Device-level entry: [n_q, Lq, 128] bf16 device tensor x packed corpus -> fp32 [n_q, n] on the device.
+def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: bool = False,
+                  out: Optional[torch.Tensor] = None, ref_bf16: Optional[bool] = None) -> torch.Tensor:
+    """Device-level entry: [n_q, Lq, 128] bf16|f16 device tensor x packed corpus -> fp32 [n_q, n] on the device.
 
-    Asynchronous on torch's current stream.  `ref_bf16=True` reproduces the rounding the
-    reference applies when it is handed bf16 tensors (processing_utils.py:179 in bf16).
+    Asynchronous on torch's current stream.  `ref_rounding=True` reproduces the rounding the reference
+    applies when torch evaluates processing_utils.py:179 in the embeddings' own 16-bit dtype
+    (`ref_bf16` is the older name of the same switch).
     """
+    if ref_bf16 is not None:
+        ref_rounding = ref_bf16
     L = _lib.lib()
-    if queries.dtype != torch.bfloat16 or queries.dim() != 3 or not queries.is_contiguous():
-        raise ValueError("queries must be a contiguous bf16 [n_q, Lq, 128] tensor")
+    if queries.dim() != 3 or not queries.is_contiguous():
+        raise ValueError("queries must be a contiguous [n_q, Lq, 128] tensor")
+    if queries.dtype != corpus.blob.dtype:   # torch.einsum raises on mixed dtypes too (SURVEY App. B 11)
+        raise RuntimeError(f"expected queries and passages of one dtype, got {queries.dtype} and {corpus.blob.dtype}")
+    dt = _lib.dtype_code(queries.dtype)
     if queries.device != corpus.device:
         raise ValueError("queries and corpus live on different devices")
     n_q, Lq, dim = queries.shape
@@ -62,11 +68,11 @@ def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_bf16: bool
     elif out.shape != (n_q, n) or out.dtype != torch.float32 or out.stride(1) != 1:
         raise ValueError("out must be fp32 [n_q, n] with unit inner stride")
     with torch.cuda.device(queries.device):
-        rc = L.msim_fwd_bf16(_lib.ptr(queries), n_q, Lq, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
-                             _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out), out.stride(0) if n_q > 1 else max(n, 1),
-                             _lib.MSIM_FLAG_REF_BF16 if ref_bf16 else 0, None,
-                             _lib.current_stream_handle(queries.device))
-    _lib.check(rc, "msim_fwd_bf16")
+        rc = L.msim_fwd(dt, _lib.ptr(queries), n_q, Lq, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
+                        _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out), out.stride(0) if n_q > 1 else max(n, 1),
+                        _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0, None,
+                        _lib.current_stream_handle(queries.device))
+    _lib.check(rc, "msim_fwd")
     return out
 
 

@@ -19,7 +19,7 @@
  *   - matrices are row-major and contiguous, embeddings are 16-byte aligned.
  *
  * Data layout ("packed corpus")
- *   D        bf16 [total_rows, dim]  every document's patch embeddings, back to back
+ *   D        bf16|f16 [total_rows, dim]  every document's patch embeddings, back to back
  *   d_off    int32 [n_d + 1]         document c owns rows d_off[c] .. d_off[c+1]-1
  *   d_clamp0 uint8 [n_d] or NULL     1 = the reference would have zero-padded this
  *                                    document inside its passage block, so a
@@ -27,7 +27,7 @@
  *                                    every per-token max
  *                                    (colpali_engine/utils/processing_utils.py:175-178,
  *                                     pad_sequence(..., padding_value=0))
- *   Q        bf16 [n_q, Lq, dim]     queries, zero rows = padding (they add 0)
+ *   Q        bf16|f16 [n_q, Lq, dim]     queries (same dtype as D), zero rows = padding (they add 0)
  */
 #ifndef COLPALI_AMD_MAXSIM_H
 #define COLPALI_AMD_MAXSIM_H
@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 1
+#define MSIM_ABI_VERSION 2
 
 /* error codes */
 #define MSIM_OK 0
@@ -47,18 +47,22 @@ extern "C" {
 #define MSIM_EUNSUPPORTED (-2) /* shape/dtype outside what the gfx950 kernels implement */
 #define MSIM_ELAUNCH (-3)      /* HIP reported an error at launch/configuration time */
 
-/* flags for msim_fwd_bf16 */
-#define MSIM_FLAG_REF_BF16 0x1u   /* reproduce the reference's bf16-input rounding:
-                                     every similarity rounded to bf16 before the max,
-                                     the token sum rounded to bf16
-                                     (processing_utils.py:179 evaluated on bf16 tensors) */
+/* embedding element types (`dtype` argument): 16-bit, fed to the MFMA as is, fp32 accumulate */
+#define MSIM_DTYPE_BF16 0
+#define MSIM_DTYPE_F16 1
+
+/* flags for msim_fwd */
+#define MSIM_FLAG_REF_ROUNDING 0x1u /* reproduce the rounding the reference applies when torch computes the
+                                       contraction in the embeddings' own dtype: every similarity rounded to
+                                       that dtype before the max, the token sum rounded to it
+                                       (processing_utils.py:179 evaluated on bf16 / fp16 tensors) */
 
 int msim_abi_version(void);
 const char *msim_last_error(void);
 
-/* Number of bytes of scratch msim_fwd_bf16 needs for this problem (0 today for
+/* Number of bytes of scratch msim_fwd needs for this problem (0 today for
  * every supported shape; kept in the ABI so callers size a workspace once). */
-size_t msim_fwd_workspace_bytes(int n_q, int Lq, int n_d, int dim);
+size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim);
 
 /*
  * scores[q, c] = sum_{i < Lq} max_{j in doc c} <Q[q,i,:], D[j,:]>      (fp32 accumulate)
@@ -70,9 +74,9 @@ size_t msim_fwd_workspace_bytes(int n_q, int Lq, int n_d, int dim);
  *       torch.einsum("bnd,csd->bcns", q, d) -> amax(dim=3) -> sum(dim=2)
  * without materialising the [b, c, n, s] similarity tensor.
  *
- * scores is fp32 [n_q, ld_scores] (ld_scores >= n_d).  dim must be 128.
+ * scores is fp32 [n_q, ld_scores] (ld_scores >= n_d).  dim must be 128, Lq <= 128.
  */
-int msim_fwd_bf16(const void *Q, int n_q, int Lq,
+int msim_fwd(int dtype, const void *Q, int n_q, int Lq,
                   const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
                   int n_d, int dim,
                   float *scores, int64_t ld_scores,
@@ -88,11 +92,11 @@ int msim_fwd_bf16(const void *Q, int n_q, int Lq,
  * pairs: int32 [n_pairs, 2] = (query index, document index).
  * out_scores: fp32 [n_pairs] or NULL; out_argmax: int32 [n_pairs, Lq] or NULL.  Lq <= 128.
  */
-int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq,
-                           const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
-                           int n_d, int dim,
-                           const int32_t *pairs, int n_pairs,
-                           float *out_scores, int32_t *out_argmax, void *stream);
+int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq,
+                      const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                      int n_d, int dim,
+                      const int32_t *pairs, int n_pairs,
+                      float *out_scores, int32_t *out_argmax, void *stream);
 
 /*
  * Backward of the contraction for a sparse set of (q, c) pairs with upstream gradient
@@ -107,11 +111,11 @@ int msim_pairs_argmax_bf16(const void *Q, int n_q, int Lq,
  * `pairs` must be sorted by query index; `order_by_doc` is a permutation of 0..n_pairs-1 that
  * sorts the pairs by document index (stable); `max_doc_rows` >= the longest document.
  */
-int msim_pairs_bwd_bf16(const void *Q, int n_q, int Lq,
-                        const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
-                        const int32_t *pairs, const int32_t *order_by_doc,
-                        const float *g, const int32_t *argmax, int n_pairs,
-                        float *dQ, float *dD, void *stream);
+int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
+                   const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
+                   const int32_t *pairs, const int32_t *order_by_doc,
+                   const float *g, const int32_t *argmax, int n_pairs,
+                   float *dQ, float *dD, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -148,3 +148,43 @@ def test_explicit_negative_variants(amd, cls, kind, offset):
         assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq), paths=3), (cls, vname, "dQ")
         assert grads_close(d.grad, want_dd, d_real.expand_as(want_dd), paths=2), (cls, vname, "dD")
         assert grads_close(n.grad, want_dn, n_real.expand_as(want_dn)), (cls, vname, "dN")
+
+
+@pytest.mark.parametrize("lowp", [torch.bfloat16, torch.float16])
+def test_fp32_embeddings_under_autocast_follow_the_reference_autocast_semantics(amd, lowp):
+    """Under torch.autocast the reference's einsum runs in the autocast dtype on casts of the fp32 embeddings
+    (the models emit fp32 there); the drop-in does the same cast, gradients come back in fp32."""
+    g = torch.Generator().manual_seed(17)
+    B, C, Lq, Ld = 8, 24, 20, 100
+    Q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1)
+    for b in range(B):
+        D[b, :Lq] = torch.nn.functional.normalize(Q[b] + 0.5 * torch.randn(Lq, 128, generator=g), dim=-1)
+    want_loss, want_dq, want_dd = lo.loss_and_grads("pairwise", Q.to(lowp).float(), D.to(lowp).float(), normalize_scores=False)
+    q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=lowp):
+        loss = amd.ColbertPairwiseCELoss(normalize_scores=False)(q, d)
+    loss.backward()
+    assert q.grad.dtype == torch.float32 and d.grad.dtype == torch.float32
+    assert abs(float(loss.detach()) - float(want_loss)) <= 1e-3 * abs(float(want_loss)) + 1e-6
+    # gradients pass through one 16-bit rounding (the kernel returns them in the autocast dtype) before the fp32 cast
+    rel = 2.0**-7 if lowp == torch.bfloat16 else 2.0**-10
+    assert torch.all((q.grad.cpu() - want_dq.float()).abs() <= want_dq.float().abs() * rel + 1e-5)
+    assert torch.all((d.grad.cpu() - want_dd.float()).abs() <= want_dd.float().abs() * rel + 1e-5)
+    with pytest.raises(NotImplementedError, match="autocast"):
+        amd.ColbertPairwiseCELoss()(Q.cuda(), D.cuda())          # fp32 without autocast: no silent conversion
+
+
+def test_float16_loss_and_grads(amd):
+    g = torch.Generator().manual_seed(23)
+    B, C, Lq, Ld = 6, 18, 33, 70
+    Q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1).to(torch.float16)
+    D = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1).to(torch.float16)
+    want_loss, want_dq, want_dd = lo.loss_and_grads("infonce", Q.float(), D.float(), offset=6, temperature=0.5)
+    q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+    loss = amd.ColbertLoss(temperature=0.5)(q, d, offset=6)
+    assert loss.dtype == torch.float16
+    assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-10 * abs(float(want_loss)) + 1e-4
+    loss.backward()
+    assert torch.all((q.grad.float().cpu() - want_dq.float()).abs() <= want_dq.float().abs() * 2.0**-9 + 2e-5)
+    assert torch.all((d.grad.float().cpu() - want_dd.float()).abs() <= want_dd.float().abs() * 2.0**-9 + 2e-5)

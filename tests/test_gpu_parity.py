@@ -147,6 +147,25 @@ def test_stream_and_batch_kernels_agree_bitwise_on_shared_queries(amd):
         assert torch.equal(one[0], big[i])
 
 
+@pytest.mark.parametrize("n_q,lq_max,n_d,ld_max", [(2, 32, 200, 700), (7, 32, 150, 300), (40, 40, 120, 500)])
+def test_float16_embeddings_against_oracle(amd, n_q, lq_max, n_d, ld_max):
+    # fp16 inputs go to the f16 MFMA (products of fp16 values are exact in fp32, like bf16)
+    qs, ps = _random_case(31 + n_q, n_q, lq_max, n_d, ld_max)
+    qs = [q.float().to(torch.float16) for q in qs]
+    ps = [p.float().to(torch.float16) for p in ps]
+    got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, 128))
+
+
+def test_mixed_dtypes_are_an_error_like_in_the_reference(amd):
+    q = [torch.zeros(4, 128, dtype=torch.bfloat16)]
+    p = [torch.zeros(4, 128, dtype=torch.float16)]
+    with pytest.raises(RuntimeError, match="one dtype"):
+        amd.score_multi_vector(q, p, device="cuda:0")
+    with pytest.raises(NotImplementedError, match="dtype"):
+        amd.score_multi_vector([torch.zeros(4, 128)], [torch.zeros(4, 128)], device="cuda:0")
+
+
 def test_empty_inputs_raise_before_any_device_work(amd):
     with pytest.raises(ValueError, match="No queries provided"):
         amd.score_multi_vector([], [torch.zeros(2, 128, dtype=torch.bfloat16)], device="cuda:0")

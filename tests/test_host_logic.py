@@ -26,7 +26,7 @@ def bf(n, dim=128, seed=0):
 def test_abi_library_loads_and_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "maxsim.h")).read()
     declared = set(re.findall(r"\b(msim_[a-z0-9_]+)\s*\(", header))
-    assert {"msim_abi_version", "msim_last_error", "msim_fwd_bf16", "msim_topk_f32"} <= declared
+    assert {"msim_abi_version", "msim_last_error", "msim_fwd", "msim_pairs_argmax", "msim_pairs_bwd", "msim_topk_f32"} <= declared
     lib = ctypes.CDLL(colpali_amd._lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/maxsim.h but not exported"
@@ -38,13 +38,14 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
 def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     L = colpali_amd._lib.lib()
     # dim != 128 -> MSIM_EUNSUPPORTED before any device work
-    rc = L.msim_fwd_bf16(16, 1, 32, 16, 16, None, 1, 64, 16, 1, 0, None, None)
+    rc = L.msim_fwd(0, 16, 1, 32, 16, 16, None, 1, 64, 16, 1, 0, None, None)
     assert rc == -2 and b"dim" in L.msim_last_error()
-    rc = L.msim_fwd_bf16(None, 1, 32, 16, 16, None, 1, 128, 16, 1, 0, None, None)
+    rc = L.msim_fwd(0, None, 1, 32, 16, 16, None, 1, 128, 16, 1, 0, None, None)
     assert rc == -1
-    rc = L.msim_fwd_bf16(16, 1, 32, 16, 16, None, 4, 128, 16, 2, 0, None, None)   # ld < n_d
+    rc = L.msim_fwd(1, 16, 1, 32, 16, 16, None, 4, 128, 16, 2, 0, None, None)   # ld < n_d
     assert rc == -1
-    assert L.msim_fwd_bf16(16, 0, 32, 16, 16, None, 4, 128, 16, 4, 0, None, None) == 0   # empty problem is a no-op
+    assert L.msim_fwd(0, 16, 0, 32, 16, 16, None, 4, 128, 16, 4, 0, None, None) == 0   # empty problem is a no-op
+    assert L.msim_fwd(7, 16, 1, 32, 16, 16, None, 1, 128, 16, 1, 0, None, None) == -2   # unknown dtype code
     assert L.msim_topk_f32(16, None, 1, 10, 10, 2000, 0, 16, 16, None, None) == -2      # k too large
     with pytest.raises(NotImplementedError):
         colpali_amd._lib.check(-2, "x")
