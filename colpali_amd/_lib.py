@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def dtype_code(dtype) -> int:
@@ -23,7 +23,24 @@ def dtype_code(dtype) -> int:
         return 0
     if dtype == torch.float16:
         return 1
-    raise NotImplementedError(f"dtype {dtype}: the gfx950 kernels take bfloat16 or float16 embeddings")
+    if dtype == torch.float32:
+        return 2
+    raise NotImplementedError(f"dtype {dtype}: the gfx950 kernels take bfloat16, float16 or float32 embeddings")
+
+
+def kernel_width(dim: int, dtype) -> int:
+    """Physical row width (elements) the kernels need for a logical embedding width `dim`.
+
+    bf16/f16 rows of 128 go to the tuned kernels as they are; every other shape goes to the generic kernels,
+    whose rows are a multiple of 32 bytes: the width is padded with zero columns (no dot product changes)."""
+    es = 4 if dtype == torch.float32 else 2
+    if es == 2 and dim == 128:
+        return dim
+    per = 32 // es
+    width = (dim + per - 1) // per * per
+    if width * es > 4096:
+        raise NotImplementedError(f"embedding rows of {dim} x {es} bytes exceed the 4 KiB the gfx950 kernels support")
+    return width
 
 _lib = None
 

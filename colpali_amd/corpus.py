@@ -1,6 +1,7 @@
 """Device-resident packed corpus: the data layout the gfx950 kernels stream.
 
-    blob    bf16 [total_rows, 128]   all passages' patch embeddings back to back
+    blob    bf16|f16|f32 [total_rows, width]   all passages' patch embeddings back to back (width = dim, zero-padded
+                                     to a multiple of 32 bytes when it is not the tuned 128 x 16-bit row)
     offsets int32 [n + 1]            passage c owns rows offsets[c] .. offsets[c+1]-1
     clamp0  uint8 [n] or None        1 = the reference zero-pads this passage inside its
                                      passage block, so a similarity of 0 joins every
@@ -16,7 +17,9 @@ from typing import List, Optional, Sequence, Union
 
 import torch
 
-EMBED_DIM = 128
+from ._lib import kernel_width
+
+EMBED_DIM = 128   # the width the tuned kernels are built for (ColPali / ColQwen2 projection dim)
 
 
 def block_clamp0(lengths: torch.Tensor, batch_size: int) -> torch.Tensor:
@@ -38,7 +41,7 @@ def block_clamp0(lengths: torch.Tensor, batch_size: int) -> torch.Tensor:
 
 @dataclass
 class PackedCorpus:
-    blob: torch.Tensor                 # bf16 | f16 [rows, 128], on the GPU
+    blob: torch.Tensor                 # bf16 | f16 | f32 [rows, width], on the GPU
     offsets: torch.Tensor              # int32 [n+1], on the GPU
     clamp0: Optional[torch.Tensor]     # uint8 [n] on the GPU, or None
     lengths: torch.Tensor              # int64 [n], on the host
@@ -53,17 +56,25 @@ class PackedCorpus:
 
     @property
     def nbytes(self) -> int:
-        return self.blob.numel() * 2
+        return self.blob.numel() * self.blob.element_size()
 
 
 def _check_embeddings(x: torch.Tensor, what: str) -> None:
-    if x.dim() not in (2, 3) or x.shape[-1] != EMBED_DIM:
+    if x.dim() not in (2, 3):
+        raise ValueError(f"{what}: expected 2-D or 3-D embeddings")
+    if x.dtype not in (torch.bfloat16, torch.float16, torch.float32):
         raise NotImplementedError(
-            f"{what}: embedding dim {x.shape[-1] if x.dim() else '?'}; the gfx950 kernels are built for dim={EMBED_DIM}")
-    if x.dtype not in (torch.bfloat16, torch.float16):
-        raise NotImplementedError(
-            f"{what}: dtype {x.dtype}; the gfx950 kernels take bfloat16 (what the ColPali/ColQwen2 forward emits) or "
-            "float16 embeddings. Converting silently would change the scores, so this is an error.")
+            f"{what}: dtype {x.dtype}; the gfx950 kernels take bfloat16 (what the ColPali/ColQwen2 forward emits), "
+            "float16 or float32 embeddings. Converting silently would change the scores, so this is an error.")
+    kernel_width(x.shape[-1], x.dtype)   # raises for rows above 4 KiB
+
+
+def _widen(x: torch.Tensor) -> torch.Tensor:
+    """[rows, dim] -> [rows, kernel_width(dim)] with zero columns appended (a no-op for the tuned shape)."""
+    width = kernel_width(x.shape[-1], x.dtype)
+    if width == x.shape[-1]:
+        return x
+    return torch.nn.functional.pad(x, (0, width - x.shape[-1]))
 
 
 def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device,
@@ -74,10 +85,10 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
         if ps.dim() != 3:
             raise ValueError("a passage tensor must be 3-D (n_passages, max_len, dim)")
         _check_embeddings(ps, "passages")
-        n, L, _ = ps.shape
+        n, L, dim = ps.shape
         # slicing a 3-D tensor in blocks and pad_sequence over its rows is a re-stack: zero rows that are
         # physically present take part in the max on their own, no clamp flag needed
-        blob = ps.reshape(n * L, EMBED_DIM).to(device, non_blocking=True).contiguous()
+        blob = _widen(ps.reshape(n * L, dim).to(device, non_blocking=True)).contiguous()
         lengths = torch.full((n,), L, dtype=torch.int64)
         clamp0 = None
     else:
@@ -89,8 +100,11 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
             _check_embeddings(p, "passages")
             if p.dtype != ps[0].dtype:
                 raise RuntimeError(f"expected passages of one dtype, got {ps[0].dtype} and {p.dtype}")
+            if p.shape[1] != ps[0].shape[1]:
+                raise RuntimeError(f"expected passages of one embedding width, got {ps[0].shape[1]} and {p.shape[1]}")
+        dim = ps[0].shape[1]
         lengths = torch.tensor([p.shape[0] for p in ps], dtype=torch.int64)
-        blob = torch.cat([p.reshape(-1, EMBED_DIM) for p in ps], dim=0).to(device, non_blocking=True).contiguous()
+        blob = _widen(torch.cat([p.reshape(-1, dim) for p in ps], dim=0).to(device, non_blocking=True)).contiguous()
         clamp0 = None
         if batch_size is not None:
             flags = block_clamp0(lengths, batch_size)
@@ -102,7 +116,7 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
                     if int(lengths[j : j + batch_size].max()) == 0:
                         raise RuntimeError("max(): Expected reduction dim 3 to have non-zero size.")
     if blob.numel() == 0:  # keep a valid device pointer
-        blob = torch.zeros((1, EMBED_DIM), dtype=blob.dtype, device=device)
+        blob = torch.zeros((1, blob.shape[1]), dtype=blob.dtype, device=device)
     offsets = torch.zeros(lengths.numel() + 1, dtype=torch.int64)
     torch.cumsum(lengths, 0, out=offsets[1:])
     if int(offsets[-1]) >= 2**31:
@@ -112,7 +126,7 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
 
 
 def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device) -> torch.Tensor:
-    """[n_q, Lq, 128] (bf16 | f16) on the device, zero padded.
+    """[n_q, Lq, width] on the device, zero padded (rows beyond a query's length and columns beyond its width).
 
     processing_utils.py:172 pads each 128-query block to its own longest query; a zero
     query row scores exactly 0 against everything (its max is 0), so padding all queries
@@ -122,7 +136,7 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
         if qs.dim() != 3:
             raise ValueError("a query tensor must be 3-D (n_queries, max_len, dim)")
         _check_embeddings(qs, "queries")
-        return qs.to(device, non_blocking=True).contiguous()
+        return _widen(qs.to(device, non_blocking=True)).contiguous()
     if len(qs) == 0:
         raise ValueError("No queries provided")
     for q in qs:
@@ -131,4 +145,7 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
         _check_embeddings(q, "queries")
         if q.dtype != qs[0].dtype:
             raise RuntimeError(f"expected queries of one dtype, got {qs[0].dtype} and {q.dtype}")
-    return torch.nn.utils.rnn.pad_sequence(list(qs), batch_first=True, padding_value=0).to(device, non_blocking=True).contiguous()
+        if q.shape[1] != qs[0].shape[1]:
+            raise RuntimeError(f"expected queries of one embedding width, got {qs[0].shape[1]} and {q.shape[1]}")
+    padded = torch.nn.utils.rnn.pad_sequence(list(qs), batch_first=True, padding_value=0).to(device, non_blocking=True)
+    return _widen(padded).contiguous()

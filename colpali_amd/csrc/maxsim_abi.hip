@@ -14,6 +14,7 @@
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
 #include "maxsim_pairs.hip"
+#include "maxsim_generic.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -71,15 +72,29 @@ int allow_lds(Kern kern, int bytes, std::atomic<int> *configured) {
     return MSIM_OK;
 }
 
+// tuned = the dim=128 16-bit kernels (K1s / K1b / pair-list); everything else goes to the generic kernels (K1g)
+bool is_tuned(int dtype, int dim, int Lq) {
+    return (dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) && dim == msim::kDim &&
+           (Lq + msim::kTokTile - 1) / msim::kTokTile <= 4;
+}
+
+int elem_bytes(int dtype) { return dtype == MSIM_DTYPE_F32 ? 4 : 2; }
+
 int check_common(const void *Q, const void *D, const int32_t *d_off, int dtype, int dim, int Lq) {
     if (!Q || !D || !d_off) return fail(MSIM_EINVAL, "null pointer argument");
-    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16)
-        return fail(MSIM_EUNSUPPORTED, "dtype code %d: the gfx950 kernels take bfloat16 (0) or float16 (1) embeddings", dtype);
-    if (dim != msim::kDim) return fail(MSIM_EUNSUPPORTED, "dim=%d: the gfx950 kernels are built for dim=128", dim);
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16 && dtype != MSIM_DTYPE_F32)
+        return fail(MSIM_EUNSUPPORTED, "dtype code %d: the gfx950 kernels take bfloat16 (0), float16 (1) or float32 (2) embeddings",
+                    dtype);
     if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
         return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
-    if ((Lq + msim::kTokTile - 1) / msim::kTokTile > 4)
-        return fail(MSIM_EUNSUPPORTED, "Lq=%d: queries longer than 128 tokens are not supported yet", Lq);
+    if (dim <= 0) return fail(MSIM_EINVAL, "dim=%d", dim);
+    if (!is_tuned(dtype, dim, Lq)) {
+        const long long row_bytes = (long long)dim * elem_bytes(dtype);
+        if (row_bytes % 32 != 0)
+            return fail(MSIM_EUNSUPPORTED, "dim=%d: an embedding row must be a multiple of 32 bytes (pad the width with zero columns)", dim);
+        if (row_bytes > msim::kGenericMaxRowBytes)
+            return fail(MSIM_EUNSUPPORTED, "dim=%d: embedding rows above %d bytes are not supported", dim, msim::kGenericMaxRowBytes);
+    }
     return MSIM_OK;
 }
 
@@ -97,9 +112,20 @@ struct FwdCall {
 
 constexpr int kStreamRing = 4;  // slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup
 
-template <int QT, int TPQ, bool F16>
-int launch_stream(const FwdCall &c) {
-    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing, F16>;
+// Cache policy of K1s's document stream: every byte is read once by one CU, so the LDS-DMA loads carry `nt`
+// (do not allocate in L2 / MALL).  Measured on MI355X, 16 GiB shard: 6.31 -> 7.02 TB/s at 1 query, 6.08 -> 6.45 TB/s
+// at 4 queries.  MSIM_STREAM_NT=0 switches it off for A/B measurements (tuning knob, not part of the ABI).
+int stream_nt() {
+    static const int v = [] {
+        const char *e = getenv("MSIM_STREAM_NT");
+        return e ? (atoi(e) != 0) : 1;
+    }();
+    return v;
+}
+
+template <int QT, int TPQ, bool F16, int AUX>
+int launch_stream_aux(const FwdCall &c) {
+    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing, F16, AUX>;
     constexpr int lds = 4 * kStreamRing * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -116,6 +142,11 @@ int launch_stream(const FwdCall &c) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_stream_kernel<%d,%d> launch: %s", QT, TPQ, hipGetErrorString(e));
     return MSIM_OK;
+}
+
+template <int QT, int TPQ, bool F16>
+int launch_stream(const FwdCall &c) {
+    return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2>(c) : launch_stream_aux<QT, TPQ, F16, 0>(c);
 }
 
 template <int NT, int TPQ, bool F16>
@@ -232,6 +263,94 @@ void launch_pairs_bwd(const uint16_t *Q, const uint16_t *D, const int32_t *d_off
                            order_by_doc, g, argmax, dD, a);
 }
 
+// ---------------------------------------------------------------- generic kernels (K1g)
+struct GenericCall {
+    const char *Q, *D;
+    const int32_t *d_off;
+    const uint8_t *clamp0;
+    float *scores;
+    long long ld;
+    int n_q, Lq, n_d, row_bytes;
+    unsigned flags;
+    const DeviceInfo *di;
+    hipStream_t st;
+};
+
+template <int DT, int T>
+int launch_generic(const GenericCall &c) {
+    auto kern = msim::maxsim_generic_kernel<DT, T>;
+    const int lds = T * msim::kTokTile * (c.row_bytes + 16);
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, 160 * 1024, configured)) return rc;
+    msim::GenericArgs a;
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.row_bytes = c.row_bytes;
+    a.flags = c.flags;
+    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    const int groups = tpq <= T ? (c.n_q + (T / tpq) - 1) / (T / tpq) : c.n_q;
+    if (groups > 65535) return fail(MSIM_EUNSUPPORTED, "too many query groups (%d) for one launch", groups);
+    const int wg_needed = (c.n_d + msim::kGenericWaves - 1) / msim::kGenericWaves;
+    int per_cu = c.di->lds_per_cu / lds;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int wg_cap = c.di->cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap, groups), dim3(msim::kGenericWaves * 64), lds, c.st,
+                       c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_generic_kernel<%d,%d> launch: %s", DT, T, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <int DT>
+int generic_dispatch(const GenericCall &c) {
+    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    const long long tiles = (long long)c.n_q * tpq;
+    const int tile_lds = msim::kTokTile * (c.row_bytes + 16);
+    int T = 4;                                   // resident token tiles: as many as fit ~80 KiB (2 workgroups per CU)
+    while (T > 1 && (T * tile_lds > 80 * 1024 || T / 2 >= tiles)) T >>= 1;
+    switch (T) {
+        case 4: return launch_generic<DT, 4>(c);
+        case 2: return launch_generic<DT, 2>(c);
+        default: return launch_generic<DT, 1>(c);
+    }
+}
+
+int generic_fwd(int dtype, const GenericCall &c) {
+    switch (dtype) {
+        case MSIM_DTYPE_F32: return generic_dispatch<msim::kDtypeF32>(c);
+        case MSIM_DTYPE_F16: return generic_dispatch<msim::kDtypeF16>(c);
+        default: return generic_dispatch<msim::kDtypeBf16>(c);
+    }
+}
+
+template <int DT>
+int generic_pairs_argmax(const char *Q, const char *D, const int32_t *d_off, const uint8_t *clamp0, const int32_t *pairs,
+                         float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a, int row_bytes, const DeviceInfo &di,
+                         hipStream_t st) {
+    const int wg_needed = (a.n_pairs + 3) / 4;
+    const int wg_cap = di.cus * 8;
+    hipLaunchKernelGGL(msim::maxsim_generic_pairs_argmax_kernel<DT>, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), 0,
+                       st, Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, row_bytes);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_generic_pairs_argmax_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <int DT>
+void generic_pairs_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
+                       const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
+                       const msim::PairsArgs &a, int dim, hipStream_t st) {
+    if (a.n_q > 0)
+        hipLaunchKernelGGL(msim::maxsim_generic_bwd_dq_kernel<DT>, dim3(a.n_q), dim3(256), 0, st, D, d_off, pairs, g, argmax, dQ, a,
+                           dim);
+    const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
+    if (a.n_d > 0 && ry > 0)
+        hipLaunchKernelGGL(msim::maxsim_generic_bwd_dd_kernel<DT>, dim3(a.n_d, ry, (dim + 127) / 128), dim3(256), 0, st, Q, d_off,
+                           pairs, order_by_doc, g, argmax, dD, a, dim);
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,6 +369,23 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
     if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
     if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
     if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
+    if (!is_tuned(dtype, dim, Lq)) {
+        GenericCall c;
+        if (int rc = device_info(&c.di)) return rc;
+        c.Q = static_cast<const char *>(Q);
+        c.D = static_cast<const char *>(D);
+        c.d_off = d_off;
+        c.clamp0 = d_clamp0;
+        c.scores = scores;
+        c.ld = ld_scores;
+        c.n_q = n_q;
+        c.Lq = Lq;
+        c.n_d = n_d;
+        c.row_bytes = dim * elem_bytes(dtype);
+        c.flags = flags;
+        c.st = static_cast<hipStream_t>(stream);
+        return generic_fwd(dtype, c);
+    }
     FwdCall c;
     if (int rc = device_info(&c.di)) return rc;
     c.Q = static_cast<const uint16_t *>(Q);
@@ -278,8 +414,20 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, 
     if (int rc = device_info(&di)) return rc;
     const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
-    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!is_tuned(dtype, dim, Lq)) {
+        const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
+        const int rb = dim * elem_bytes(dtype);
+        switch (dtype) {
+            case MSIM_DTYPE_F32:
+                return generic_pairs_argmax<msim::kDtypeF32>(qc, dc, d_off, d_clamp0, pairs, out_scores, out_argmax, a, rb, *di, st);
+            case MSIM_DTYPE_F16:
+                return generic_pairs_argmax<msim::kDtypeF16>(qc, dc, d_off, d_clamp0, pairs, out_scores, out_argmax, a, rb, *di, st);
+            default:
+                return generic_pairs_argmax<msim::kDtypeBf16>(qc, dc, d_off, d_clamp0, pairs, out_scores, out_argmax, a, rb, *di, st);
+        }
+    }
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     return dtype == MSIM_DTYPE_F16
                ? pairs_argmax_dispatch<true>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st)
                : pairs_argmax_dispatch<false>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
@@ -298,7 +446,15 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, con
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
     const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == MSIM_DTYPE_F16)
+    if (!is_tuned(dtype, dim, Lq)) {
+        const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
+        if (dtype == MSIM_DTYPE_F32)
+            generic_pairs_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st);
+        else if (dtype == MSIM_DTYPE_F16)
+            generic_pairs_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st);
+        else
+            generic_pairs_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st);
+    } else if (dtype == MSIM_DTYPE_F16)
         launch_pairs_bwd<true>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);
     else
         launch_pairs_bwd<false>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);

@@ -42,7 +42,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // TPQ : token tiles per query = ceil(Lq / 32)
 // RING: slabs in the wave-private LDS ring
 // F16 : embeddings are IEEE half instead of bfloat16
-template <int QT, int TPQ, int RING, bool F16>
+// AUX : cache-policy bits of the LDS-DMA loads (0 = default, 2 = nt: streamed once, do not keep in L2 / MALL)
+template <int QT, int TPQ, int RING, bool F16, int AUX = 0>
 __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
                                                             const uint16_t *__restrict__ D,       // [rows, 128] bf16
                                                             const int32_t *__restrict__ d_off,    // [n_d + 1]
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3],
-                                                     soff + i * 1024, 0, 0);
+                                                     soff + i * 1024, 0, AUX);
         p_slot = (p_slot + 1 == RING) ? 0 : p_slot + 1;
         p_row += kSlabRows;
         if (p_row >= p_len) {

@@ -25,7 +25,7 @@ from .scoring import maxsim_scores
 
 
 def _dense_corpus(d: torch.Tensor) -> PackedCorpus:
-    """View a dense [C, Ld, 128] tensor as a packed corpus (no copy; zero rows stay physical rows)."""
+    """View a dense [C, Ld, width] tensor as a packed corpus (no copy; zero rows stay physical rows)."""
     C, Ld, _ = d.shape
     offsets = torch.arange(C + 1, dtype=torch.int32, device=d.device) * Ld
     return PackedCorpus(blob=d.view(C * Ld, d.shape[2]), offsets=offsets, clamp0=None,
@@ -39,11 +39,17 @@ def _check_embeddings(q: torch.Tensor, d: torch.Tensor) -> None:
         raise RuntimeError(f"expected query and doc embeddings of one dtype, got {q.dtype} and {d.dtype}")
     if q.device.type != "cuda" or d.device != q.device:
         raise RuntimeError("colpali_amd losses run on an MI355X only (no CPU fallback): move the embeddings to the GPU")
-    if q.dtype not in (torch.bfloat16, torch.float16) or q.shape[2] != 128:
+    if q.dtype not in (torch.bfloat16, torch.float16, torch.float32):
         raise NotImplementedError(
-            f"colpali_amd losses take bf16/fp16 embeddings of dim 128 (got {q.dtype}, dim {q.shape[2]}); fp32 embeddings "
-            "are accepted under torch.autocast (where the reference's einsum runs in the autocast dtype as well). "
-            "Converting silently would change the loss, so this is an error")
+            f"colpali_amd losses take bf16/fp16/fp32 embeddings (got {q.dtype}). Converting silently would change the "
+            "loss, so this is an error")
+    _lib.kernel_width(q.shape[2], q.dtype)   # raises for rows above 4 KiB
+
+
+def _widen(x: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the embedding width to what the kernels stream (differentiable; a no-op for 128 x 16-bit rows)."""
+    width = _lib.kernel_width(x.shape[-1], x.dtype)
+    return x if width == x.shape[-1] else F.pad(x, (0, width - x.shape[-1]))
 
 
 class _MaxSim(torch.autograd.Function):
@@ -84,7 +90,7 @@ def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
 
 
 def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor):
-    """(dQ fp32 [B,Lq,128], dD fp32 [C,Ld,128]) for upstream dLoss/dscores [B, C]."""
+    """(dQ fp32 [B,Lq,width], dD fp32 [C,Ld,width]) for upstream dLoss/dscores [B, C]."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C, Ld, _ = dc.shape
@@ -147,7 +153,7 @@ def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, 
     (late_interaction_losses.py:235-240, :381-386)."""
     query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
-    return _MaxSimPairs.apply(query_embeddings, doc_embeddings, pairs)
+    return _MaxSimPairs.apply(_widen(query_embeddings), _widen(doc_embeddings), pairs)
 
 
 def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
@@ -169,7 +175,7 @@ def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torc
     """Differentiable fused MaxSim: fp32 [B, C] (late_interaction_losses.py:297-298 without the 4-D tensor)."""
     query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
-    return _MaxSim.apply(query_embeddings, doc_embeddings)
+    return _MaxSim.apply(_widen(query_embeddings), _widen(doc_embeddings))
 
 
 class ColbertModule(torch.nn.Module):

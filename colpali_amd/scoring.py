@@ -45,7 +45,7 @@ def _require_gpu(device: Union[str, torch.device]) -> torch.device:
 
 def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: bool = False,
                   out: Optional[torch.Tensor] = None, ref_bf16: Optional[bool] = None) -> torch.Tensor:
-    """Device-level entry: [n_q, Lq, 128] bf16|f16 device tensor x packed corpus -> fp32 [n_q, n] on the device.
+    """Device-level entry: [n_q, Lq, width] device tensor x packed corpus -> fp32 [n_q, n] on the device.
 
     Asynchronous on torch's current stream.  `ref_rounding=True` reproduces the rounding the reference
     applies when torch evaluates processing_utils.py:179 in the embeddings' own 16-bit dtype
@@ -55,13 +55,15 @@ def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: 
         ref_rounding = ref_bf16
     L = _lib.lib()
     if queries.dim() != 3 or not queries.is_contiguous():
-        raise ValueError("queries must be a contiguous [n_q, Lq, 128] tensor")
+        raise ValueError("queries must be a contiguous [n_q, Lq, width] tensor")
     if queries.dtype != corpus.blob.dtype:   # torch.einsum raises on mixed dtypes too
         raise RuntimeError(f"expected queries and passages of one dtype, got {queries.dtype} and {corpus.blob.dtype}")
     dt = _lib.dtype_code(queries.dtype)
     if queries.device != corpus.device:
         raise ValueError("queries and corpus live on different devices")
     n_q, Lq, dim = queries.shape
+    if dim != corpus.blob.shape[1]:
+        raise RuntimeError(f"queries have embedding width {dim}, the corpus {corpus.blob.shape[1]}")
     n = len(corpus)
     if out is None:
         out = torch.empty((n_q, n), dtype=torch.float32, device=queries.device)

@@ -19,7 +19,7 @@
  *   - matrices are row-major and contiguous, embeddings are 16-byte aligned.
  *
  * Data layout ("packed corpus")
- *   D        bf16|f16 [total_rows, dim]  every document's patch embeddings, back to back
+ *   D        bf16|f16|f32 [total_rows, dim]  every document's patch embeddings, back to back
  *   d_off    int32 [n_d + 1]         document c owns rows d_off[c] .. d_off[c+1]-1
  *   d_clamp0 uint8 [n_d] or NULL     1 = the reference would have zero-padded this
  *                                    document inside its passage block, so a
@@ -27,7 +27,7 @@
  *                                    every per-token max
  *                                    (colpali_engine/utils/processing_utils.py:175-178,
  *                                     pad_sequence(..., padding_value=0))
- *   Q        bf16|f16 [n_q, Lq, dim]     queries (same dtype as D), zero rows = padding (they add 0)
+ *   Q        bf16|f16|f32 [n_q, Lq, dim]     queries (same dtype as D), zero rows = padding (they add 0)
  */
 #ifndef COLPALI_AMD_MAXSIM_H
 #define COLPALI_AMD_MAXSIM_H
@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 2
+#define MSIM_ABI_VERSION 3
 
 /* error codes */
 #define MSIM_OK 0
@@ -47,9 +47,13 @@ extern "C" {
 #define MSIM_EUNSUPPORTED (-2) /* shape/dtype outside what the gfx950 kernels implement */
 #define MSIM_ELAUNCH (-3)      /* HIP reported an error at launch/configuration time */
 
-/* embedding element types (`dtype` argument): 16-bit, fed to the MFMA as is, fp32 accumulate */
+/* embedding element types (`dtype` argument), fed to the MFMA as is, fp32 accumulate.
+ * bf16 / f16 with dim == 128 and Lq <= 128 take the tuned kernels; every other combination (fp32 embeddings,
+ * other widths such as ColQwen3's 320, longer queries) takes the generic kernels, which need
+ * dim * sizeof(element) to be a multiple of 32 bytes (pad the width with zero columns) and <= 4096 bytes. */
 #define MSIM_DTYPE_BF16 0
 #define MSIM_DTYPE_F16 1
+#define MSIM_DTYPE_F32 2
 
 /* flags for msim_fwd */
 #define MSIM_FLAG_REF_ROUNDING 0x1u /* reproduce the rounding the reference applies when torch computes the
@@ -74,7 +78,7 @@ size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim);
  *       torch.einsum("bnd,csd->bcns", q, d) -> amax(dim=3) -> sum(dim=2)
  * without materialising the [b, c, n, s] similarity tensor.
  *
- * scores is fp32 [n_q, ld_scores] (ld_scores >= n_d).  dim must be 128, Lq <= 128.
+ * scores is fp32 [n_q, ld_scores] (ld_scores >= n_d).
  */
 int msim_fwd(int dtype, const void *Q, int n_q, int Lq,
                   const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
@@ -90,7 +94,7 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq,
  *   colpali_engine/loss/late_interaction_losses.py:298 -> :91 (scores_raw.amax(dim=dim_max)),
  * and the forward of the paired contractions "bnd,bsd->bns" / "bnd,blsd->blns" (:235-238, :381-384).
  * pairs: int32 [n_pairs, 2] = (query index, document index).
- * out_scores: fp32 [n_pairs] or NULL; out_argmax: int32 [n_pairs, Lq] or NULL.  Lq <= 128.
+ * out_scores: fp32 [n_pairs] or NULL; out_argmax: int32 [n_pairs, Lq] or NULL.
  */
 int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq,
                       const void *D, const int32_t *d_off, const uint8_t *d_clamp0,

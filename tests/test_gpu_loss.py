@@ -171,8 +171,10 @@ def test_fp32_embeddings_under_autocast_follow_the_reference_autocast_semantics(
     rel = 2.0**-7 if lowp == torch.bfloat16 else 2.0**-10
     assert torch.all((q.grad.cpu() - want_dq.float()).abs() <= want_dq.float().abs() * rel + 1e-5)
     assert torch.all((d.grad.cpu() - want_dd.float()).abs() <= want_dd.float().abs() * rel + 1e-5)
-    with pytest.raises(NotImplementedError, match="autocast"):
-        amd.ColbertPairwiseCELoss()(Q.cuda(), D.cuda())          # fp32 without autocast: no silent conversion
+    # fp32 without autocast: computed in fp32 (exact-fp32 MFMA), like the reference does -- no silent down-conversion
+    loss32 = amd.ColbertPairwiseCELoss(normalize_scores=False)(Q.cuda(), D.cuda())
+    want32, _, _ = lo.loss_and_grads("pairwise", Q, D, normalize_scores=False)
+    assert loss32.dtype == torch.float32 and abs(float(loss32) - float(want32)) <= 1e-5 * abs(float(want32)) + 1e-6
 
 
 def test_float16_loss_and_grads(amd):
@@ -188,3 +190,84 @@ def test_float16_loss_and_grads(amd):
     loss.backward()
     assert torch.all((q.grad.float().cpu() - want_dq.float()).abs() <= want_dq.float().abs() * 2.0**-9 + 2e-5)
     assert torch.all((d.grad.float().cpu() - want_dd.float()).abs() <= want_dd.float().abs() * 2.0**-9 + 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp32 embeddings (a model trained / evaluated in fp32, no autocast): generic kernels, exact-fp32 MFMA.
+# Here the golden vectors are the live reference's own fp32 outputs (loss, dQ, dD from its autograd), so the
+# comparison is reference-vs-HIP directly, not through the oracle.
+
+@pytest.mark.parametrize("cls", ["ColbertPairwiseCELoss", "ColbertLoss"])
+@pytest.mark.parametrize("offset", [0, 6])
+def test_fp32_loss_and_grads_against_reference_goldens(amd, cls, offset):
+    z = load_golden("loss_small.npz")
+    Q, D = torch.from_numpy(z["Q"]), torch.from_numpy(z["D"])
+    q_real = (Q.abs().sum(-1, keepdim=True) > 0)
+    d_real = (D.abs().sum(-1, keepdim=True) > 0)
+    for vname, kw in VARIANTS.items():
+        key = f"{cls}_{vname}_off{offset}"
+        if key + "_loss" not in z.files:
+            continue
+        q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+        loss = getattr(amd, cls)(**kw)(q, d, offset=offset)
+        assert loss.dtype == torch.float32 and loss.dim() == 0
+        want = float(z[key + "_loss"])
+        assert abs(float(loss.detach()) - want) <= 1e-5 * abs(want) + 1e-6, key
+        loss.backward()
+        for got, name, mask in ((q.grad, "dQ", q_real), (d.grad, "dD", d_real)):
+            w = torch.from_numpy(z[f"{key}_{name}"])
+            assert got.dtype == torch.float32 and got.shape == w.shape
+            bad = ((got.cpu() - w).abs() > 1e-4 * w.abs() + 1e-6) & mask.expand_as(w)
+            assert int(bad.sum()) == 0, (key, name)
+
+
+@pytest.mark.parametrize("cls", ["ColbertNegativeCELoss", "ColbertPairwiseNegativeCELoss"])
+def test_fp32_explicit_negatives_against_reference_goldens(amd, cls):
+    z = load_golden("loss_negatives.npz")
+    Q, D, N = (torch.from_numpy(z[k]) for k in ("Q", "D", "N"))
+    q_real = (Q.abs().sum(-1, keepdim=True) > 0)
+    n_real = (N.abs().sum(-1, keepdim=True) > 0)
+    variants = {"default": dict(), "nonorm_w0": dict(normalize_scores=False, in_batch_term_weight=0.0),
+                "T1_w03": dict(temperature=1.0, in_batch_term_weight=0.3)}
+    for offset in (0, 6):
+        for vname, kw in variants.items():
+            key = f"{cls}_{vname}_off{offset}"
+            q, d, n = (t.cuda().requires_grad_(True) for t in (Q, D, N))
+            loss = getattr(amd, cls)(**kw)(q, d, n, offset=offset)
+            want = float(z[key + "_loss"])
+            assert abs(float(loss.detach()) - want) <= 1e-5 * abs(want) + 1e-6, key
+            loss.backward()
+            for got, name, mask in ((q.grad, "dQ", q_real), (n.grad, "dN", n_real)):
+                w = torch.from_numpy(z[f"{key}_{name}"])
+                bad = ((got.cpu() - w).abs() > 1e-4 * w.abs() + 1e-6) & mask.expand_as(w)
+                assert int(bad.sum()) == 0, (key, name)
+
+
+def test_width_320_bf16_loss_and_grads(amd):
+    # ColQwen3 geometry (dim=320): generic forward, generic pair-list backward
+    g = torch.Generator().manual_seed(29)
+    B, C, Lq, Ld = 6, 18, 40, 90
+    Q = torch.nn.functional.normalize(torch.randn(B, Lq, 320, generator=g), dim=-1).to(torch.bfloat16)
+    D = torch.nn.functional.normalize(torch.randn(C, Ld, 320, generator=g), dim=-1).to(torch.bfloat16)
+    want_loss, want_dq, want_dd = lo.loss_and_grads("pairwise", Q.float(), D.float(), offset=6, normalize_scores=False)
+    q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+    loss = amd.ColbertPairwiseCELoss(normalize_scores=False)(q, d, offset=6)
+    assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6
+    loss.backward()
+    assert q.grad.shape == q.shape and d.grad.shape == d.shape
+    assert grads_close(q.grad, want_dq) and grads_close(d.grad, want_dd)
+
+
+def test_generic_pairs_argmax_matches_oracle_routing_fp32(amd):
+    from oracle import maxsim_oracle as mo
+
+    g = torch.Generator().manual_seed(5)
+    Q = torch.nn.functional.normalize(torch.randn(5, 40, 64, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(7, 100, 64, generator=g), dim=-1)
+    pairs = torch.tensor([[0, 0], [0, 6], [1, 3], [4, 2], [4, 3], [4, 6]], dtype=torch.int32)
+    offs = (torch.arange(8, dtype=torch.int32) * 100)
+    s, am = amd.loss.maxsim_pairs(Q.cuda(), D.cuda(), offs.cuda(), pairs.cuda())
+    ws, wam = mo.maxsim_argmax_f32(Q.numpy(), D.numpy().reshape(-1, 64), offs.numpy(), None)
+    for k, (b, c) in enumerate(pairs.tolist()):
+        assert abs(float(s[k]) - ws[b, c]) < 1e-5 * max(1.0, abs(ws[b, c]))
+        np.testing.assert_array_equal(am[k].cpu().numpy(), wam[b, c])

@@ -163,7 +163,7 @@ def test_mixed_dtypes_are_an_error_like_in_the_reference(amd):
     with pytest.raises(RuntimeError, match="one dtype"):
         amd.score_multi_vector(q, p, device="cuda:0")
     with pytest.raises(NotImplementedError, match="dtype"):
-        amd.score_multi_vector([torch.zeros(4, 128)], [torch.zeros(4, 128)], device="cuda:0")
+        amd.score_multi_vector([torch.zeros(4, 128, dtype=torch.float64)], [torch.zeros(4, 128, dtype=torch.float64)], device="cuda:0")
 
 
 def test_empty_inputs_raise_before_any_device_work(amd):
@@ -186,4 +186,93 @@ def test_transpose_detecting_asymmetric_inputs(amd):
     q, d = q.to(torch.bfloat16), d.to(torch.bfloat16)
     got = amd.score_multi_vector([q], [d], device="cuda:0").numpy()
     want = (q.float() @ d.float().T).max(dim=1).values.sum().item()
+    assert abs(got[0, 0] - want) <= 1e-5 * max(abs(want), 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Generic kernels (K1g): fp32 embeddings, widths other than 128, queries longer than 128 tokens.
+
+def test_reference_unit_test_shape_fp32_dim32_list_and_tensor(amd):
+    """Mirror of the reference's tests/utils/test_processing_utils.py:15-35 (fp32, dim=32, list vs padded tensor),
+    on the golden inputs whose outputs were produced by the live reference."""
+    z = load_golden("score_fp32_d32.npz")
+    q, p = torch.from_numpy(z["q"]), torch.from_numpy(z["p"])
+    qs = list(torch.split(q, z["q_lens"].tolist()))
+    ps = list(torch.split(p, z["p_lens"].tolist()))
+    from_list = amd.score_multi_vector(qs, ps, device="cuda:0")
+    assert from_list.shape == (len(qs), len(ps)) and from_list.dtype == torch.float32 and from_list.device.type == "cpu"
+    qs_padded = torch.nn.utils.rnn.pad_sequence(qs, batch_first=True)
+    ps_padded = torch.nn.utils.rnn.pad_sequence(ps, batch_first=True)
+    from_tensor = amd.score_multi_vector(qs_padded, ps_padded, device="cuda:0")
+    assert from_tensor.shape == (len(qs), len(ps))
+    assert torch.allclose(from_list, from_tensor), "Scores from list and tensor inputs should match"
+    assert close(from_list.numpy(), z["scores_list"]) and close(from_tensor.numpy(), z["scores_tensor"])
+
+
+def _random_generic(seed, n_q, lq_max, n_d, ld_max, dim, dtype):
+    g = torch.Generator().manual_seed(seed)
+    def unit(n):
+        return torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=-1).to(dtype)
+    q_lens = torch.randint(1, lq_max + 1, (n_q,), generator=g).tolist()
+    q_lens[0] = lq_max
+    d_lens = torch.randint(1, ld_max + 1, (n_d,), generator=g).tolist()
+    return [unit(n) for n in q_lens], [unit(n) for n in d_lens]
+
+
+@pytest.mark.parametrize("dtype,dim,n_q,lq_max,n_d,ld_max,bs", [
+    (torch.float32, 128, 3, 32, 200, 300, 128),    # fp32 embeddings of the usual width, T=4 whole queries
+    (torch.float32, 128, 9, 100, 60, 130, 16),     # four token tiles per query
+    (torch.float32, 128, 2, 200, 40, 90, 128),     # seven token tiles: sub-passes with same-thread accumulation
+    (torch.float32, 32, 5, 7, 64, 20, 128),        # the reference unit test's width
+    (torch.float32, 320, 4, 40, 50, 100, 128),     # ColQwen3 width in fp32 (1280-byte rows: T=2)
+    (torch.float32, 1024, 2, 33, 10, 70, 128),     # 4 KiB rows: T=1
+    (torch.bfloat16, 320, 6, 32, 150, 400, 128),   # ColQwen3 (colqwen3 dim=320)
+    (torch.bfloat16, 320, 40, 32, 100, 300, 7),
+    (torch.bfloat16, 128, 3, 150, 80, 200, 128),   # dim 128 but queries longer than the tuned kernels hold
+    (torch.bfloat16, 100, 4, 20, 70, 90, 128),     # width padded 100 -> 112 with zero columns
+    (torch.bfloat16, 64, 17, 32, 90, 260, 5),
+    (torch.float16, 64, 5, 32, 90, 260, 128),
+    (torch.float16, 512, 3, 64, 30, 100, 128),
+])
+def test_generic_kernels_against_oracle(amd, dtype, dim, n_q, lq_max, n_d, ld_max, bs):
+    qs, ps = _random_generic(dim * 3 + n_q, n_q, lq_max, n_d, ld_max, dim, dtype)
+    got = amd.score_multi_vector(qs, ps, batch_size=bs, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, bs))
+
+
+def test_generic_many_documents_and_literal_rounding(amd):
+    # more documents than resident waves; REF rounding mode on the generic bf16 path equals the literal oracle tier
+    qs, ps = _random_generic(3, 3, 32, 5000, 40, 320, torch.bfloat16)
+    got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, 128))
+    dev = torch.device("cuda:0")
+    lit = amd.maxsim_scores(amd.pack_queries(qs, dev), amd.pack_passages(ps[:300], dev), ref_rounding=True).cpu().numpy()
+    want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps[:300]], mode="bf16ref")
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-3))) - 7)
+    assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
+
+
+def test_generic_and_tuned_kernels_agree_bitwise(amd):
+    # same 32x32x16 MFMA chain in the same k order, same reduction tree: a 128-wide bf16 query scored by the tuned
+    # kernels (Lq <= 128) and, zero-padded to 160 tokens, by the generic kernel must give identical fp32 values
+    qs, ps = _random_case(21, 3, 32, 200, 500)
+    dev = torch.device("cuda:0")
+    corpus = amd.pack_passages(ps, dev)
+    tuned = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()
+    long_q = [torch.cat([q, q.new_zeros(160 - q.shape[0], 128)]) for q in qs]
+    generic = amd.maxsim_scores(amd.pack_queries(long_q, dev), corpus).cpu()
+    assert torch.equal(tuned, generic)
+
+
+def test_transpose_detecting_asymmetric_inputs_fp32(amd):
+    q = torch.zeros(32, 48)
+    d = torch.zeros(70, 48)
+    for i in range(32):
+        q[i, (3 * i) % 48] = 1.0 + i / 64
+        q[i, (5 * i + 1) % 48] = -0.5
+    for j in range(70):
+        d[j, (7 * j) % 48] = 0.25 + j / 128
+        d[j, (3 * j + 2) % 48] += 1.0
+    got = amd.score_multi_vector([q], [d], device="cuda:0").numpy()
+    want = (q.double() @ d.double().T).max(dim=1).values.sum().item()
     assert abs(got[0, 0] - want) <= 1e-5 * max(abs(want), 1)

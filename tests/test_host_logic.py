@@ -37,8 +37,10 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
 
 def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     L = colpali_amd._lib.lib()
-    # dim != 128 -> MSIM_EUNSUPPORTED before any device work
-    rc = L.msim_fwd(0, 16, 1, 32, 16, 16, None, 1, 64, 16, 1, 0, None, None)
+    # a row that is not a multiple of 32 bytes, or above 4 KiB -> MSIM_EUNSUPPORTED before any device work
+    rc = L.msim_fwd(0, 16, 1, 32, 16, 16, None, 1, 100, 16, 1, 0, None, None)
+    assert rc == -2 and b"dim" in L.msim_last_error()
+    rc = L.msim_fwd(2, 16, 1, 32, 16, 16, None, 1, 2048, 16, 1, 0, None, None)
     assert rc == -2 and b"dim" in L.msim_last_error()
     rc = L.msim_fwd(0, None, 1, 32, 16, 16, None, 1, 128, 16, 1, 0, None, None)
     assert rc == -1
@@ -86,11 +88,26 @@ def test_pack_queries_pads_with_zero_rows():
     assert q.shape == (2, 7, 128) and torch.count_nonzero(q[0, 3:]) == 0
 
 
-def test_dtype_and_dim_are_errors_not_silent_conversions():
+def test_unsupported_dtype_and_width_are_errors_not_silent_conversions():
     with pytest.raises(NotImplementedError, match="dtype"):
-        C.pack_queries([torch.randn(3, 128)], torch.device("cpu"))
-    with pytest.raises(NotImplementedError, match="dim"):
-        C.pack_passages([bf(3, dim=64)], torch.device("cpu"))
+        C.pack_queries([torch.randn(3, 128, dtype=torch.float64)], torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="4 KiB"):
+        C.pack_passages([torch.randn(3, 1100)], torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="one embedding width"):
+        C.pack_passages([bf(3, dim=64), bf(3, dim=128)], torch.device("cpu"))
+
+
+def test_generic_widths_are_zero_padded_to_32_byte_rows():
+    # fp32 keeps its dtype (reference tests use fp32, dim=32: tests/utils/test_processing_utils.py:8);
+    # widths that are not a multiple of 32 bytes get zero columns, which change no dot product
+    q = C.pack_queries([torch.randn(3, 32), torch.randn(5, 32)], torch.device("cpu"))
+    assert q.dtype == torch.float32 and q.shape == (2, 5, 32)
+    pc = C.pack_passages([bf(4, dim=100, seed=1), bf(6, dim=100, seed=2)], torch.device("cpu"))
+    assert pc.blob.shape == (10, 112) and torch.count_nonzero(pc.blob[:, 100:]) == 0
+    assert torch.equal(pc.blob[:4, :100], bf(4, dim=100, seed=1))
+    assert colpali_amd._lib.kernel_width(128, torch.bfloat16) == 128
+    assert colpali_amd._lib.kernel_width(320, torch.bfloat16) == 320
+    assert colpali_amd._lib.kernel_width(30, torch.float32) == 32
 
 
 def test_empty_inputs_and_cpu_device_errors_mirror_or_fail_loudly():
