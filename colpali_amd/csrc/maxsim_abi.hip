@@ -15,6 +15,7 @@
 #include "maxsim_batch.hip"
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
+#include "maxsim_smooth.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -351,6 +352,90 @@ void generic_pairs_bwd(const char *Q, const char *D, const int32_t *d_off, int m
                            pairs, order_by_doc, g, argmax, dD, a, dim);
 }
 
+// ---------------------------------------------------------------- smooth-max (tau * logsumexp) kernels
+int check_smooth(const void *Q, const void *D, const int32_t *d_off, int dtype, int dim, int Lq, float tau) {
+    if (!Q || !D || !d_off) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16 && dtype != MSIM_DTYPE_F32)
+        return fail(MSIM_EUNSUPPORTED, "dtype code %d", dtype);
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15)
+        return fail(MSIM_EINVAL, "Q and D must be 16-byte aligned");
+    if (!(tau > 0.0f)) return fail(MSIM_EINVAL, "tau must be positive");
+    if (dim <= 0 || Lq <= 0) return fail(MSIM_EINVAL, "bad size (dim=%d Lq=%d)", dim, Lq);
+    const long long row_bytes = (long long)dim * elem_bytes(dtype);
+    if (row_bytes % 32 != 0)
+        return fail(MSIM_EUNSUPPORTED, "dim=%d: an embedding row must be a multiple of 32 bytes (pad the width with zero columns)", dim);
+    if (row_bytes > msim::kGenericMaxRowBytes)
+        return fail(MSIM_EUNSUPPORTED, "dim=%d: embedding rows above %d bytes are not supported", dim, msim::kGenericMaxRowBytes);
+    return MSIM_OK;
+}
+
+template <int DT, int T>
+int launch_smooth(const GenericCall &c, float tau) {
+    auto kern = msim::maxsim_smooth_kernel<DT, T>;
+    const int lds = T * msim::kTokTile * (c.row_bytes + 16);
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, 160 * 1024, configured)) return rc;
+    msim::SmoothArgs a;
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.row_bytes = c.row_bytes;
+    a.tau = tau;
+    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    const int groups = tpq <= T ? (c.n_q + (T / tpq) - 1) / (T / tpq) : c.n_q;
+    if (groups > 65535) return fail(MSIM_EUNSUPPORTED, "too many query groups (%d) for one launch", groups);
+    const int wg_needed = (c.n_d + msim::kGenericWaves - 1) / msim::kGenericWaves;
+    int per_cu = c.di->lds_per_cu / lds;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int wg_cap = c.di->cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap, groups), dim3(msim::kGenericWaves * 64), lds, c.st,
+                       c.Q, c.D, c.d_off, c.scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_kernel<%d,%d> launch: %s", DT, T, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <int DT>
+int smooth_dispatch(const GenericCall &c, float tau) {
+    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    const long long tiles = (long long)c.n_q * tpq;
+    const int tile_lds = msim::kTokTile * (c.row_bytes + 16);
+    int T = 2;                                   // (max, sum) state per tile on top of the accumulators: two tiles per wave
+    while (T > 1 && (T * tile_lds > 80 * 1024 || T / 2 >= tiles)) T >>= 1;
+    return T == 2 ? launch_smooth<DT, 2>(c, tau) : launch_smooth<DT, 1>(c, tau);
+}
+
+template <int DT>
+int smooth_pairs(const char *Q, const char *D, const int32_t *d_off, const int32_t *pairs, float *out_scores, float *out_lse,
+                 const msim::PairsArgs &a, int row_bytes, float tau, const DeviceInfo &di, hipStream_t st) {
+    const int wg_needed = (a.n_pairs + 3) / 4;
+    const int wg_cap = di.cus * 8;
+    hipLaunchKernelGGL(msim::maxsim_smooth_pairs_kernel<DT>, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), 0, st, Q, D,
+                       d_off, pairs, out_scores, out_lse, a, row_bytes, tau);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_pairs_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <int DT>
+int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
+               const int32_t *order_by_doc, const float *g, const float *lse, float *dQ, float *dD,
+               const msim::SmoothBwdArgs &a, hipStream_t st) {
+    const int tpq = (a.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    const int cb = (a.dim + 31) / 32;
+    if (a.n_q > 0)
+        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true>), dim3(a.n_q, tpq, cb), dim3(256), 0, st, Q, D, d_off, pairs,
+                           order_by_doc, g, lse, dQ, a);
+    const int slabs = (max_doc_rows + 31) / 32;
+    if (a.n_d > 0 && slabs > 0)
+        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false>), dim3(a.n_d, slabs, cb), dim3(256), 0, st, Q, D, d_off, pairs,
+                           order_by_doc, g, lse, dD, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_bwd_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -461,6 +546,73 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, con
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_bwd launch: %s", hipGetErrorString(e));
     return MSIM_OK;
+}
+
+// ---------------------------------------------------------------- smooth-max entry points
+int msim_smooth_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim, float tau,
+                    float *scores, int64_t ld_scores, void *stream) {
+    if (n_q < 0 || n_d < 0) return fail(MSIM_EINVAL, "negative size (n_q=%d n_d=%d)", n_q, n_d);
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!scores) return fail(MSIM_EINVAL, "null pointer argument");
+    if (int rc = check_smooth(Q, D, d_off, dtype, dim, Lq, tau)) return rc;
+    if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
+    GenericCall c;
+    if (int rc = device_info(&c.di)) return rc;
+    c.Q = static_cast<const char *>(Q);
+    c.D = static_cast<const char *>(D);
+    c.d_off = d_off;
+    c.clamp0 = nullptr;
+    c.scores = scores;
+    c.ld = ld_scores;
+    c.n_q = n_q;
+    c.Lq = Lq;
+    c.n_d = n_d;
+    c.row_bytes = dim * elem_bytes(dtype);
+    c.flags = 0;
+    c.st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MSIM_DTYPE_F32: return smooth_dispatch<msim::kDtypeF32>(c, tau);
+        case MSIM_DTYPE_F16: return smooth_dispatch<msim::kDtypeF16>(c, tau);
+        default: return smooth_dispatch<msim::kDtypeBf16>(c, tau);
+    }
+}
+
+int msim_smooth_pairs(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
+                      const int32_t *pairs, int n_pairs, float tau, float *out_scores, float *out_lse, void *stream) {
+    if (n_q < 0 || n_d < 0 || n_pairs < 0) return fail(MSIM_EINVAL, "negative size");
+    if (n_pairs == 0) return MSIM_OK;
+    if (!pairs) return fail(MSIM_EINVAL, "null pointer argument");
+    if (int rc = check_smooth(Q, D, d_off, dtype, dim, Lq, tau)) return rc;
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
+    const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
+    const int rb = dim * elem_bytes(dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MSIM_DTYPE_F32: return smooth_pairs<msim::kDtypeF32>(qc, dc, d_off, pairs, out_scores, out_lse, a, rb, tau, *di, st);
+        case MSIM_DTYPE_F16: return smooth_pairs<msim::kDtypeF16>(qc, dc, d_off, pairs, out_scores, out_lse, a, rb, tau, *di, st);
+        default: return smooth_pairs<msim::kDtypeBf16>(qc, dc, d_off, pairs, out_scores, out_lse, a, rb, tau, *di, st);
+    }
+}
+
+int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
+                          int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g, const float *lse,
+                          int n_pairs, float tau, float *dQ, float *dD, void *stream) {
+    if (n_q < 0 || n_d < 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
+    if (!dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
+    if (n_pairs > 0 && (!pairs || !order_by_doc || !g || !lse)) return fail(MSIM_EINVAL, "null pair-list argument");
+    if (int rc = check_smooth(Q, D, d_off, dtype, dim, Lq, tau)) return rc;
+    if ((max_doc_rows + 31) / 32 > 65535) return fail(MSIM_EUNSUPPORTED, "max_doc_rows=%d too large", max_doc_rows);
+    if ((Lq + 31) / 32 > 65535) return fail(MSIM_EUNSUPPORTED, "Lq=%d too large", Lq);
+    msim::SmoothBwdArgs a{n_q, Lq, n_d, n_pairs, dim * elem_bytes(dtype), dim, tau};
+    const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MSIM_DTYPE_F32: return smooth_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
+        case MSIM_DTYPE_F16: return smooth_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
+        default: return smooth_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
+    }
 }
 
 // ---------------------------------------------------------------- top-k selection

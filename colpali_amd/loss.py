@@ -156,6 +156,116 @@ def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, 
     return _MaxSimPairs.apply(_widen(query_embeddings), _widen(doc_embeddings), pairs)
 
 
+def smooth_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pairs: torch.Tensor, tau: float,
+                 want_scores: bool = True, want_lse: bool = True):
+    """Smooth-max score (+ per-token logsumexp of sim / tau) for an int32 [n_pairs, 2] list of (query, doc) pairs."""
+    L = _lib.lib()
+    B, Lq, dim = qc.shape
+    C = offsets.numel() - 1
+    n_pairs = pairs.shape[0]
+    dev = qc.device
+    scores = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if want_scores else None
+    lse = torch.empty((n_pairs, Lq), dtype=torch.float32, device=dev) if want_lse else None
+    with torch.cuda.device(dev):
+        rc = L.msim_smooth_pairs(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim,
+                                 _lib.ptr(pairs), n_pairs, tau, _lib.ptr(scores), _lib.ptr(lse), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_smooth_pairs")
+    return scores, lse
+
+
+def _smooth_backward(qc, dc, offsets, pairs, gp, tau):
+    """(dQ, dD) fp32 for the listed pairs (sorted by query) with upstream gradients gp."""
+    L = _lib.lib()
+    B, Lq, dim = qc.shape
+    C, Ld, _ = dc.shape
+    dev = qc.device
+    dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
+    dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
+    n_pairs = pairs.shape[0]
+    if n_pairs == 0:
+        return dq.zero_(), dd.zero_()
+    order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
+    _, lse = smooth_pairs(qc, dc, offsets, pairs, tau, want_scores=False)
+    with torch.cuda.device(dev):
+        rc = L.msim_smooth_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
+                                     _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(lse), n_pairs, tau,
+                                     _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_smooth_pairs_bwd")
+    return dq, dd
+
+
+class _MaxSimSmooth(torch.autograd.Function):
+    """scores[b, c] = sum_n tau * logsumexp_s(<Q[b,n], D[c,s]> / tau)  (late_interaction_losses.py:40-44, :88-90)."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor, tau: float) -> torch.Tensor:
+        L = _lib.lib()
+        qc, dc = q.contiguous(), d.contiguous()
+        corpus = _dense_corpus(dc)
+        B, Lq, dim = qc.shape
+        C = dc.shape[0]
+        scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)
+        with torch.cuda.device(qc.device):
+            rc = L.msim_smooth_fwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(corpus.offsets), C, dim,
+                                   tau, _lib.ptr(scores), max(C, 1), _lib.current_stream_handle(qc.device))
+        _lib.check(rc, "msim_smooth_fwd")
+        ctx.save_for_backward(qc, dc, corpus.offsets)
+        ctx.tau = tau
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores: torch.Tensor):
+        qc, dc, offsets = ctx.saved_tensors
+        g = grad_scores.to(torch.float32)
+        pairs64 = torch.nonzero(g)                      # row-major = sorted by query, then doc (one host sync)
+        gp = g[pairs64[:, 0], pairs64[:, 1]].contiguous()
+        dq, dd = _smooth_backward(qc, dc, offsets, pairs64.to(torch.int32).contiguous(), gp, ctx.tau)
+        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
+
+
+class _MaxSimPairsSmooth(torch.autograd.Function):
+    """Smooth-max score of an explicit pair list sorted by query index."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor, pairs: torch.Tensor, tau: float) -> torch.Tensor:
+        qc, dc = q.contiguous(), d.contiguous()
+        corpus = _dense_corpus(dc)
+        scores, _ = smooth_pairs(qc, dc, corpus.offsets, pairs, tau, want_lse=False)
+        ctx.save_for_backward(qc, dc, corpus.offsets, pairs)
+        ctx.tau = tau
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores: torch.Tensor):
+        qc, dc, offsets, pairs = ctx.saved_tensors
+        dq, dd = _smooth_backward(qc, dc, offsets, pairs, grad_scores.to(torch.float32).contiguous(), ctx.tau)
+        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None, None)
+
+
+def _widen32(x: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the width to a multiple of 32 bytes (what the smooth-max kernels stream; differentiable)."""
+    per = 32 // x.element_size()
+    width = (x.shape[-1] + per - 1) // per * per
+    return x if width == x.shape[-1] else F.pad(x, (0, width - x.shape[-1]))
+
+
+def maxsim_smooth(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, tau: float) -> torch.Tensor:
+    """Differentiable fused smooth-max late interaction: fp32 [B, C]."""
+    query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
+    _check_embeddings(query_embeddings, doc_embeddings)
+    return _MaxSimSmooth.apply(_widen32(query_embeddings), _widen32(doc_embeddings), float(tau))
+
+
+def maxsim_smooth_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, pairs: torch.Tensor,
+                         tau: float) -> torch.Tensor:
+    """Differentiable smooth-max score of listed (query, doc) pairs: fp32 [n_pairs]; `pairs` int32 [n,2] sorted by query."""
+    query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
+    _check_embeddings(query_embeddings, doc_embeddings)
+    return _MaxSimPairsSmooth.apply(_widen32(query_embeddings), _widen32(doc_embeddings), pairs, float(tau))
+
+
 def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
     """Under torch.autocast the reference's einsum (late_interaction_losses.py:297) is an autocast-to-lower-precision
     op: fp32 embeddings are cast to the autocast dtype before the contraction (models emit fp32 there because
@@ -218,10 +328,11 @@ class ColbertModule(torch.nn.Module):
 
     # -- shared front end of every in-batch loss: lengths, fused MaxSim, optional normalisation / filtering
     def _inbatch_scores(self, query_embeddings, doc_embeddings, offset):
-        if self.use_smooth_max:
-            raise NotImplementedError("use_smooth_max=True (tau * logsumexp over patches) has no gfx950 kernel yet")
         lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)          # :296 -- first component, not a norm test
-        scores = maxsim(query_embeddings, doc_embeddings)
+        if self.use_smooth_max:                                        # :88-89: tau * logsumexp(raw / tau) instead of amax
+            scores = maxsim_smooth(query_embeddings, doc_embeddings, self.tau)
+        else:
+            scores = maxsim(query_embeddings, doc_embeddings)
         if self.normalize_scores:
             scores = self._apply_normalization(scores, lengths)
         rows, pos_idx = self._get_idx(scores.size(0), offset, scores.device)
@@ -297,18 +408,20 @@ class _ExplicitNegativesMixin:
 
     def _explicit_negative_term(self, query_embeddings, doc_embeddings, neg_doc_embeddings, offset):
         if self.use_smooth_max:
-            raise NotImplementedError("use_smooth_max=True (tau * logsumexp over patches) has no gfx950 kernel yet")
+            paired = lambda q, d, pairs: maxsim_smooth_paired(q, d, pairs, self.tau)   # noqa: E731
+        else:
+            paired = maxsim_paired
         B = query_embeddings.size(0)
         n_neg = neg_doc_embeddings.size(1)
         dev = query_embeddings.device
         lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)
         rows = torch.arange(B, dtype=torch.int32, device=dev)
         pos_pairs = torch.stack([rows, rows + offset], dim=1).contiguous()                 # (b, offset + b)
-        pos_scores = maxsim_paired(query_embeddings, doc_embeddings, pos_pairs)            # "bnd,bsd->bns" -> amax -> sum
+        pos_scores = paired(query_embeddings, doc_embeddings, pos_pairs)                   # "bnd,bsd->bns" -> amax -> sum
         neg_flat = neg_doc_embeddings.reshape(B * n_neg, neg_doc_embeddings.size(2), neg_doc_embeddings.size(3))
         neg_pairs = torch.stack([rows.repeat_interleave(n_neg),
                                  torch.arange(B * n_neg, dtype=torch.int32, device=dev)], dim=1).contiguous()
-        neg_scores = maxsim_paired(query_embeddings, neg_flat, neg_pairs).view(B, n_neg)  # "bnd,blsd->blns" -> amax -> sum
+        neg_scores = paired(query_embeddings, neg_flat, neg_pairs).view(B, n_neg)          # "bnd,blsd->blns" -> amax -> sum
         if self.normalize_scores:
             pos_scores = self._apply_normalization(pos_scores, lengths)
             neg_scores = self._apply_normalization(neg_scores, lengths)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 3
+#define MSIM_ABI_VERSION 4
 
 /* error codes */
 #define MSIM_OK 0
@@ -120,6 +120,35 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
                    const int32_t *pairs, const int32_t *order_by_doc,
                    const float *g, const int32_t *argmax, int n_pairs,
                    float *dQ, float *dD, void *stream);
+
+/*
+ * Smooth-max late interaction (training losses constructed with use_smooth_max=True):
+ *     scores[q, c] = sum_{i < Lq} tau * log sum_{j in doc c} exp(<Q[q,i,:], D[j,:]> / tau)
+ * Replaces colpali_engine/loss/late_interaction_losses.py:40-44 (_smooth_max = tau * logsumexp(scores / tau)) applied
+ * through :88-90 (_aggregate) to the einsum of :153 / :297 / :444, again without the [b, c, n, s] tensor.  Every row of a
+ * document takes part (physical zero padding rows contribute exp(0), as in the reference); there is no d_clamp0 here
+ * because score_multi_vector has no smooth-max mode.  dim * sizeof(element) must be a multiple of 32 bytes, <= 4096.
+ *
+ * msim_smooth_pairs: the same for an explicit pair list; out_lse [n_pairs, Lq] receives the natural-log
+ *     lse[p, i] = log sum_j exp(<Q[q_p,i], D[j]> / tau)     (what the backward needs; either output may be NULL).
+ * msim_smooth_pairs_bwd: autograd of the expression for the listed pairs with upstream gradient g[p]:
+ *     w[p,i,j] = exp(<Q[q_p,i], D[j]> / tau - lse[p,i])     (softmax over the document's rows)
+ *     dQ[q, i, :]       = sum_{p: q_p = q} g[p] * sum_j w[p,i,j] * D[d_off[c_p] + j, :]
+ *     dD[d_off[c]+j, :] = sum_{p: c_p = c} g[p] * sum_i w[p,i,j] * Q[q_p, i, :]
+ * Same conventions as msim_pairs_bwd (pairs sorted by query, order_by_doc, full overwrite, deterministic, no atomics).
+ */
+int msim_smooth_fwd(int dtype, const void *Q, int n_q, int Lq,
+                    const void *D, const int32_t *d_off, int n_d, int dim, float tau,
+                    float *scores, int64_t ld_scores, void *stream);
+int msim_smooth_pairs(int dtype, const void *Q, int n_q, int Lq,
+                      const void *D, const int32_t *d_off, int n_d, int dim,
+                      const int32_t *pairs, int n_pairs, float tau,
+                      float *out_scores, float *out_lse, void *stream);
+int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
+                          const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
+                          const int32_t *pairs, const int32_t *order_by_doc,
+                          const float *g, const float *lse, int n_pairs, float tau,
+                          float *dQ, float *dD, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

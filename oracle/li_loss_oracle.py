@@ -16,10 +16,18 @@ import torch
 import torch.nn.functional as F  # noqa: N812
 
 
-def _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter_threshold, filter_factor):
+def _aggregate(raw, use_smooth_max, tau, dim_max, dim_sum):
+    """:72-91 -- amax, or the smooth max tau * logsumexp(raw / tau) (:40-44), then the token sum."""
+    if use_smooth_max:
+        return (tau * torch.logsumexp(raw / tau, dim=dim_max)).sum(dim=dim_sum)
+    return raw.amax(dim=dim_max).sum(dim=dim_sum)
+
+
+def _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter_threshold, filter_factor,
+            use_smooth_max=False, tau=0.1):
     lengths = (q[:, :, 0] != 0).sum(dim=1)                                   # :296
     raw = torch.einsum("bnd,csd->bcns", q, d)                                # :297
-    scores = raw.amax(dim=3).sum(dim=2)                                      # :298 -> :91
+    scores = _aggregate(raw, use_smooth_max, tau, 3, 2)                      # :298 -> :88-91
     if normalize_scores:
         scores = scores / lengths.unsqueeze(1)                               # :58
     B = scores.size(0)
@@ -35,11 +43,13 @@ def _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter
 
 def loss_and_grads(kind: str, Q: torch.Tensor, D: torch.Tensor, offset: int = 0, temperature=None,
                    normalize_scores: bool = True, pos_aware_negative_filtering: bool = False,
-                   filter_threshold: float = 0.95, filter_factor: float = 0.5):
+                   filter_threshold: float = 0.95, filter_factor: float = 0.5,
+                   use_smooth_max: bool = False, tau: float = 0.1):
     """kind in {"pairwise", "infonce", "sigmoid"} -> (loss, dQ, dD) as float64 tensors."""
     q = Q.detach().double().requires_grad_(True)
     d = D.detach().double().requires_grad_(True)
-    scores, pos_idx = _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter_threshold, filter_factor)
+    scores, pos_idx = _scores(q, d, offset, normalize_scores, pos_aware_negative_filtering, filter_threshold, filter_factor,
+                              use_smooth_max, tau)
     if kind == "pairwise":
         T = 1.0 if temperature is None else temperature
         pos = scores.diagonal(offset=offset)                                 # :309
@@ -62,7 +72,8 @@ def loss_and_grads(kind: str, Q: torch.Tensor, D: torch.Tensor, offset: int = 0,
 
 
 def negatives_loss_and_grads(kind: str, Q, D, N, offset: int = 0, temperature: float = 0.02,
-                             normalize_scores: bool = True, in_batch_term_weight: float = 0.5):
+                             normalize_scores: bool = True, in_batch_term_weight: float = 0.5,
+                             use_smooth_max: bool = False, tau: float = 0.1):
     """Explicit-negative variants (:215-252 "negative_ce", :361-398 "pairwise_negative_ce").
     N: [B, n_neg, Lneg, dim].  Returns (loss, dQ, dD, dN) in float64."""
     q = Q.detach().double().requires_grad_(True)
@@ -72,14 +83,14 @@ def negatives_loss_and_grads(kind: str, Q, D, N, offset: int = 0, temperature: f
     lengths = (q[:, :, 0] != 0).sum(dim=1)
     pos_raw = torch.einsum("bnd,bsd->bns", q, d[offset : offset + B])          # :235-237 / :381-383
     neg_raw = torch.einsum("bnd,blsd->blns", q, n)                             # :238 / :384
-    pos = pos_raw.amax(dim=2).sum(dim=1)
-    neg = neg_raw.amax(dim=3).sum(dim=2)
+    pos = _aggregate(pos_raw, use_smooth_max, tau, 2, 1)
+    neg = _aggregate(neg_raw, use_smooth_max, tau, 3, 2)
     if normalize_scores:
         pos = pos / lengths
         neg = neg / lengths.unsqueeze(1)
     loss = F.softplus((neg - pos.unsqueeze(1)) / temperature).mean()           # :246 / :392
     if in_batch_term_weight > 0:
-        scores, pos_idx = _scores(q, d, offset, normalize_scores, False, 0.95, 0.5)
+        scores, pos_idx = _scores(q, d, offset, normalize_scores, False, 0.95, 0.5, use_smooth_max, tau)
         if kind == "negative_ce":
             ib = F.cross_entropy(scores / temperature, pos_idx)
         else:

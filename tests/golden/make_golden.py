@@ -184,5 +184,43 @@ def main():
     save("loss_kat.npz", pairwise_zero=z.numpy(), ln2=np.float32(np.log(2.0)))
 
 
+def smooth_golden():
+    """(8) use_smooth_max=True (late_interaction_losses.py:40-44, :88-90): loss + autograd gradients of the reference
+    modules on the loss_small / loss_negatives inputs.  Separate file so the other fixtures stay byte-identical:
+        python tests/golden/make_golden.py smooth"""
+    zs = np.load(os.path.join(HERE, "loss_small.npz"))
+    zn = np.load(os.path.join(HERE, "loss_negatives.npz"))
+    Q, D, N = torch.from_numpy(zs["Q"]), torch.from_numpy(zs["D"]), torch.from_numpy(zn["N"])
+    out = {}
+    variants = {"tau01": dict(use_smooth_max=True), "tau002_nonorm_T1": dict(use_smooth_max=True, tau=0.02, normalize_scores=False,
+                                                                          temperature=1.0)}
+    for cls_name in ("ColbertPairwiseCELoss", "ColbertLoss"):
+        for vname, kw in variants.items():
+            for offset in (0, 6):
+                q = Q.clone().requires_grad_(True); d = D.clone().requires_grad_(True)
+                loss = getattr(L, cls_name)(**kw)(q, d, offset=offset)
+                loss.backward()
+                key = f"{cls_name}_{vname}_off{offset}"
+                out[key + "_loss"] = loss.detach().numpy(); out[key + "_dQ"] = q.grad.numpy()
+                if offset == 6:   # keep the fixture small: document gradients for one offset only
+                    out[key + "_dD"] = d.grad.numpy()
+    for cls_name in ("ColbertNegativeCELoss", "ColbertPairwiseNegativeCELoss"):
+        for vname, kw in {"tau01": dict(use_smooth_max=True), "tau05_T1_w03": dict(use_smooth_max=True, tau=0.5, temperature=1.0,
+                                                                                     in_batch_term_weight=0.3)}.items():
+            for offset in (0, 6):
+                q = Q.clone().requires_grad_(True); d = D.clone().requires_grad_(True); n = N.clone().requires_grad_(True)
+                loss = getattr(L, cls_name)(**kw)(q, d, n, offset=offset)
+                loss.backward()
+                key = f"{cls_name}_{vname}_off{offset}"
+                out[key + "_loss"] = loss.detach().numpy(); out[key + "_dQ"] = q.grad.numpy()
+                if offset == 0:
+                    out[key + "_dN"] = n.grad.numpy()
+    save("loss_smooth.npz", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "smooth":
+        smooth_golden()
+    else:
+        main()
+        smooth_golden()

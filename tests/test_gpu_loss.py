@@ -271,3 +271,90 @@ def test_generic_pairs_argmax_matches_oracle_routing_fp32(amd):
     for k, (b, c) in enumerate(pairs.tolist()):
         assert abs(float(s[k]) - ws[b, c]) < 1e-5 * max(1.0, abs(ws[b, c]))
         np.testing.assert_array_equal(am[k].cpu().numpy(), wam[b, c])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# use_smooth_max=True: tau * logsumexp over document rows (late_interaction_losses.py:40-44, :88-90).
+# fp32 inputs are compared with the live reference's own outputs (tests/golden/loss_smooth.npz); bf16 inputs with the
+# float64 oracle on the same bf16-valued numbers.  Every row takes part here (zero padding rows contribute exp(0)), so
+# there are no ties and no rows to exclude.
+
+SMOOTH = {"tau01": dict(use_smooth_max=True),
+          "tau002_nonorm_T1": dict(use_smooth_max=True, tau=0.02, normalize_scores=False, temperature=1.0)}
+SMOOTH_NEG = {"tau01": dict(use_smooth_max=True),
+              "tau05_T1_w03": dict(use_smooth_max=True, tau=0.5, temperature=1.0, in_batch_term_weight=0.3)}
+
+
+def _close32(got, want, rtol=2e-3, atol=1e-5):
+    want = torch.as_tensor(want)
+    return bool(torch.all((got.float().cpu() - want).abs() <= rtol * want.abs() + atol))
+
+
+@pytest.mark.parametrize("cls", ["ColbertPairwiseCELoss", "ColbertLoss"])
+def test_smooth_max_fp32_against_reference_goldens(amd, cls):
+    z = load_golden("loss_smooth.npz")
+    zs = load_golden("loss_small.npz")
+    Q, D = torch.from_numpy(zs["Q"]), torch.from_numpy(zs["D"])
+    for vname, kw in SMOOTH.items():
+        for offset in (0, 6):
+            key = f"{cls}_{vname}_off{offset}"
+            q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+            loss = getattr(amd, cls)(**kw)(q, d, offset=offset)
+            want = float(z[key + "_loss"])
+            assert loss.dtype == torch.float32 and abs(float(loss.detach()) - want) <= 2e-4 * abs(want) + 1e-6, key
+            loss.backward()
+            assert _close32(q.grad, z[key + "_dQ"]), (key, "dQ")
+            if key + "_dD" in z.files:
+                assert _close32(d.grad, z[key + "_dD"]), (key, "dD")
+
+
+@pytest.mark.parametrize("cls", ["ColbertNegativeCELoss", "ColbertPairwiseNegativeCELoss"])
+def test_smooth_max_explicit_negatives_fp32_against_reference_goldens(amd, cls):
+    z = load_golden("loss_smooth.npz")
+    zn = load_golden("loss_negatives.npz")
+    Q, D, N = (torch.from_numpy(zn[k]) for k in ("Q", "D", "N"))
+    for vname, kw in SMOOTH_NEG.items():
+        for offset in (0, 6):
+            key = f"{cls}_{vname}_off{offset}"
+            q, d, n = (t.cuda().requires_grad_(True) for t in (Q, D, N))
+            loss = getattr(amd, cls)(**kw)(q, d, n, offset=offset)
+            want = float(z[key + "_loss"])
+            assert abs(float(loss.detach()) - want) <= 2e-4 * abs(want) + 1e-6, key
+            loss.backward()
+            assert _close32(q.grad, z[key + "_dQ"]), (key, "dQ")
+            if key + "_dN" in z.files:
+                assert _close32(n.grad, z[key + "_dN"]), (key, "dN")
+
+
+@pytest.mark.parametrize("B,C,Lq,Ld,dim,dtype", [(8, 24, 20, 100, 128, torch.bfloat16), (5, 11, 40, 70, 128, torch.bfloat16),
+                                                 (4, 9, 33, 45, 320, torch.bfloat16), (6, 12, 70, 50, 64, torch.float16)])
+def test_smooth_max_16bit_inputs_against_oracle(amd, B, C, Lq, Ld, dim, dtype):
+    g = torch.Generator().manual_seed(B * 100 + C)
+    Q = torch.nn.functional.normalize(torch.randn(B, Lq, dim, generator=g), dim=-1).to(dtype)
+    D = torch.nn.functional.normalize(torch.randn(C, Ld, dim, generator=g), dim=-1).to(dtype)
+    Q[1, Lq - 3:] = 0       # padded query rows still contribute tau * log(Ld) each, as in the reference
+    D[2, Ld - 7:] = 0
+    want_loss, want_dq, want_dd = lo.loss_and_grads("infonce", Q.float(), D.float(), offset=2, temperature=0.5,
+                                                    use_smooth_max=True, tau=0.1)
+    q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+    loss = amd.ColbertLoss(temperature=0.5, use_smooth_max=True, tau=0.1)(q, d, offset=2)
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+    assert loss.dtype == dtype and abs(float(loss.detach()) - float(want_loss)) <= eps * abs(float(want_loss)) + 1e-4
+    loss.backward()
+    assert torch.all((q.grad.float().cpu() - want_dq.float()).abs() <= want_dq.float().abs() * 2 * eps + 2e-5)
+    assert torch.all((d.grad.float().cpu() - want_dd.float()).abs() <= want_dd.float().abs() * 2 * eps + 2e-5)
+
+
+def test_smooth_max_scores_match_float64_logsumexp(amd):
+    # forward alone, dense and pair-list entry points, including a query longer than 64 tokens (sub-passes)
+    g = torch.Generator().manual_seed(3)
+    Q = torch.nn.functional.normalize(torch.randn(7, 75, 128, generator=g), dim=-1).to(torch.bfloat16)
+    D = torch.nn.functional.normalize(torch.randn(19, 130, 128, generator=g), dim=-1).to(torch.bfloat16)
+    tau = 0.05
+    want = (tau * torch.logsumexp(torch.einsum("bnd,csd->bcns", Q.double(), D.double()) / tau, dim=3)).sum(2)
+    got = amd.loss.maxsim_smooth(Q.cuda(), D.cuda(), tau).cpu().double()
+    assert torch.max((got - want).abs() / want.abs().clamp_min(1.0)) < 1e-5
+    pairs = torch.tensor([[0, 3], [0, 18], [2, 0], [6, 5], [6, 6]], dtype=torch.int32)
+    got_p = amd.loss.maxsim_smooth_paired(Q.cuda(), D.cuda(), pairs.cuda(), tau).cpu().double()
+    want_p = torch.stack([want[b, c] for b, c in pairs.tolist()])
+    assert torch.max((got_p - want_p).abs() / want_p.abs().clamp_min(1.0)) < 1e-5

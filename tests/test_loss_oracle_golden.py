@@ -53,3 +53,40 @@ def test_explicit_negative_variants_match_the_reference(cls, kind):
             assert abs(float(loss) - float(z[key + "_loss"])) < 5e-6 * max(1.0, abs(float(loss))), key
             np.testing.assert_allclose(dQ.numpy(), z[key + "_dQ"], rtol=5e-4, atol=1e-5, err_msg=key)
             np.testing.assert_allclose(dN.numpy(), z[key + "_dN"], rtol=5e-4, atol=1e-5, err_msg=key)
+
+
+SMOOTH = {"tau01": dict(use_smooth_max=True),
+          "tau002_nonorm_T1": dict(use_smooth_max=True, tau=0.02, normalize_scores=False, temperature=1.0)}
+SMOOTH_NEG = {"tau01": dict(use_smooth_max=True),
+              "tau05_T1_w03": dict(use_smooth_max=True, tau=0.5, temperature=1.0, in_batch_term_weight=0.3)}
+
+
+@pytest.mark.parametrize("cls,kind", [("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")])
+def test_smooth_max_loss_and_gradients_match_the_reference(cls, kind):
+    """use_smooth_max=True (late_interaction_losses.py:40-44, :88-90) against the live reference's outputs."""
+    z = load_golden("loss_smooth.npz")
+    zs = load_golden("loss_small.npz")
+    Q, D = torch.from_numpy(zs["Q"]), torch.from_numpy(zs["D"])
+    for vname, kw in SMOOTH.items():
+        for offset in (0, 6):
+            key = f"{cls}_{vname}_off{offset}"
+            loss, dQ, dD = lo.loss_and_grads(kind, Q, D, offset=offset, **kw)
+            assert abs(float(loss) - float(z[key + "_loss"])) < 5e-6 * max(1.0, abs(float(loss))), key
+            np.testing.assert_allclose(dQ.numpy(), z[key + "_dQ"], rtol=5e-4, atol=5e-6, err_msg=key)
+            if key + "_dD" in z.files:
+                np.testing.assert_allclose(dD.numpy(), z[key + "_dD"], rtol=5e-4, atol=5e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("cls,kind", [("ColbertNegativeCELoss", "negative_ce"), ("ColbertPairwiseNegativeCELoss", "pairwise_negative_ce")])
+def test_smooth_max_explicit_negative_variants_match_the_reference(cls, kind):
+    z = load_golden("loss_smooth.npz")
+    zn = load_golden("loss_negatives.npz")
+    Q, D, N = (torch.from_numpy(zn[k]) for k in ("Q", "D", "N"))
+    for vname, kw in SMOOTH_NEG.items():
+        for offset in (0, 6):
+            key = f"{cls}_{vname}_off{offset}"
+            loss, dQ, dD, dN = lo.negatives_loss_and_grads(kind, Q, D, N, offset=offset, **kw)
+            assert abs(float(loss) - float(z[key + "_loss"])) < 5e-6 * max(1.0, abs(float(loss))), key
+            np.testing.assert_allclose(dQ.numpy(), z[key + "_dQ"], rtol=5e-4, atol=1e-5, err_msg=key)
+            if key + "_dN" in z.files:
+                np.testing.assert_allclose(dN.numpy(), z[key + "_dN"], rtol=5e-4, atol=1e-5, err_msg=key)
