@@ -218,9 +218,32 @@ def smooth_golden():
     save("loss_smooth.npz", **out)
 
 
+SIGMOID_VARIANTS = {"default": dict(), "nonorm_T1": dict(normalize_scores=False, temperature=1.0),
+                    "filter_T05": dict(pos_aware_negative_filtering=True, temperature=0.5),
+                    "smooth_T1": dict(use_smooth_max=True, temperature=1.0)}
+
+
+def sigmoid_golden():
+    """(9) ColbertSigmoidLoss (late_interaction_losses.py:401-465) on the square in-batch case (C == B, offset 0), the only
+    shape its flattened pos_mask construction (:456-462) addresses consistently.
+        python tests/golden/make_golden.py sigmoid"""
+    zs = np.load(os.path.join(HERE, "loss_small.npz"))
+    Q, D = torch.from_numpy(zs["Q"]), torch.from_numpy(zs["D"])[:6].contiguous()
+    out = {}
+    for vname, kw in SIGMOID_VARIANTS.items():
+        q = Q.clone().requires_grad_(True); d = D.clone().requires_grad_(True)
+        loss = L.ColbertSigmoidLoss(**kw)(q, d)
+        loss.backward()
+        out[f"{vname}_loss"] = loss.detach().numpy(); out[f"{vname}_dQ"] = q.grad.numpy(); out[f"{vname}_dD"] = d.grad.numpy()
+    save("loss_sigmoid.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "smooth":
         smooth_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sigmoid":
+        sigmoid_golden()
     else:
         main()
         smooth_golden()
+        sigmoid_golden()

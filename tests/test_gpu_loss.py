@@ -358,3 +358,40 @@ def test_smooth_max_scores_match_float64_logsumexp(amd):
     got_p = amd.loss.maxsim_smooth_paired(Q.cuda(), D.cuda(), pairs.cuda(), tau).cpu().double()
     want_p = torch.stack([want[b, c] for b, c in pairs.tolist()])
     assert torch.max((got_p - want_p).abs() / want_p.abs().clamp_min(1.0)) < 1e-5
+
+
+SIGMOID_VARIANTS = {"default": dict(), "nonorm_T1": dict(normalize_scores=False, temperature=1.0),
+                    "filter_T05": dict(pos_aware_negative_filtering=True, temperature=0.5),
+                    "smooth_T1": dict(use_smooth_max=True, temperature=1.0)}
+
+
+def test_sigmoid_loss_fp32_against_reference_goldens_and_bf16_against_oracle(amd):
+    """ColbertSigmoidLoss (late_interaction_losses.py:401-465), square in-batch case."""
+    z = load_golden("loss_sigmoid.npz")
+    zs = load_golden("loss_small.npz")
+    Q, D = torch.from_numpy(zs["Q"]), torch.from_numpy(zs["D"])[:6].contiguous()
+    q_real = (Q.abs().sum(-1, keepdim=True) > 0)
+    d_real = (D.abs().sum(-1, keepdim=True) > 0)
+    for vname, kw in SIGMOID_VARIANTS.items():
+        q, d = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+        loss = amd.ColbertSigmoidLoss(**kw)(q, d)
+        want = float(z[vname + "_loss"])
+        assert loss.dtype == torch.float32 and abs(float(loss.detach()) - want) <= 2e-4 * abs(want) + 1e-6, vname
+        loss.backward()
+        smooth = kw.get("use_smooth_max", False)     # hard max: exclude the exact ties at all-zero padding rows
+        for got, name, mask in ((q.grad, "dQ", q_real), (d.grad, "dD", d_real)):
+            w = torch.from_numpy(z[f"{vname}_{name}"])
+            bad = (got.cpu() - w).abs() > 2e-3 * w.abs() + 1e-5
+            if not smooth:
+                bad &= mask.expand_as(w)
+            assert int(bad.sum()) == 0, (vname, name)
+        # bf16 inputs against the float64 oracle
+        Qb, Db = Q.to(torch.bfloat16), D.to(torch.bfloat16)
+        want_loss, want_dq, want_dd = lo.loss_and_grads("sigmoid", Qb.float(), Db.float(), **kw)
+        q, d = Qb.cuda().requires_grad_(True), Db.cuda().requires_grad_(True)
+        loss = amd.ColbertSigmoidLoss(**kw)(q, d)
+        assert loss.dtype == torch.bfloat16
+        assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-7 * abs(float(want_loss)) + 1e-4, vname
+        loss.backward()
+        assert grads_close(q.grad, want_dq, None if smooth else q_real.expand_as(want_dq), paths=2), (vname, "dQ bf16")
+        assert grads_close(d.grad, want_dd, None if smooth else d_real.expand_as(want_dd), paths=2), (vname, "dD bf16")

@@ -90,3 +90,20 @@ def test_smooth_max_explicit_negative_variants_match_the_reference(cls, kind):
             np.testing.assert_allclose(dQ.numpy(), z[key + "_dQ"], rtol=5e-4, atol=1e-5, err_msg=key)
             if key + "_dN" in z.files:
                 np.testing.assert_allclose(dN.numpy(), z[key + "_dN"], rtol=5e-4, atol=1e-5, err_msg=key)
+
+
+SIGMOID_VARIANTS = {"default": dict(), "nonorm_T1": dict(normalize_scores=False, temperature=1.0),
+                    "filter_T05": dict(pos_aware_negative_filtering=True, temperature=0.5),
+                    "smooth_T1": dict(use_smooth_max=True, temperature=1.0)}
+
+
+def test_sigmoid_loss_matches_the_reference():
+    """ColbertSigmoidLoss (late_interaction_losses.py:401-465), square in-batch case."""
+    z = load_golden("loss_sigmoid.npz")
+    zs = load_golden("loss_small.npz")
+    Q, D = torch.from_numpy(zs["Q"]), torch.from_numpy(zs["D"])[:6]
+    for vname, kw in SIGMOID_VARIANTS.items():
+        loss, dQ, dD = lo.loss_and_grads("sigmoid", Q, D, **kw)
+        assert abs(float(loss) - float(z[vname + "_loss"])) < 5e-6 * max(1.0, abs(float(loss))), vname
+        np.testing.assert_allclose(dQ.numpy(), z[vname + "_dQ"], rtol=5e-4, atol=5e-6, err_msg=vname)
+        np.testing.assert_allclose(dD.numpy(), z[vname + "_dD"], rtol=5e-4, atol=5e-6, err_msg=vname)
