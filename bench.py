@@ -141,6 +141,38 @@ def torch_gpu_reference(q_len, doc_len):
                       f"(includes its per-block pad_sequence + H2D), best of 3"}
 
 
+def embed_head_numbers(amd, dev):
+    """SURVEY 8(f) N1, the step before the path: hidden states of 500 ColPali pages (1030 x 2048 bf16, 2.1 GB) ->
+    projection + L2 norm + mask, written as the scorer's corpus rows.  HBM-bound (128 FLOP per streamed byte)."""
+    B, S, H = 500, 1030, 2048
+    g = torch.Generator(device=dev).manual_seed(3)
+    hidden = torch.randn((B, S, H), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    weight = (torch.randn((128, H), generator=g, device=dev) / H**0.5).to(torch.bfloat16)
+    bias = (torch.randn((128,), generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    mask = torch.ones((B, S), dtype=torch.long, device=dev)
+    mask[:, S - 6:] = 0
+
+    def ref():
+        proj = torch.nn.functional.linear(hidden, weight, bias)
+        proj = proj / proj.norm(dim=-1, keepdim=True)
+        return proj * mask.unsqueeze(-1)
+
+    out = {}
+    for name, fn in (("fused_head", lambda: amd.embedding_head(hidden, weight, bias, mask)), ("reference_lines_on_this_gpu", ref)):
+        for _ in range(2):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(7)]
+        for a, b in evs:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[3]
+        byts = B * S * H * 2 + B * S * 256
+        out[name] = {"ms": ms, "rows_per_s": B * S / ms * 1e3, "hbm_gbs": byts / ms / 1e6, "frac_of_8TBs": byts / ms / 1e6 / HBM_PEAK_GBS}
+    out["workload"] = f"{B} pages x {S} tokens x hidden {H} bf16 -> [rows, 128] unit rows (algorithmic bytes = hidden read + rows written)"
+    del hidden
+    return out
+
+
 def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
     """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list)."""
     dev = q.device
@@ -265,6 +297,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
         out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)
+        out["embed_head"] = embed_head_numbers(amd, dev)
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []

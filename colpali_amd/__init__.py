@@ -6,11 +6,14 @@ Drop-in for the MaxSim hot path of illuin-tech/colpali:
   * ColbertPairwiseCELoss (+ ColbertLoss, ColbertSigmoidLoss, ColbertModule)
                                   <- colpali_engine/loss/late_interaction_losses.py:255-313 (:110-164, :401-465, :6-107)
   * ShardedRetriever / topk       -- sharded-corpus top-k with an RCCL all-gather merge (no reference equivalent)
+  * embedding_head / CorpusWriter <- the projection / L2-norm / mask tail of every Col* forward
+                                     (models/paligemma/colpali/modeling_colpali.py:67-77), writing the packed corpus
 The compute lives in hand-written HIP kernels behind a C ABI (include/maxsim.h,
 colpali_amd/csrc/); this package is the thin host-side mirror of the reference interface.
 """
 from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
 from . import loss
+from .embed import CorpusWriter, embedding_head
 from .loss import (ColbertLoss, ColbertModule, ColbertNegativeCELoss, ColbertPairwiseCELoss,
                    ColbertPairwiseNegativeCELoss, ColbertSigmoidLoss, maxsim, maxsim_paired)
 from .patch import patch_colpali_engine, unpatch_colpali_engine
@@ -18,6 +21,8 @@ from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk
 from .scoring import get_torch_device, maxsim_scores, score_multi_vector
 
 __all__ = [
+    "CorpusWriter",
+    "embedding_head",
     "ColbertLoss",
     "ColbertModule",
     "ColbertNegativeCELoss",

@@ -16,6 +16,7 @@
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
 #include "maxsim_smooth.hip"
+#include "embed_head.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -613,6 +614,43 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void 
         case MSIM_DTYPE_F16: return smooth_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
         default: return smooth_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
     }
+}
+
+// ---------------------------------------------------------------- embedding head (the producer of the corpus format)
+int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, const void *bias, int n_out,
+                    const int32_t *row_map, void *out, int64_t ld_out, void *stream) {
+    if (M < 0 || H <= 0) return fail(MSIM_EINVAL, "bad size (M=%lld H=%d)", (long long)M, H);
+    if (M == 0) return MSIM_OK;
+    if (!X || !W || !row_map || !out) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16)
+        return fail(MSIM_EUNSUPPORTED, "dtype code %d: the embedding head takes bfloat16 (0) or float16 (1) hidden states", dtype);
+    if (n_out != msim::kHeadN) return fail(MSIM_EUNSUPPORTED, "n_out=%d: the embedding head is built for 128 output columns", n_out);
+    if (H % msim::kHeadBK != 0 || H > 16384) return fail(MSIM_EUNSUPPORTED, "H=%d: hidden size must be a multiple of 64, <= 16384", H);
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) return fail(MSIM_EINVAL, "X and W must be 16-byte aligned");
+    if (ld_out < msim::kHeadN) return fail(MSIM_EINVAL, "ld_out=%lld < 128", (long long)ld_out);
+    if (M > (int64_t)0x7fffffff * 128) return fail(MSIM_EUNSUPPORTED, "too many rows");
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    msim::HeadArgs a;
+    a.M = M;
+    a.H = H;
+    a.ld_out = ld_out;
+    const long long tiles = (M + msim::kHeadBM - 1) / msim::kHeadBM;
+    const int grid = tiles < di->cus ? (int)tiles : di->cus;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *x = static_cast<const uint16_t *>(X), *w = static_cast<const uint16_t *>(W), *b = static_cast<const uint16_t *>(bias);
+    uint16_t *o = static_cast<uint16_t *>(out);
+    auto go = [&](auto kern, std::atomic<int> *configured) -> int {
+        if (int rc = allow_lds(kern, msim::kHeadLds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(msim::kHeadThreads), msim::kHeadLds, st, x, w, b, row_map, o, a);
+        return MSIM_OK;
+    };
+    static std::atomic<int> configured[2][kMaxDevices];
+    const int rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true>, configured[0]) : go(msim::embed_head_kernel<false>, configured[1]);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
 }
 
 // ---------------------------------------------------------------- top-k selection

@@ -1,0 +1,143 @@
+"""Embedding head on the MI355X: the last lines of every Col* model forward, fused, writing the scorer's corpus format.
+
+Reference lines (identical in every model family):
+    colpali_engine/models/paligemma/colpali/modeling_colpali.py:67-77
+    colpali_engine/models/qwen2/colqwen2/modeling_colqwen2.py:65-74
+        proj = self.custom_text_proj(hidden_states)
+        proj = proj / proj.norm(dim=-1, keepdim=True)
+        proj = proj * attention_mask.unsqueeze(-1)
+        [proj = proj * image_mask]                         # mask_non_image_embeddings
+and the road from there to the scorer (README.md:121-126: `torch.unbind(embeddings.to("cpu"))`, later
+`pad_sequence` + H2D per block inside score_multi_vector, processing_utils.py:172-178).
+
+`embedding_head`  -- dense drop-in for those lines: same [B, S, 128] tensor.
+`CorpusWriter`    -- the MI355X-native road: rows go straight from the model's hidden states into the resident
+                     packed corpus the MaxSim kernels stream; masked positions are dropped and replaced by the
+                     per-document clamp0 flag (a zero row and "similarity 0 takes part in the max" are the same
+                     thing), so the corpus holds real patches only and never leaves the GPU.
+All arithmetic runs in colpali_amd/csrc/embed_head.hip behind msim_embed_head (include/maxsim.h); no torch fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .corpus import PackedCorpus, block_clamp0
+
+HEAD_DIM = 128
+_TILE = 256
+
+
+def _check(hidden: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], mask: torch.Tensor) -> None:
+    if hidden.dim() != 3:
+        raise ValueError("hidden_states must be [batch, sequence, hidden]")
+    if hidden.device.type != "cuda":
+        raise RuntimeError("colpali_amd.embedding_head runs on an MI355X only (no CPU fallback)")
+    if hidden.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"embedding head: hidden states of dtype {hidden.dtype}; bf16 / fp16 only")
+    if weight.shape != (HEAD_DIM, hidden.shape[2]) or weight.dtype != hidden.dtype or weight.device != hidden.device:
+        raise ValueError(f"weight must be [{HEAD_DIM}, hidden] with the dtype/device of the hidden states")
+    if bias is not None and (bias.shape != (HEAD_DIM,) or bias.dtype != hidden.dtype or bias.device != hidden.device):
+        raise ValueError(f"bias must be [{HEAD_DIM}] with the dtype/device of the hidden states")
+    if hidden.shape[2] % 64 != 0:
+        raise NotImplementedError(f"embedding head: hidden size {hidden.shape[2]} is not a multiple of 64")
+    if mask.shape != hidden.shape[:2]:
+        raise ValueError("attention_mask must be [batch, sequence]")
+
+
+def _launch(hidden: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], row_map: torch.Tensor,
+            out: torch.Tensor) -> None:
+    L = _lib.lib()
+    x = hidden.contiguous()
+    M, H = x.shape[0] * x.shape[1], x.shape[2]
+    with torch.cuda.device(x.device):
+        rc = L.msim_embed_head(_lib.dtype_code(x.dtype), _lib.ptr(x), M, H, _lib.ptr(weight.contiguous()),
+                               _lib.ptr(bias.contiguous() if bias is not None else None), HEAD_DIM, _lib.ptr(row_map),
+                               _lib.ptr(out), out.stride(0), _lib.current_stream_handle(x.device))
+    _lib.check(rc, "msim_embed_head")
+
+
+def _padded_map(n: int, device) -> torch.Tensor:
+    """int32 row map with the tile padding the kernel may read (filled with -1 = drop)."""
+    return torch.full(((n + _TILE - 1) // _TILE * _TILE,), -1, dtype=torch.int32, device=device)
+
+
+def embedding_head(hidden_states: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                   attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense drop-in for modeling_colpali.py:67-77: [B, S, hidden] -> [B, S, 128] (unit rows, masked rows zero).
+
+    `extra_mask` is the optional image-token mask of `mask_non_image_embeddings` ([B, S] or [B, S, 1])."""
+    _check(hidden_states, weight, bias, attention_mask)
+    B, S, _ = hidden_states.shape
+    keep = attention_mask.reshape(-1) != 0
+    if extra_mask is not None:
+        keep = keep & (extra_mask.reshape(-1) != 0)
+    rows = torch.arange(B * S, dtype=torch.int32, device=hidden_states.device)
+    row_map = _padded_map(B * S, hidden_states.device)
+    row_map[: B * S] = torch.where(keep, rows, -2 - rows)
+    out = torch.empty((B * S, HEAD_DIM), dtype=hidden_states.dtype, device=hidden_states.device)
+    _launch(hidden_states, weight, bias, row_map, out)
+    return out.view(B, S, HEAD_DIM)
+
+
+class CorpusWriter:
+    """Device-resident packed corpus under construction: `append` runs the fused head on a batch of hidden states and
+    writes the unmasked rows of every page back to back; `finish` returns the PackedCorpus the scorer streams.
+
+    Scores of the finished corpus equal what the reference computes from `list(torch.unbind(model(**batch)))`
+    (README.md:121-126) with the same `batch_size` blocking: a page's masked positions are zero rows there, here they
+    are dropped and the page carries the clamp0 flag; pages of different padded lengths sharing a scorer block get the
+    flag through the same `block_clamp0` rule as pack_passages.
+    """
+
+    def __init__(self, capacity_rows: int, device, dtype: torch.dtype = torch.bfloat16, score_batch_size: Optional[int] = 128):
+        self.device = torch.device(device)
+        self.blob = torch.empty((max(capacity_rows, 1), HEAD_DIM), dtype=dtype, device=self.device)
+        self.capacity = capacity_rows
+        self.score_batch_size = score_batch_size
+        self._rows_dev = torch.zeros((), dtype=torch.int64, device=self.device)   # exact count, stays on the device
+        self._rows_upper = 0                                                       # host-side bound (no sync per append)
+        self._bases, self._counts, self._padded_lens = [], [], []
+
+    def append(self, hidden_states: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+               attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor] = None) -> int:
+        """Returns the number of pages appended.  Asynchronous: no host synchronisation."""
+        _check(hidden_states, weight, bias, attention_mask)
+        if hidden_states.dtype != self.blob.dtype or hidden_states.device != self.device:
+            raise ValueError("hidden states must have the writer's dtype and device")
+        B, S, _ = hidden_states.shape
+        self._rows_upper += B * S
+        if self._rows_upper > self.capacity:
+            raise RuntimeError(f"CorpusWriter capacity of {self.capacity} rows exceeded (upper bound {self._rows_upper})")
+        keep = attention_mask != 0
+        if extra_mask is not None:
+            keep = keep & (extra_mask.reshape(B, S) != 0)
+        counts = keep.sum(dim=1)                                                   # int64 [B]
+        ends = torch.cumsum(counts, 0) + self._rows_dev
+        bases = ends - counts
+        rank = torch.cumsum(keep, dim=1) - 1
+        dest = torch.where(keep, bases[:, None] + rank, -1).to(torch.int32)
+        row_map = _padded_map(B * S, self.device)
+        row_map[: B * S] = dest.reshape(-1)
+        _launch(hidden_states, weight, bias, row_map, self.blob)
+        self._rows_dev = ends[-1]
+        self._bases.append(bases)
+        self._counts.append(counts)
+        self._padded_lens.append(torch.full((B,), S, dtype=torch.int64))
+        return B
+
+    def finish(self, id_base: int = 0) -> PackedCorpus:
+        """One host synchronisation (the page lengths are needed on the host for the block flags)."""
+        counts = torch.cat(self._counts)
+        lengths = counts.cpu()
+        padded = torch.cat(self._padded_lens)
+        offsets = torch.zeros(lengths.numel() + 1, dtype=torch.int64)
+        torch.cumsum(lengths, 0, out=offsets[1:])
+        flags = (lengths < padded).to(torch.uint8)                                  # page had masked positions
+        if self.score_batch_size is not None:
+            flags |= block_clamp0(padded, self.score_batch_size)                   # shorter than its scorer block
+        total = int(offsets[-1])
+        return PackedCorpus(blob=self.blob[: max(total, 1)], offsets=offsets.to(torch.int32).to(self.device),
+                            clamp0=flags.to(self.device) if bool(flags.any()) else None, lengths=lengths, id_base=id_base)

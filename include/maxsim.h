@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 4
+#define MSIM_ABI_VERSION 5
 
 /* error codes */
 #define MSIM_OK 0
@@ -149,6 +149,26 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
                           const int32_t *pairs, const int32_t *order_by_doc,
                           const float *g, const float *lse, int n_pairs, float tau,
                           float *dQ, float *dD, void *stream);
+
+/*
+ * Embedding head: the last three lines of every Col* model forward, producing the scorer's corpus format.
+ *     y   = X @ W^T + bias                       nn.Linear(hidden, 128)
+ *     y   = y / ||y||_2                          (row-wise, rounding chain of the model dtype)
+ *     out = y * mask
+ * Replaces colpali_engine/models/paligemma/colpali/modeling_colpali.py:67-77 and
+ * colpali_engine/models/qwen2/colqwen2/modeling_colqwen2.py:65-74 (identical in the other families), and the
+ * unbind / .cpu() / pad_sequence / H2D round trip between the model and the scorer (README.md:121-126,
+ * processing_utils.py:172-178): rows can be written straight into the packed corpus blob msim_fwd streams.
+ *   X [M, H] bf16|f16 hidden states (row-major, H a multiple of 64), W [128, H], bias [128] or NULL (same dtype)
+ *   row_map int32, ceil(M / 256) * 256 entries (the padding is never dereferenced for rows >= M but must be readable):
+ *       v >= 0   write the normalised row m to out row v
+ *       v == -1  drop row m (masked position of an unpadded corpus)
+ *       v <= -2  write a row of (signed) zeros to out row -2 - v   (masked position kept in place: the dense model output)
+ *   out [rows, ld_out] same dtype as X, ld_out >= 128 elements.
+ */
+int msim_embed_head(int dtype, const void *X, int64_t M, int H,
+                    const void *W, const void *bias, int n_out,
+                    const int32_t *row_map, void *out, int64_t ld_out, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -34,3 +34,21 @@ def load():
     from colpali_engine.utils.processing_utils import BaseVisualRetrieverProcessor  # noqa: E402
 
     return BaseVisualRetrieverProcessor, late_interaction_losses
+
+
+def load_colpali_class():
+    """The live reference's ColPali model class (random-init use only: no weights exist here).  The model
+    sub-packages' __init__ files import every family, so they are stubbed the same way as the top-level package."""
+    if not available():
+        raise RuntimeError(f"reference checkout not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True
+    for name, sub in (("colpali_engine", ""), ("colpali_engine.models", "models"),
+                      ("colpali_engine.models.paligemma", "models/paligemma"),
+                      ("colpali_engine.models.paligemma.colpali", "models/paligemma/colpali")):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [os.path.join(REFERENCE_ROOT, "colpali_engine", sub)]
+            sys.modules[name] = pkg
+    from colpali_engine.models.paligemma.colpali.modeling_colpali import ColPali  # noqa: E402
+
+    return ColPali

@@ -238,8 +238,48 @@ def sigmoid_golden():
     save("loss_sigmoid.npz", **out)
 
 
+def head_golden():
+    """(10) the embedding head (modeling_colpali.py:67-72) as executed by the live reference's ColPali.forward on a
+    random-init tiny PaliGemma config: the hidden states its custom_text_proj received, its weight / bias, the attention
+    mask and the forward's return value, in fp32 and in bf16.
+        python tests/golden/make_golden.py head"""
+    from transformers import PaliGemmaConfig
+
+    ColPali = refimport.load_colpali_class()
+    cfg = PaliGemmaConfig(
+        vision_config=dict(model_type="siglip_vision_model", hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                           num_attention_heads=2, image_size=28, patch_size=14, projection_dim=128, vocab_size=300),
+        text_config=dict(model_type="gemma", hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, head_dim=64, vocab_size=300),
+        image_token_index=299, projection_dim=128, hidden_size=128, vocab_size=300)
+    torch.manual_seed(0)
+    model = ColPali(cfg).eval()
+    g = torch.Generator().manual_seed(1)
+    B, S = 5, 37
+    ids = torch.randint(0, 290, (B, S), generator=g)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, 30:] = 0          # right padding (ColPali style)
+    mask[3, 11:] = 0
+    out = {"input_ids": ids.numpy(), "attention_mask": mask.numpy()}
+    for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = model.to(dtype)
+        cap = {}
+        hook = m.custom_text_proj.register_forward_hook(lambda mod, inp, o: cap.update(h=inp[0].detach().clone()))
+        with torch.no_grad():
+            y = m(input_ids=ids, attention_mask=mask)
+        hook.remove()
+        conv = (lambda t: t.float().numpy()) if dtype == torch.float32 else (lambda t: bits(t.contiguous()))
+        out[f"hidden_{tag}"] = conv(cap["h"])
+        out[f"weight_{tag}"] = conv(m.custom_text_proj.weight.detach())
+        out[f"bias_{tag}"] = conv(m.custom_text_proj.bias.detach())
+        out[f"out_{tag}"] = conv(y)
+    save("head_colpali_tiny.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "smooth":
+    if len(sys.argv) > 1 and sys.argv[1] == "head":
+        head_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "smooth":
         smooth_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "sigmoid":
         sigmoid_golden()
@@ -247,3 +287,4 @@ if __name__ == "__main__":
         main()
         smooth_golden()
         sigmoid_golden()
+        head_golden()
