@@ -141,6 +141,40 @@ def torch_gpu_reference(q_len, doc_len):
                       f"(includes its per-block pad_sequence + H2D), best of 3"}
 
 
+def dropin_numbers(amd):
+    """BASELINE configs 2/3 geometry through the drop-in entry point itself: 100 queries x 1000 pages handed over as HOST
+    lists (what README.md:121-126 leaves the user with), end to end including packing, PCIe upload and the D2H of the
+    result -- never the headline `value`, which is measured with the corpus resident."""
+    from oracle import torch_port
+
+    g = torch.Generator().manual_seed(21)
+
+    def unit(n):
+        return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16)
+
+    out = {}
+    for name, lens in (("config2_colpali_1000x1030", [1030] * 1000),
+                       ("config3_colqwen2_1000x267-779", torch.randint(267, 780, (1000,), generator=g).tolist())):
+        qs, ps = [unit(32) for _ in range(100)], [unit(n) for n in lens]
+
+        def timed(fn, reps):
+            fn()
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2]
+
+        ours = timed(lambda: amd.score_multi_vector(qs, ps, device="cuda:0"), 5)
+        ref = timed(lambda: torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0"), 3)
+        out[name] = {"pairs": 100 * len(ps), "ms": ours * 1e3, "pairs_per_s": 100 * len(ps) / ours,
+                     "reference_on_this_gpu_ms": ref * 1e3, "speedup_vs_reference_on_this_gpu": ref / ours}
+    return out
+
+
 def embed_head_numbers(amd, dev):
     """SURVEY 8(f) N1, the step before the path: hidden states of 500 ColPali pages (1030 x 2048 bf16, 2.1 GB) ->
     projection + L2 norm + mask, written as the scorer's corpus rows.  HBM-bound (128 FLOP per streamed byte)."""
@@ -298,6 +332,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
         out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)
         out["embed_head"] = embed_head_numbers(amd, dev)
+        out["dropin_from_host_lists"] = dropin_numbers(amd)
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []

@@ -18,7 +18,8 @@ from .loss import (ColbertLoss, ColbertModule, ColbertNegativeCELoss, ColbertPai
                    ColbertPairwiseNegativeCELoss, ColbertSigmoidLoss, maxsim, maxsim_paired)
 from .patch import patch_colpali_engine, unpatch_colpali_engine
 from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
-from .scoring import get_torch_device, maxsim_scores, score_multi_vector
+from .scoring import (get_similarity_maps_from_embeddings, get_torch_device, maxsim_scores, score_multi_vector,
+                      score_single_vector, similarity_matrix)
 
 __all__ = [
     "CorpusWriter",
@@ -45,4 +46,7 @@ __all__ = [
     "unpatch_colpali_engine",
     "pack_queries",
     "score_multi_vector",
+    "score_single_vector",
+    "similarity_matrix",
+    "get_similarity_maps_from_embeddings",
 ]

@@ -437,6 +437,39 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
     return MSIM_OK;
 }
 
+// ---------------------------------------------------------------- plain similarity matrix
+template <int DT, int T>
+int launch_sim(const char *A, const char *B, float *out, const msim::SimArgs &a, const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::sim_matrix_kernel<DT, T>;
+    const int lds = T * msim::kTokTile * (a.row_bytes + 16);
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, 160 * 1024, configured)) return rc;
+    const int groups = (a.n_a + T * msim::kTokTile - 1) / (T * msim::kTokTile);
+    if (groups > 65535) return fail(MSIM_EUNSUPPORTED, "too many row groups (%d) for one launch", groups);
+    const int slabs = (a.n_b + msim::kSlabRows - 1) / msim::kSlabRows;
+    const int wg_needed = (slabs + msim::kGenericWaves - 1) / msim::kGenericWaves;
+    int per_cu = di.lds_per_cu / lds;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int wg_cap = di.cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap, groups), dim3(msim::kGenericWaves * 64), lds, st, A, B,
+                       out, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "sim_matrix_kernel<%d,%d> launch: %s", DT, T, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <int DT>
+int sim_dispatch(const char *A, const char *B, float *out, const msim::SimArgs &a, const DeviceInfo &di, hipStream_t st) {
+    const int tile_lds = msim::kTokTile * (a.row_bytes + 16);
+    int T = 4;
+    while (T > 1 && (T * tile_lds > 80 * 1024 || (T / 2) * msim::kTokTile >= a.n_a)) T >>= 1;
+    switch (T) {
+        case 4: return launch_sim<DT, 4>(A, B, out, a, di, st);
+        case 2: return launch_sim<DT, 2>(A, B, out, a, di, st);
+        default: return launch_sim<DT, 1>(A, B, out, a, di, st);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -651,6 +684,28 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));
     return MSIM_OK;
+}
+
+// ---------------------------------------------------------------- plain similarity matrix entry point
+int msim_sim_matrix(int dtype, const void *A, int n_a, const void *B, int n_b, int dim, float *out, int64_t ld_out,
+                    uint32_t flags, void *stream) {
+    if (n_a < 0 || n_b < 0) return fail(MSIM_EINVAL, "negative size (n_a=%d n_b=%d)", n_a, n_b);
+    if (n_a == 0 || n_b == 0) return MSIM_OK;
+    if (!out) return fail(MSIM_EINVAL, "null pointer argument");
+    static const int32_t dummy_off[2] = {0, 0};
+    if (int rc = check_smooth(A, B, dummy_off, dtype, dim, 1, 1.0f)) return rc;     // same row-layout contract as the generic kernels
+    if (ld_out < n_b) return fail(MSIM_EINVAL, "ld_out=%lld < n_b=%d", (long long)ld_out, n_b);
+    if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    msim::SimArgs a{ld_out, n_a, n_b, dim * elem_bytes(dtype), flags};
+    const char *ac = static_cast<const char *>(A), *bc = static_cast<const char *>(B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MSIM_DTYPE_F32: return sim_dispatch<msim::kDtypeF32>(ac, bc, out, a, *di, st);
+        case MSIM_DTYPE_F16: return sim_dispatch<msim::kDtypeF16>(ac, bc, out, a, *di, st);
+        default: return sim_dispatch<msim::kDtypeBf16>(ac, bc, out, a, *di, st);
+    }
 }
 
 // ---------------------------------------------------------------- top-k selection

@@ -340,3 +340,89 @@ __global__ __launch_bounds__(256) void maxsim_generic_bwd_dd_kernel(const char *
 }
 
 }  // namespace msim
+
+namespace msim {
+
+// ---------------------------------------------------------------------------------------------------------
+// Plain similarity matrix  out[i, j] = <A[i, :], B[j, :]>  (fp32 accumulate, no reduction), any width / dtype:
+//   colpali_engine/utils/processing_utils.py:126       torch.einsum("bd,cd->bc", qs, ps)          (score_single_vector)
+//   colpali_engine/interpretability/similarity_map_utils.py:50   torch.einsum("nk,ijk->nij", query, image_grid)
+// Workgroup = 8 waves sharing T tiles of 32 A rows in LDS (K1g staging); every wave walks 32-row slabs of B with
+// fragment-shaped global loads.  MFMA roles are chosen so that one lane holds one B row (= output column): a store
+// instruction writes 32 consecutive floats of an output row.
+struct SimArgs {
+    long long ld;          // leading dimension of out
+    int n_a, n_b, row_bytes;
+    unsigned flags;        // kFlagRefBf16: round every dot product to the input dtype (what torch stores)
+};
+
+template <int DT, int T>
+__global__ __launch_bounds__(kGenericWaves * 64) void sim_matrix_kernel(const char *__restrict__ A, const char *__restrict__ B,
+                                                                        float *__restrict__ out, SimArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row_bytes = a.row_bytes;
+    const int q_stride = row_bytes + 16;
+    const int tile_bytes = kTokTile * q_stride;
+    const int n_steps = row_bytes >> 5;
+    const int n16 = row_bytes >> 4;
+    const int a0 = blockIdx.y * (T * kTokTile);          // first A row of this workgroup's group of tiles
+    const int half_off = (lane >> 5) * 16;
+    const bool ref_round = (a.flags & kFlagRefBf16) != 0;
+
+    for (int idx = threadIdx.x; idx < T * kTokTile * n16; idx += kGenericWaves * 64) {
+        const int r = idx / n16, p = idx - r * n16;       // r = row inside the group (0 .. 32T-1)
+        i32x4 v = {0, 0, 0, 0};
+        if (a0 + r < a.n_a) v = *reinterpret_cast<const i32x4 *>(A + (size_t)(a0 + r) * row_bytes + p * 16);
+        *reinterpret_cast<i32x4 *>(smem + (r >> 5) * tile_bytes + (r & 31) * q_stride + p * 16) = v;
+    }
+    __syncthreads();
+    const char *a_lds = smem + (lane & 31) * q_stride + half_off;
+
+    const int n_slabs = (a.n_b + kSlabRows - 1) / kSlabRows;
+    for (int s = blockIdx.x * kGenericWaves + wave; s < n_slabs; s += gridDim.x * kGenericWaves) {
+        const int b0 = s * kSlabRows;
+        int brow = b0 + (lane & 31);
+        brow = brow < a.n_b ? brow : a.n_b - 1;
+        const char *bptr = B + (size_t)brow * row_bytes + half_off;
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int j = 0;
+#pragma unroll 1
+        for (; j + 4 <= n_steps; j += 4) {
+            bf16x8 bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bv[u] = *reinterpret_cast<const bf16x8 *>(bptr + (j + u) * 32);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a_lds + t * tile_bytes + (j + u) * 32);
+                    acc[t] = mfma_step<DT>(av, bv[u], acc[t]);   // A rows -> accumulator rows, B rows -> lane column
+                }
+        }
+#pragma unroll 1
+        for (; j < n_steps; ++j) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(bptr + j * 32);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a_lds + t * tile_bytes + j * 32);
+                acc[t] = mfma_step<DT>(av, bv, acc[t]);
+            }
+        }
+        const int col = b0 + (lane & 31);
+        if (col < a.n_b) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int arow = a0 + t * kTokTile + acc_row(r, lane);
+                    if (arow < a.n_a) out[(size_t)arow * a.ld + col] = ref_round ? round_generic<DT>(acc[t][r]) : acc[t][r];
+                }
+        }
+    }
+}
+
+}  // namespace msim

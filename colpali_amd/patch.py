@@ -18,7 +18,7 @@ import importlib
 import sys
 
 from . import loss as _loss
-from .scoring import score_multi_vector
+from .scoring import get_similarity_maps_from_embeddings, score_multi_vector, score_single_vector
 
 _LOSS_NAMES = ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss", "ColbertNegativeCELoss",
                "ColbertPairwiseNegativeCELoss")
@@ -31,6 +31,12 @@ def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
         cls = pu.BaseVisualRetrieverProcessor
         _saved.setdefault("score_multi_vector", cls.__dict__["score_multi_vector"])
         cls.score_multi_vector = staticmethod(score_multi_vector)
+        _saved.setdefault("score_single_vector", cls.__dict__["score_single_vector"])
+        cls.score_single_vector = staticmethod(score_single_vector)
+        sm = sys.modules.get("colpali_engine.interpretability.similarity_map_utils")
+        if sm is not None:   # only when the user has imported the interpretability helpers
+            _saved.setdefault((sm.__name__, "get_similarity_maps_from_embeddings"), sm.get_similarity_maps_from_embeddings)
+            sm.get_similarity_maps_from_embeddings = get_similarity_maps_from_embeddings
     if losses:
         mods = [importlib.import_module("colpali_engine.loss.late_interaction_losses")]
         pkg = sys.modules.get("colpali_engine.loss")
@@ -45,9 +51,9 @@ def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
 
 def unpatch_colpali_engine() -> None:
     for key, obj in list(_saved.items()):
-        if key == "score_multi_vector":
+        if key in ("score_multi_vector", "score_single_vector"):
             pu = importlib.import_module("colpali_engine.utils.processing_utils")
-            pu.BaseVisualRetrieverProcessor.score_multi_vector = obj
+            setattr(pu.BaseVisualRetrieverProcessor, key, obj)
         else:
             setattr(sys.modules[key[0]], key[1], obj)
         del _saved[key]

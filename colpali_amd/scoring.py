@@ -14,7 +14,7 @@ from typing import List, Optional, Union
 import torch
 
 from . import _lib
-from .corpus import PackedCorpus, pack_passages, pack_queries
+from .corpus import PackedCorpus, _check_embeddings, _widen, pack_passages, pack_queries
 
 logger = logging.getLogger(__name__)
 
@@ -103,3 +103,67 @@ def score_multi_vector(
     scores = maxsim_scores(q, corpus).cpu()
     assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
     return scores.to(torch.float32)
+
+
+def similarity_matrix(a: torch.Tensor, b: torch.Tensor, *, ref_rounding: bool = False,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-level entry: out[i, j] = <a[i], b[j]> in fp32 for [n_a, dim] x [n_b, dim] device tensors (msim_sim_matrix)."""
+    L = _lib.lib()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("expected [n_a, dim] and [n_b, dim]")
+    if a.dtype != b.dtype:
+        raise RuntimeError(f"expected both operands of one dtype, got {a.dtype} and {b.dtype}")
+    if a.device.type != "cuda" or b.device != a.device:
+        raise RuntimeError("colpali_amd.similarity_matrix runs on an MI355X only (no CPU fallback)")
+    _check_embeddings(a, "similarity operand")
+    aw, bw = _widen(a).contiguous(), _widen(b).contiguous()
+    n_a, n_b = a.shape[0], b.shape[0]
+    if out is None:
+        out = torch.empty((n_a, n_b), dtype=torch.float32, device=a.device)
+    elif out.shape != (n_a, n_b) or out.dtype != torch.float32 or (n_b > 1 and out.stride(1) != 1):
+        raise ValueError("out must be fp32 [n_a, n_b] with unit inner stride")
+    with torch.cuda.device(a.device):
+        rc = L.msim_sim_matrix(_lib.dtype_code(a.dtype), _lib.ptr(aw), n_a, _lib.ptr(bw), n_b, aw.shape[1], _lib.ptr(out),
+                               out.stride(0) if n_a > 1 else max(n_b, 1),
+                               _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0, _lib.current_stream_handle(a.device))
+    _lib.check(rc, "msim_sim_matrix")
+    return out
+
+
+def score_single_vector(
+    qs: Union[torch.Tensor, List[torch.Tensor]],
+    ps: Union[torch.Tensor, List[torch.Tensor]],
+    device: Optional[Union[str, torch.device]] = None,
+) -> torch.Tensor:
+    """Dot-product scores of single-vector (bi-encoder) embeddings, drop-in for processing_utils.py:103-130:
+    a new fp32 tensor [n_queries, n_passages] on `device` (the reference does not move this one to the CPU)."""
+    device = device or get_torch_device("auto")
+    if isinstance(qs, list) and isinstance(ps, list):
+        if len(qs) == 0:
+            raise ValueError("No queries provided")
+        if len(ps) == 0:
+            raise ValueError("No passages provided")
+        qs, ps = torch.stack(qs), torch.stack(ps)
+    dev = _require_gpu(device)
+    scores = similarity_matrix(qs.to(dev), ps.to(dev))
+    assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+    return scores.to(torch.float32)
+
+
+def get_similarity_maps_from_embeddings(image_embeddings: torch.Tensor, query_embeddings: torch.Tensor, n_patches,
+                                        image_mask: torch.Tensor) -> List[torch.Tensor]:
+    """Per-image similarity maps [query_tokens, n_patches_x, n_patches_y], drop-in for
+    colpali_engine/interpretability/similarity_map_utils.py:9-55 (same checks, same axis order, same dtype)."""
+    if isinstance(n_patches, tuple):
+        n_patches = [n_patches] * image_embeddings.size(0)
+    maps: List[torch.Tensor] = []
+    for idx in range(image_embeddings.size(0)):
+        nx, ny = n_patches[idx]
+        if image_mask[idx].sum() != nx * ny:
+            raise ValueError(
+                f"The number of patches ({nx} x {ny} = {nx * ny}) "
+                f"does not match the number of non-padded image tokens ({image_mask[idx].sum()}).")
+        patches = image_embeddings[idx][image_mask[idx]]                       # (h w) c, h = n_patches_y, w = n_patches_x
+        sim = similarity_matrix(query_embeddings[idx].contiguous(), patches.contiguous())   # [n, h*w]
+        maps.append(sim.view(-1, ny, nx).permute(0, 2, 1).to(image_embeddings.dtype))   # "(h w) -> w h": [n, x, y]
+    return maps

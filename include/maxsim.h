@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 5
+#define MSIM_ABI_VERSION 6
 
 /* error codes */
 #define MSIM_OK 0
@@ -169,6 +169,17 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
 int msim_embed_head(int dtype, const void *X, int64_t M, int H,
                     const void *W, const void *bias, int n_out,
                     const int32_t *row_map, void *out, int64_t ld_out, void *stream);
+
+/*
+ * Plain similarity matrix, no reduction:   out[i, j] = <A[i, :], B[j, :]>   (fp32 accumulate)
+ * Replaces colpali_engine/utils/processing_utils.py:126  torch.einsum("bd,cd->bc", qs, ps)   (score_single_vector, the
+ * bi-encoder scorer of the same processor class) and the contraction of
+ * colpali_engine/interpretability/similarity_map_utils.py:50  torch.einsum("nk,ijk->nij", query, image_grid).
+ *   A [n_a, dim], B [n_b, dim] (bf16 | f16 | f32, rows a multiple of 32 bytes, <= 4096), out fp32 [n_a, ld_out].
+ *   MSIM_FLAG_REF_ROUNDING: round every dot product to the input dtype (what torch stores for 16-bit inputs).
+ */
+int msim_sim_matrix(int dtype, const void *A, int n_a, const void *B, int n_b, int dim,
+                    float *out, int64_t ld_out, uint32_t flags, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

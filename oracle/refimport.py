@@ -52,3 +52,19 @@ def load_colpali_class():
     from colpali_engine.models.paligemma.colpali.modeling_colpali import ColPali  # noqa: E402
 
     return ColPali
+
+
+def load_similarity_map_utils():
+    """colpali_engine/interpretability/similarity_map_utils.py of the live reference (the package __init__ pulls the
+    plotting helpers and seaborn, which is not installed: stub the package, import the one module)."""
+    if not available():
+        raise RuntimeError(f"reference checkout not found at {REFERENCE_ROOT}")
+    load()
+    name = "colpali_engine.interpretability"
+    if name not in sys.modules:
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "colpali_engine", "interpretability")]
+        sys.modules[name] = pkg
+    from colpali_engine.interpretability import similarity_map_utils  # noqa: E402
+
+    return similarity_map_utils

@@ -276,8 +276,42 @@ def head_golden():
     save("head_colpali_tiny.npz", **out)
 
 
+def sim_golden():
+    """(11) score_single_vector (processing_utils.py:103-130) and get_similarity_maps_from_embeddings
+    (interpretability/similarity_map_utils.py:9-55) of the live reference.
+        python tests/golden/make_golden.py sim"""
+    sm = refimport.load_similarity_map_utils()
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    # bi-encoder scores: fp32 (the reference's unit-test dtype, dim 32) and bf16 (BiPali width 1024)
+    q32, p32 = torch.randn(4, 32, generator=g), torch.randn(8, 32, generator=g)
+    out["sv_q_f32"], out["sv_p_f32"] = q32.numpy(), p32.numpy()
+    out["sv_scores_f32"] = P.score_single_vector(list(q32), list(p32), device="cpu").numpy()
+    qb, pb = unit_rows(37, 1024, g), unit_rows(101, 1024, g)
+    out["sv_q_bf16"], out["sv_p_bf16"] = bits(qb), bits(pb)
+    out["sv_scores_bf16"] = P.score_single_vector(qb, pb, device="cpu").numpy()                 # literal (bf16-rounded dots)
+    out["sv_scores_bf16_truth"] = P.score_single_vector(qb.float(), pb.float(), device="cpu").numpy()
+    # similarity maps: 2 images, 6 x 5 and 4 x 7 patch grids inside 40-token sequences, bf16 and fp32
+    B, S, dim = 2, 40, 128
+    img = torch.stack([unit_rows(S, dim, g) for _ in range(B)])
+    qry = torch.stack([unit_rows(9, dim, g) for _ in range(B)])
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[0, 3:33] = True       # 30 = 6 x 5
+    mask[1, 10:38] = True      # 28 = 4 x 7
+    n_patches = [(6, 5), (4, 7)]
+    out["map_img_bf16"], out["map_qry_bf16"], out["map_mask"] = bits(img), bits(qry), mask.numpy()
+    out["map_n_patches"] = np.array(n_patches, np.int32)
+    for tag, conv in (("bf16", lambda t: t), ("f32", lambda t: t.float())):
+        maps = sm.get_similarity_maps_from_embeddings(conv(img), conv(qry), n_patches, mask)
+        for i, m in enumerate(maps):
+            out[f"map_{tag}_{i}"] = m.float().numpy()
+    save("sim_matrix.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "head":
+    if len(sys.argv) > 1 and sys.argv[1] == "sim":
+        sim_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "head":
         head_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "smooth":
         smooth_golden()
@@ -288,3 +322,4 @@ if __name__ == "__main__":
         smooth_golden()
         sigmoid_golden()
         head_golden()
+        sim_golden()

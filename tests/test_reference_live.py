@@ -70,6 +70,9 @@ def test_patch_routes_the_reference_entry_points_to_the_native_implementations()
         assert surface(colpali_amd.ColbertLoss.__init__) == surface(L.ColbertLoss.__init__)
         assert surface(colpali_amd.ColbertSigmoidLoss.__init__) == surface(L.ColbertSigmoidLoss.__init__)
         assert surface(colpali_amd.score_multi_vector) == surface(orig)
+        assert surface(colpali_amd.score_single_vector) == surface(P.score_single_vector)
+        sm = refimport.load_similarity_map_utils()
+        assert surface(colpali_amd.get_similarity_maps_from_embeddings) == surface(sm.get_similarity_maps_from_embeddings)
     finally:
         colpali_amd.unpatch_colpali_engine()
     assert P.score_multi_vector is orig
