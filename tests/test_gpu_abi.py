@@ -69,3 +69,38 @@ def test_deterministic_across_repeated_launches(amd):
     a = amd.maxsim_scores(q.to(dev), corpus).clone()
     for _ in range(3):
         assert torch.equal(amd.maxsim_scores(q.to(dev), corpus), a)
+
+
+def test_every_other_entry_point_is_graph_capturable(amd):
+    """Smooth-max forward, similarity matrix, embedding head and the generic (fp32) scorer under hipGraph capture: nothing
+    in the library allocates or synchronises."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    Q = torch.nn.functional.normalize(torch.randn(6, 20, 128, generator=g), dim=-1).to(torch.bfloat16).to(dev)
+    D = torch.nn.functional.normalize(torch.randn(9, 50, 128, generator=g), dim=-1).to(torch.bfloat16).to(dev)
+    hidden = torch.randn(2, 40, 256, generator=g).to(torch.bfloat16).to(dev)
+    W = (torch.randn(128, 256, generator=g) / 16).to(torch.bfloat16).to(dev)
+    b = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+    mask = torch.ones(2, 40, dtype=torch.long, device=dev)
+    Qf, Df = Q.float(), D.float()
+    corpus32 = amd.pack_passages(list(Df), dev, batch_size=None)
+
+    def run():
+        return (amd.loss.maxsim_smooth(Q, D, 0.1), amd.similarity_matrix(Q[0], D[0]),
+                amd.embedding_head(hidden, W, b, mask), amd.maxsim_scores(Qf, corpus32))
+
+    eager = [t.clone() for t in run()]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = run()
+    for t in captured:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for got, want in zip(captured, eager):
+        assert torch.equal(got, want)
