@@ -15,6 +15,7 @@
 #include "maxsim_batch.hip"
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
+#include "maxsim_panels.hip"
 #include "maxsim_smooth.hip"
 #include "embed_head.hip"
 #include "topk_select.hip"
@@ -310,8 +311,8 @@ int generic_dispatch(const GenericCall &c) {
     const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const long long tiles = (long long)c.n_q * tpq;
     const int tile_lds = msim::kTokTile * (c.row_bytes + 16);
-    int T = 4;                                   // resident token tiles: as many as fit ~80 KiB (2 workgroups per CU)
-    while (T > 1 && (T * tile_lds > 80 * 1024 || T / 2 >= tiles)) T >>= 1;
+    int T = 4;                                   // resident token tiles: as many as fit 96 KiB of LDS
+    while (T > 1 && (T * tile_lds > 96 * 1024 || T / 2 >= tiles)) T >>= 1;
     switch (T) {
         case 4: return launch_generic<DT, 4>(c);
         case 2: return launch_generic<DT, 2>(c);
@@ -470,6 +471,78 @@ int sim_dispatch(const char *A, const char *B, float *out, const msim::SimArgs &
     }
 }
 
+// ---------------------------------------------------------------- panel kernels (K1sP / K1bP): 16-bit, dim 320
+constexpr int kPanels320 = 3, kLast320 = 4;     // 320 = (2 * 8 + 4) * 16
+
+bool is_panels(int dtype, int dim, long long tiles, int tpq) {
+    if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || dim != 320 || tpq > 4) return false;
+    return tiles <= 4 || tpq <= 2;               // K1sP holds <= 4 token tiles, K1bP whole queries of <= 2 tiles per wave
+}
+
+template <int QT, int TPQ, bool F16>
+int launch_stream_panels(const FwdCall &c) {
+    auto kern = msim::maxsim_stream_panels_kernel<QT, TPQ, kPanels320, kLast320, F16, 2>;
+    constexpr int lds = 4 * msim::kPanelRing * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    msim::StreamArgs a;
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.flags = c.flags;
+    const int wg_needed = (c.n_d + 3) / 4;
+    const int wg_cap = c.di->cus * (c.di->lds_per_cu / lds);
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, c.st, c.Q, c.D, c.d_off, c.clamp0,
+                       c.scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_stream_panels_kernel<%d,%d> launch: %s", QT, TPQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <int NT, int TPQ, bool F16>
+int launch_batch_panels(const FwdCall &c) {
+    auto kern = msim::maxsim_batch_panels_kernel<NT, TPQ, kPanels320, kLast320, F16>;
+    constexpr int lds = msim::kPanelStages * kPanels320 * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    msim::BatchArgs a;
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.flags = c.flags;
+    const int q_per_block = msim::kBatchWaves * NT / TPQ;
+    a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
+    const int cus_per_xcd = c.di->cus / 8 > 0 ? c.di->cus / 8 : 1;
+    const int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
+    a.n_ranges = 8 * sub;
+    const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
+    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_panels_kernel<%d,%d> launch: %s", NT, TPQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <bool F16>
+int panels_dispatch(const FwdCall &c) {
+    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
+    if ((long long)c.n_q * tpq <= 4) {
+        switch (c.n_q * 10 + tpq) {
+            case 11: return launch_stream_panels<1, 1, F16>(c);
+            case 21: return launch_stream_panels<2, 1, F16>(c);
+            case 31: return launch_stream_panels<3, 1, F16>(c);
+            case 41: return launch_stream_panels<4, 1, F16>(c);
+            case 12: return launch_stream_panels<2, 2, F16>(c);
+            case 22: return launch_stream_panels<4, 2, F16>(c);
+            case 13: return launch_stream_panels<3, 3, F16>(c);
+            default: return launch_stream_panels<4, 4, F16>(c);
+        }
+    }
+    if (tpq == 2) return launch_batch_panels<2, 2, F16>(c);
+    return c.n_q <= 8 ? launch_batch_panels<1, 1, F16>(c) : launch_batch_panels<2, 1, F16>(c);
+}
+
 }  // namespace
 
 extern "C" {
@@ -488,6 +561,25 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
     if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
     if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
     if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
+    {
+        const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+        if (is_panels(dtype, dim, (long long)n_q * tpq, tpq)) {
+            FwdCall c;
+            if (int rc = device_info(&c.di)) return rc;
+            c.Q = static_cast<const uint16_t *>(Q);
+            c.D = static_cast<const uint16_t *>(D);
+            c.d_off = d_off;
+            c.clamp0 = d_clamp0;
+            c.scores = scores;
+            c.ld = ld_scores;
+            c.n_q = n_q;
+            c.Lq = Lq;
+            c.n_d = n_d;
+            c.flags = flags;
+            c.st = static_cast<hipStream_t>(stream);
+            return dtype == MSIM_DTYPE_F16 ? panels_dispatch<true>(c) : panels_dispatch<false>(c);
+        }
+    }
     if (!is_tuned(dtype, dim, Lq)) {
         GenericCall c;
         if (int rc = device_info(&c.di)) return rc;

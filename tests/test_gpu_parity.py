@@ -276,3 +276,59 @@ def test_transpose_detecting_asymmetric_inputs_fp32(amd):
     got = amd.score_multi_vector([q], [d], device="cuda:0").numpy()
     want = (q.double() @ d.double().T).max(dim=1).values.sum().item()
     assert abs(got[0, 0] - want) <= 1e-5 * max(abs(want), 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Panel kernels (K1sP / K1bP): the tuned path for dim = 320 (ColQwen3), 16-bit.
+
+@pytest.mark.parametrize("dtype,n_q,lq_max,n_d,ld_max,bs", [
+    (torch.bfloat16, 1, 32, 300, 1100, 128),    # K1sP<1,1>: ragged long documents, tails of every size
+    (torch.bfloat16, 2, 20, 257, 200, 128),     # K1sP<2,1>
+    (torch.bfloat16, 3, 32, 64, 1024, 16),      # K1sP<3,1>
+    (torch.bfloat16, 4, 32, 100, 300, 7),       # K1sP<4,1>, clamp0 everywhere
+    (torch.bfloat16, 1, 64, 90, 260, 128),      # K1sP<2,2>
+    (torch.bfloat16, 2, 50, 120, 200, 128),     # K1sP<4,2>
+    (torch.bfloat16, 1, 96, 60, 200, 128),      # K1sP<3,3>
+    (torch.bfloat16, 1, 128, 40, 150, 128),     # K1sP<4,4>
+    (torch.bfloat16, 8, 32, 300, 500, 128),     # K1bP<1,1>: exactly one workgroup's queries
+    (torch.bfloat16, 5, 32, 300, 500, 5),       # K1bP<1,1>: partial
+    (torch.bfloat16, 13, 32, 300, 500, 128),    # K1bP<2,1>
+    (torch.bfloat16, 33, 32, 500, 300, 128),    # K1bP<2,1>, three query blocks, partial last block
+    (torch.bfloat16, 17, 64, 90, 260, 128),     # K1bP<2,2>
+    (torch.bfloat16, 9, 100, 40, 130, 128),     # four tiles per query, more than K1sP holds -> generic kernel
+    (torch.float16, 3, 32, 200, 700, 128),
+    (torch.float16, 40, 40, 120, 500, 128),
+])
+def test_dim320_panel_kernels_against_oracle(amd, dtype, n_q, lq_max, n_d, ld_max, bs):
+    qs, ps = _random_generic(n_q * 31 + n_d, n_q, lq_max, n_d, ld_max, 320, dtype)
+    got = amd.score_multi_vector(qs, ps, batch_size=bs, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, bs))
+
+
+def test_dim320_panel_kernels_agree_bitwise_with_each_other_and_the_generic_kernel(amd):
+    # the same MFMA chain in the same k order and the same reduction tree in K1sP (query alone), K1bP (inside a batch)
+    # and K1g (same query zero-padded to 160 tokens: five tiles, which only the generic kernel takes)
+    qs, ps = _random_generic(11, 20, 32, 200, 500, 320, torch.bfloat16)
+    dev = torch.device("cuda:0")
+    corpus = amd.pack_passages(ps, dev)
+    big = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()                      # K1bP<2,1>
+    lq = max(q.shape[0] for q in qs)
+    for i in (0, 7, 19):
+        padded = torch.cat([qs[i], qs[i].new_zeros(lq - qs[i].shape[0], 320)])
+        one = amd.maxsim_scores(amd.pack_queries([padded], dev), corpus).cpu()            # K1sP<1,1>
+        assert torch.equal(one[0], big[i])
+        long_q = torch.cat([qs[i], qs[i].new_zeros(160 - qs[i].shape[0], 320)])
+        gen = amd.maxsim_scores(amd.pack_queries([long_q], dev), corpus).cpu()            # K1g
+        assert torch.equal(gen[0], big[i])
+
+
+def test_dim320_many_documents_and_literal_rounding(amd):
+    qs, ps = _random_generic(5, 2, 32, 6000, 40, 320, torch.bfloat16)        # more documents than resident waves
+    got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    assert close(got, _oracle(qs, ps, 128))
+    qs, ps = _random_generic(6, 12, 32, 300, 400, 320, torch.bfloat16)
+    dev = torch.device("cuda:0")
+    lit = amd.maxsim_scores(amd.pack_queries(qs, dev), amd.pack_passages(ps, dev), ref_rounding=True).cpu().numpy()
+    want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], mode="bf16ref")
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-3))) - 7)
+    assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
