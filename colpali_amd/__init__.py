@@ -16,6 +16,7 @@ from . import loss
 from .embed import CorpusWriter, embedding_head
 from .loss import (ColbertLoss, ColbertModule, ColbertNegativeCELoss, ColbertPairwiseCELoss,
                    ColbertPairwiseNegativeCELoss, ColbertSigmoidLoss, maxsim, maxsim_paired)
+from .pooling import HierarchicalTokenPooler, TokenPoolingOutput
 from .patch import patch_colpali_engine, unpatch_colpali_engine
 from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
 from .scoring import (get_similarity_maps_from_embeddings, get_torch_device, maxsim_scores, score_multi_vector,
@@ -23,6 +24,8 @@ from .scoring import (get_similarity_maps_from_embeddings, get_torch_device, max
 
 __all__ = [
     "CorpusWriter",
+    "HierarchicalTokenPooler",
+    "TokenPoolingOutput",
     "embedding_head",
     "ColbertLoss",
     "ColbertModule",

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def dtype_code(dtype) -> int:
@@ -81,6 +81,10 @@ def lib() -> ctypes.CDLL:
     L.msim_embed_head.restype = i32
     L.msim_sim_matrix.argtypes = [i32, vp, i32, vp, i32, i32, vp, i64, u32, vp]
     L.msim_sim_matrix.restype = i32
+    L.msim_pool_cluster.argtypes = [i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.msim_pool_cluster.restype = i32
+    L.msim_pool_reduce.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
+    L.msim_pool_reduce.restype = i32
     L.msim_topk_workspace_bytes.argtypes = [i32, i64, i32]
     L.msim_topk_workspace_bytes.restype = sz
     L.msim_topk_f32.argtypes = [vp, vp, i32, i64, i64, i32, i64, vp, vp, vp, vp]

@@ -18,6 +18,7 @@
 #include "maxsim_panels.hip"
 #include "maxsim_smooth.hip"
 #include "embed_head.hip"
+#include "token_pooling.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -798,6 +799,61 @@ int msim_sim_matrix(int dtype, const void *A, int n_a, const void *B, int n_b, i
         case MSIM_DTYPE_F16: return sim_dispatch<msim::kDtypeF16>(ac, bc, out, a, *di, st);
         default: return sim_dispatch<msim::kDtypeBf16>(ac, bc, out, a, *di, st);
     }
+}
+
+// ---------------------------------------------------------------- hierarchical token pooling
+int msim_pool_cluster(int dtype, const void *E, const int32_t *d_off, int n_pages, int dim, int max_rows,
+                      const int64_t *ws_off, int pool_factor, float *X_ws, double *D_ws, int32_t *labels,
+                      int32_t *n_clusters, void *stream) {
+    if (n_pages < 0 || max_rows < 0) return fail(MSIM_EINVAL, "negative size");
+    if (n_pages == 0) return MSIM_OK;
+    if (!E || !d_off || !ws_off || !X_ws || !D_ws || !labels || !n_clusters) return fail(MSIM_EINVAL, "null pointer argument");
+    if (pool_factor < 1) return fail(MSIM_EINVAL, "pool_factor must be >= 1");
+    static const int32_t dummy_off[2] = {0, 0};
+    if (int rc = check_smooth(E, E, dummy_off, dtype, dim, 1, 1.0f)) return rc;      // row layout contract of the generic kernels
+    if (max_rows > msim::kPoolMaxN) return fail(MSIM_EUNSUPPORTED, "a page of %d rows: at most %d are supported", max_rows, msim::kPoolMaxN);
+    if (n_pages > 65535) return fail(MSIM_EUNSUPPORTED, "at most 65535 pages per call");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    msim::PoolArgs a{n_pages, dim, dim * elem_bytes(dtype), pool_factor};
+    const char *e = static_cast<const char *>(E);
+    if (max_rows > 0) {
+        const dim3 ggrid((max_rows + 127) / 128, (max_rows + 31) / 32, n_pages);
+        switch (dtype) {
+            case MSIM_DTYPE_F32: hipLaunchKernelGGL(msim::pool_gram_kernel<msim::kDtypeF32>, ggrid, dim3(256), 0, st, e, d_off, ws_off, X_ws, a); break;
+            case MSIM_DTYPE_F16: hipLaunchKernelGGL(msim::pool_gram_kernel<msim::kDtypeF16>, ggrid, dim3(256), 0, st, e, d_off, ws_off, X_ws, a); break;
+            default: hipLaunchKernelGGL(msim::pool_gram_kernel<msim::kDtypeBf16>, ggrid, dim3(256), 0, st, e, d_off, ws_off, X_ws, a); break;
+        }
+        const int tiles = (max_rows + 15) / 16;
+        hipLaunchKernelGGL(msim::pool_pdist_kernel, dim3(tiles, tiles, n_pages), dim3(256), 0, st, d_off, ws_off, X_ws, D_ws);
+    }
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(msim::pool_cluster_kernel, (int)sizeof(msim::PoolLds), configured)) return rc;
+    hipLaunchKernelGGL(msim::pool_cluster_kernel, dim3(n_pages), dim3(msim::kPoolThreads), sizeof(msim::PoolLds), st, d_off, ws_off, D_ws,
+                       labels, n_clusters, pool_factor);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(MSIM_ELAUNCH, "token pooling launch: %s", hipGetErrorString(err));
+    return MSIM_OK;
+}
+
+int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages, int dim, int ld_in, const int32_t *labels,
+                     const int32_t *out_off, void *out, int ld_out, void *stream) {
+    if (n_pages < 0) return fail(MSIM_EINVAL, "negative size");
+    if (n_pages == 0) return MSIM_OK;
+    if (!E || !d_off || !labels || !out_off || !out) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16 && dtype != MSIM_DTYPE_F32) return fail(MSIM_EUNSUPPORTED, "dtype code %d", dtype);
+    if (dim <= 0 || dim > 2048 || ld_in < dim || ld_out < dim) return fail(MSIM_EUNSUPPORTED, "dim=%d (ld_in=%d ld_out=%d)", dim, ld_in, ld_out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *e = static_cast<const char *>(E);
+    char *o = static_cast<char *>(out);
+    const int es = elem_bytes(dtype);
+    switch (dtype) {
+        case MSIM_DTYPE_F32: hipLaunchKernelGGL(msim::pool_reduce_kernel<msim::kDtypeF32>, dim3(n_pages), dim3(256), 0, st, e, d_off, labels, out_off, o, dim, ld_in * es, ld_out * es); break;
+        case MSIM_DTYPE_F16: hipLaunchKernelGGL(msim::pool_reduce_kernel<msim::kDtypeF16>, dim3(n_pages), dim3(256), 0, st, e, d_off, labels, out_off, o, dim, ld_in * es, ld_out * es); break;
+        default: hipLaunchKernelGGL(msim::pool_reduce_kernel<msim::kDtypeBf16>, dim3(n_pages), dim3(256), 0, st, e, d_off, labels, out_off, o, dim, ld_in * es, ld_out * es); break;
+    }
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(MSIM_ELAUNCH, "pool_reduce_kernel launch: %s", hipGetErrorString(err));
+    return MSIM_OK;
 }
 
 // ---------------------------------------------------------------- top-k selection

@@ -18,6 +18,7 @@ import importlib
 import sys
 
 from . import loss as _loss
+from .pooling import HierarchicalTokenPooler
 from .scoring import get_similarity_maps_from_embeddings, score_multi_vector, score_single_vector
 
 _LOSS_NAMES = ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss", "ColbertNegativeCELoss",
@@ -37,6 +38,12 @@ def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
         if sm is not None:   # only when the user has imported the interpretability helpers
             _saved.setdefault((sm.__name__, "get_similarity_maps_from_embeddings"), sm.get_similarity_maps_from_embeddings)
             sm.get_similarity_maps_from_embeddings = get_similarity_maps_from_embeddings
+        for name in ("colpali_engine.compression.token_pooling.hierarchical_token_pooling",
+                     "colpali_engine.compression.token_pooling", "colpali_engine.compression"):
+            mod = sys.modules.get(name)   # only when the user has imported the pooling helpers
+            if mod is not None and hasattr(mod, "HierarchicalTokenPooler"):
+                _saved.setdefault((name, "HierarchicalTokenPooler"), mod.HierarchicalTokenPooler)
+                mod.HierarchicalTokenPooler = HierarchicalTokenPooler
     if losses:
         mods = [importlib.import_module("colpali_engine.loss.late_interaction_losses")]
         pkg = sys.modules.get("colpali_engine.loss")

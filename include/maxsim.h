@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 6
+#define MSIM_ABI_VERSION 7
 
 /* error codes */
 #define MSIM_OK 0
@@ -180,6 +180,26 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H,
  */
 int msim_sim_matrix(int dtype, const void *A, int n_a, const void *B, int n_b, int dim,
                     float *out, int64_t ld_out, uint32_t flags, void *stream);
+
+/*
+ * Hierarchical token pooling (Ward clustering of a page's patch embeddings, mean-pooling every cluster):
+ * replaces colpali_engine/compression/token_pooling/hierarchical_token_pooling.py:83-146, i.e. torch.mm + SciPy's
+ * linkage(method="ward") on the rows of 1 - E E^T + fcluster(criterion="maxclust") + the per-cluster mean / normalize,
+ * which the reference runs page by page on the CPU.
+ *
+ * msim_pool_cluster: labels[r0 + i] = 0-based flat cluster of row i of page c (r0 = d_off[c]), numbered as SciPy numbers
+ *   them; n_clusters[c] = number of clusters (<= max(n_c / pool_factor, 1)).
+ *   E [rows, dim] packed pages (bf16 | f16 | f32, rows a multiple of 32 bytes), d_off int32 [n_pages + 1];
+ *   max_rows >= the longest page (<= 2048); ws_off int64 [n_pages + 1] = exclusive prefix sums of n_c * n_c (element offsets
+ *   of page c in both workspaces); X_ws fp32 and D_ws fp64 each of ws_off[n_pages] elements.
+ * msim_pool_reduce: out[out_off[c] + k, :] = normalize(mean of the rows of page c labelled k), k < out_off[c+1] - out_off[c],
+ *   in E's dtype; `dim` logical columns, ld_in / ld_out = elements between consecutive rows of E / out.
+ */
+int msim_pool_cluster(int dtype, const void *E, const int32_t *d_off, int n_pages, int dim, int max_rows,
+                      const int64_t *ws_off, int pool_factor, float *X_ws, double *D_ws,
+                      int32_t *labels, int32_t *n_clusters, void *stream);
+int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages, int dim, int ld_in,
+                     const int32_t *labels, const int32_t *out_off, void *out, int ld_out, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -68,3 +68,19 @@ def load_similarity_map_utils():
     from colpali_engine.interpretability import similarity_map_utils  # noqa: E402
 
     return similarity_map_utils
+
+
+def load_token_pooler():
+    """HierarchicalTokenPooler of the live reference (compression/token_pooling/hierarchical_token_pooling.py)."""
+    if not available():
+        raise RuntimeError(f"reference checkout not found at {REFERENCE_ROOT}")
+    load()
+    for name, sub in (("colpali_engine.compression", "compression"),
+                      ("colpali_engine.compression.token_pooling", "compression/token_pooling")):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [os.path.join(REFERENCE_ROOT, "colpali_engine", sub)]
+            sys.modules[name] = pkg
+    from colpali_engine.compression.token_pooling.hierarchical_token_pooling import HierarchicalTokenPooler  # noqa: E402
+
+    return HierarchicalTokenPooler

@@ -308,8 +308,38 @@ def sim_golden():
     save("sim_matrix.npz", **out)
 
 
+def pooling_golden():
+    """(12) HierarchicalTokenPooler (compression/token_pooling/hierarchical_token_pooling.py:83-146) of the live reference:
+    list inputs in fp32 and bf16, pool factors 2 / 3 / 4, one page with duplicated patches (exact ties).
+        python tests/golden/make_golden.py pooling"""
+    import warnings
+
+    warnings.simplefilter("ignore")
+    Pooler = refimport.load_token_pooler()
+    g = torch.Generator().manual_seed(77)
+    lens = [40, 97, 12, 2, 130]
+    embs = [F.normalize(torch.randn(n, 128, generator=g), dim=-1) for n in lens]
+    embs[1][10:30] = embs[1][5]                      # a blank region: identical patch embeddings
+    # cluster-structured page: patches are noisy copies of a few prototypes (what real pages look like)
+    proto = F.normalize(torch.randn(9, 128, generator=g), dim=-1)
+    embs.append(F.normalize(proto[torch.randint(0, 9, (150,), generator=g)] + 0.15 * torch.randn(150, 128, generator=g), dim=-1))
+    out = {"lens": np.array([e.shape[0] for e in embs], np.int32), "emb_f32": np.concatenate([e.numpy() for e in embs])}
+    for tag, conv in (("f32", lambda t: t), ("bf16", lambda t: t.to(torch.bfloat16))):
+        for pf in (2, 3, 4):
+            res = Pooler().pool_embeddings([conv(e) for e in embs], pool_factor=pf, return_dict=True)
+            for i, (pe, mp) in enumerate(zip(res.pooled_embeddings, res.cluster_id_to_indices)):
+                out[f"{tag}_pf{pf}_{i}_pooled"] = pe.float().numpy()
+                labels = np.full(embs[i].shape[0], -1, np.int32)
+                for c, idx in mp.items():
+                    labels[idx[0].numpy()] = c
+                out[f"{tag}_pf{pf}_{i}_labels"] = labels
+    save("token_pooling.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sim":
+    if len(sys.argv) > 1 and sys.argv[1] == "pooling":
+        pooling_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sim":
         sim_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "head":
         head_golden()
@@ -323,3 +353,4 @@ if __name__ == "__main__":
         sigmoid_golden()
         head_golden()
         sim_golden()
+        pooling_golden()
