@@ -105,7 +105,8 @@ class HierarchicalTokenPooler:
         return cast(List[torch.Tensor], embeddings)
 
     # ---- hierarchical_token_pooling.py:38-146
-    def _pool_embeddings_impl(self, embeddings: List[torch.Tensor], pool_factor: int, num_workers: Optional[int] = None):
+    def _pool_embeddings_impl(self, embeddings: List[torch.Tensor], pool_factor: int, num_workers: Optional[int] = None,
+                              want_maps: bool = True):
         if not (num_workers is None or num_workers >= 1):
             raise ValueError(f"Invalid number of workers: {num_workers}")
         for e in embeddings:
@@ -143,13 +144,19 @@ class HierarchicalTokenPooler:
                                     _lib.ptr(labels), _lib.ptr(out_off.to(torch.int32).to(dev)), _lib.ptr(pooled), dim,
                                     _lib.current_stream_handle(dev))
         _lib.check(rc, "msim_pool_reduce")
+        out_off_l, offs_l = out_off.tolist(), offs.tolist()
+        pooled_list = [pooled[out_off_l[i] : out_off_l[i + 1]].to(e.device) for i, e in enumerate(embeddings)]
+        if not want_maps:
+            return pooled_list, None
+        # cluster id -> token indices (ascending), including the ids that stayed empty (:124-131): one stable sort per page
         labels_host = labels.cpu()
-        pooled_list, maps = [], []
+        maps = []
         for i, e in enumerate(embeddings):
-            pooled_list.append(pooled[int(out_off[i]) : int(out_off[i + 1])].to(e.device))
-            lab = labels_host[int(offs[i]) : int(offs[i + 1])]
+            lab = labels_host[offs_l[i] : offs_l[i + 1]].to(torch.int64)
             max_clusters = max(e.size(0) // pool_factor, 1)
-            maps.append({c: cast(Tuple[torch.Tensor], torch.where(lab == c)) for c in range(max_clusters)})
+            order = torch.sort(lab, stable=True).indices
+            parts = order.split(torch.bincount(lab, minlength=max_clusters).tolist())
+            maps.append({c: (parts[c],) for c in range(max_clusters)})
         return pooled_list, maps
 
     # ---- base_token_pooling.py:106-167
@@ -159,7 +166,7 @@ class HierarchicalTokenPooler:
             return TokenPoolingOutput(pooled_embeddings=[], cluster_id_to_indices=[])
         self._validate_embeddings(embeddings)
         prepared = self._prepare_embeddings(embeddings, padding, padding_side)
-        pooled, mapping = self._pool_embeddings_impl(prepared, num_workers=num_workers, **pool_kwargs)
+        pooled, mapping = self._pool_embeddings_impl(prepared, num_workers=num_workers, want_maps=return_dict, **pool_kwargs)
         if isinstance(embeddings, torch.Tensor) and embeddings.dim() == 3:
             pooled = torch.nn.utils.rnn.pad_sequence(pooled, batch_first=True, padding_value=0.0, padding_side=padding_side)
         if not return_dict:
