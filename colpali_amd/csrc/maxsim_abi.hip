@@ -127,9 +127,9 @@ int stream_nt() {
     return v;
 }
 
-template <int QT, int TPQ, bool F16, int AUX>
+template <int QT, int TPQ, bool F16, int AUX, bool IL>
 int launch_stream_aux(const FwdCall &c) {
-    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing, F16, AUX>;
+    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing, F16, AUX, IL>;
     constexpr int lds = 4 * kStreamRing * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -148,9 +148,21 @@ int launch_stream_aux(const FwdCall &c) {
     return MSIM_OK;
 }
 
+// LDS-DMA pieces of the next slab issued between the MFMAs of the current one (default).  Interleaved A/B on a 16 GiB
+// shard (profiles/r01_logs/ab_stream_il.log): 4 queries 6.37-6.43 -> 6.52-6.55 TB/s, 6-8 queries +1 %, 1-2 queries unchanged.
+// MSIM_STREAM_IL=0 selects the block-issue variant (tuning knob, not part of the ABI).
+int stream_il() {
+    static const int v = [] {
+        const char *e = getenv("MSIM_STREAM_IL");
+        return e ? (atoi(e) != 0) : 1;
+    }();
+    return v;
+}
+
 template <int QT, int TPQ, bool F16>
 int launch_stream(const FwdCall &c) {
-    return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2>(c) : launch_stream_aux<QT, TPQ, F16, 0>(c);
+    if (stream_il() && stream_nt()) return launch_stream_aux<QT, TPQ, F16, 2, true>(c);
+    return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
 
 template <int NT, int TPQ, bool F16>

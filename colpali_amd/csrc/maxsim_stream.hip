@@ -43,7 +43,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // RING: slabs in the wave-private LDS ring
 // F16 : embeddings are IEEE half instead of bfloat16
 // AUX : cache-policy bits of the LDS-DMA loads (0 = default, 2 = nt: streamed once, do not keep in L2 / MALL)
-template <int QT, int TPQ, int RING, bool F16, int AUX = 0>
+// IL  : issue the 8 LDS-DMA pieces of the next slab BETWEEN the MFMAs of the current one instead of in a block in
+//       front of them (the matrix pipe idles while a block of DMA instructions issues; one piece per QT MFMAs hides)
+template <int QT, int TPQ, int RING, bool F16, int AUX = 0, bool IL = false>
 __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
                                                             const uint16_t *__restrict__ D,       // [rows, 128] bf16
                                                             const int32_t *__restrict__ d_off,    // [n_d + 1]
@@ -128,13 +130,39 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
         return true;
     };
 
+    // IL: every request is 8 loads, real or through an empty descriptor (out-of-range lanes fetch nothing and count like any
+    // other load), so the number of outstanding loads is a constant and the instruction stream has no branches
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D, 0, 0, 0x00020000);
+    auto advance = [&](bool live) {
+        p_slot = (p_slot + 1 == RING) ? 0 : p_slot + 1;
+        if (live) {
+            p_row += kSlabRows;
+            if (p_row >= p_len) {
+                p_idx += GW;
+                p_open();
+            }
+        }
+    };
     // prologue: RING-1 slabs in flight
+    if constexpr (IL) {
 #pragma unroll
-    for (int i = 0; i < RING - 1; ++i) produce();
+        for (int k = 0; k < RING - 1; ++k) {
+            const bool live = p_idx < a.n_d;
+            const __amdgpu_buffer_rsrc_t rs = live ? p_rsrc : null_rsrc;
+            char *dst = ring + p_slot * kSlabBytes;
+            const int soff = live ? p_row * kRowBytes : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, AUX);
+            advance(live);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) produce();
+    }
 
     const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
     int c_slot = 0;
-
     for (int c_idx = gw; c_idx < a.n_d; c_idx += GW) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nslab = (len + kSlabRows - 1) / kSlabRows;
@@ -143,12 +171,25 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
         for (int t = 0; t < QT; ++t) m[t] = -INFINITY;
 
         for (int s = 0; s < nslab; ++s) {
-            // the slot consumed in the previous iteration is free again: refill it, then wait for slab s
-            const bool issued = produce();
-            if (issued)
-                wait_vmcnt<8 * (RING - 1)>();
-            else
-                wait_vmcnt<0>();
+            // next slab to request (its slot is the one consumed in the previous iteration: free again)
+            bool nx_live = false;
+            char *nx_dst = ring;
+            int nx_soff = 0;
+            __amdgpu_buffer_rsrc_t nx_rsrc = p_rsrc;
+            if constexpr (IL) {
+                wait_vmcnt<8 * (RING - 2)>();     // RING - 1 requests are outstanding: all but the oldest may stay in flight
+                nx_live = p_idx < a.n_d;
+                nx_dst = ring + p_slot * kSlabBytes;
+                nx_soff = nx_live ? p_row * kRowBytes : 0;
+                nx_rsrc = nx_live ? p_rsrc : null_rsrc;
+            } else {
+                // the slot consumed in the previous iteration is free again: refill it, then wait for slab s
+                const bool issued = produce();
+                if (issued)
+                    wait_vmcnt<8 * (RING - 1)>();
+                else
+                    wait_vmcnt<0>();
+            }
 
             const char *src = ring + c_slot * kSlabBytes;
             bf16x8 af[kKSteps];
@@ -161,8 +202,16 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
             for (int t = 0; t < QT; ++t) {
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks)
+                for (int ks = 0; ks < kKSteps; ++ks) {
+                    if constexpr (IL) {
+                        if ((t * kKSteps + ks) % QT == 0) {                      // one DMA piece per QT MFMAs: 8 per slab
+                            const int i = (t * kKSteps + ks) / QT;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(nx_rsrc, MSIM_LDS(nx_dst + i * 1024), 16, src_off[i & 3],
+                                                                     nx_soff + i * 1024, 0, AUX);
+                        }
+                    }
                     acc = mfma32<F16>(af[ks], qf[t][ks], acc);
+                }
                 if (rows_left < kSlabRows) {  // tail slab: rows past the document end do not exist
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -170,6 +219,7 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
                 }
                 m[t] = fold_max16(m[t], acc);
             }
+            if constexpr (IL) advance(nx_live);                                  // the 8 pieces are out: advance the cursor
         }
 
         // ---- document epilogue: combine the two lane halves, clamp, sum over tokens, store
