@@ -440,11 +440,11 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
     const int tpq = (a.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int cb = (a.dim + 31) / 32;
     if (a.n_q > 0)
-        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true>), dim3(a.n_q, tpq, cb), dim3(256), 0, st, Q, D, d_off, pairs,
+        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true>), dim3(a.n_q, tpq, cb), dim3(msim::kSmoothWavesDQ * 64), 0, st, Q, D, d_off, pairs,
                            order_by_doc, g, lse, dQ, a);
     const int slabs = (max_doc_rows + 31) / 32;
     if (a.n_d > 0 && slabs > 0)
-        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false>), dim3(a.n_d, slabs, cb), dim3(256), 0, st, Q, D, d_off, pairs,
+        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false>), dim3(a.n_d, slabs, cb), dim3(msim::kSmoothWavesDD * 64), 0, st, Q, D, d_off, pairs,
                            order_by_doc, g, lse, dD, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_bwd_kernel launch: %s", hipGetErrorString(e));

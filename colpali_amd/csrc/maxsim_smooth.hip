@@ -240,8 +240,12 @@ struct SmoothBwdArgs {
     float tau;
 };
 
+// NW = waves per workgroup: 16 for dQ (few owner tiles, each with a long (pair, slab) list: more waves hide the dependent
+// global loads of the recompute), 4 for dD (thousands of owner tiles).
+constexpr int kSmoothWavesDQ = 16, kSmoothWavesDD = 4;
+
 template <int DT, bool DQ>
-__global__ __launch_bounds__(256) void maxsim_smooth_bwd_kernel(const char *__restrict__ Q, const char *__restrict__ D,
+__global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) void maxsim_smooth_bwd_kernel(const char *__restrict__ Q, const char *__restrict__ D,
                                                                 const int32_t *__restrict__ d_off,
                                                                 const int32_t *__restrict__ pairs,         // sorted by query
                                                                 const int32_t *__restrict__ order_by_doc,  // pair ids sorted by doc
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(256) void maxsim_smooth_bwd_kernel(const char *__re
                                                                 float *__restrict__ out,                   // dQ or dD
                                                                 SmoothBwdArgs a) {
     constexpr int ES = elem_size<DT>();
-    __shared__ float red[3][16][64];
+    constexpr int NW = DQ ? kSmoothWavesDQ : kSmoothWavesDD;
+    __shared__ float red[NW - 1][16][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void maxsim_smooth_bwd_kernel(const char *__re
         float lse_own = 0.0f;
         if constexpr (DQ) lse_own = lse_p[orow];        // token = owner row
         for (int ot = 0; ot < n_tiles; ++ot, ++item) {
-            if ((item & 3) != wave) continue;
+            if (item % NW != wave) continue;
             const int t0 = ot * 32;
             const int t_rows = oth_len - t0;            // >= 1
             // ---- first product: A = other rows (-> accumulator registers), B = owner rows (-> lane column)
@@ -348,9 +353,8 @@ __global__ __launch_bounds__(256) void maxsim_smooth_bwd_kernel(const char *__re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc2[r];
-            v += red[0][r][lane];
-            v += red[1][r][lane];
-            v += red[2][r][lane];
+#pragma unroll
+            for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
             const int orow_out = acc_row(r, lane);
             if (col_valid && orow_out < own_rows) {
                 const size_t base_row = DQ ? (size_t)own * a.Lq : (size_t)d_off[own];
