@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def dtype_code(dtype) -> int:
@@ -75,7 +75,9 @@ def lib() -> ctypes.CDLL:
     L.msim_smooth_fwd.restype = i32
     L.msim_smooth_pairs.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, vp, i32, f32, vp, vp, vp]
     L.msim_smooth_pairs.restype = i32
-    L.msim_smooth_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp]
+    L.msim_smooth_bwd_workspace_bytes.argtypes = [i32, i32, i32]
+    L.msim_smooth_bwd_workspace_bytes.restype = sz
+    L.msim_smooth_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp]
     L.msim_smooth_pairs_bwd.restype = i32
     L.msim_embed_head.argtypes = [i32, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp]
     L.msim_embed_head.restype = i32

@@ -435,20 +435,35 @@ int smooth_pairs(const char *Q, const char *D, const int32_t *d_off, const int32
 
 template <int DT>
 int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
-               const int32_t *order_by_doc, const float *g, const float *lse, float *dQ, float *dD,
-               const msim::SmoothBwdArgs &a, hipStream_t st) {
+               const int32_t *order_by_doc, const float *g, const float *lse, float *dQ, float *dD, float *workspace,
+               msim::SmoothBwdArgs a, int n_split, hipStream_t st) {
     const int tpq = (a.Lq + msim::kTokTile - 1) / msim::kTokTile;
-    const int cb = (a.dim + 31) / 32;
-    if (a.n_q > 0)
-        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true>), dim3(a.n_q, tpq, cb), dim3(msim::kSmoothWavesDQ * 64), 0, st, Q, D, d_off, pairs,
-                           order_by_doc, g, lse, dQ, a);
+    const int cg = (a.dim + 32 * msim::kSmoothCB - 1) / (32 * msim::kSmoothCB);
+    if (a.n_q > 0) {
+        a.n_split = n_split;
+        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true>), dim3(a.n_q * n_split, tpq, cg), dim3(msim::kSmoothWavesDQ * 64), 0,
+                           st, Q, D, d_off, pairs, order_by_doc, g, lse, n_split > 1 ? workspace : dQ, a);
+        if (n_split > 1) {
+            const long long n = (long long)a.n_q * a.Lq * a.dim;
+            hipLaunchKernelGGL(msim::smooth_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, workspace, dQ, n, n_split);
+        }
+    }
     const int slabs = (max_doc_rows + 31) / 32;
-    if (a.n_d > 0 && slabs > 0)
-        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false>), dim3(a.n_d, slabs, cb), dim3(msim::kSmoothWavesDD * 64), 0, st, Q, D, d_off, pairs,
-                           order_by_doc, g, lse, dD, a);
+    if (a.n_d > 0 && slabs > 0) {
+        a.n_split = 1;
+        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false>), dim3(a.n_d, slabs, cg), dim3(msim::kSmoothWavesDD * 64), 0, st, Q,
+                           D, d_off, pairs, order_by_doc, g, lse, dD, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_bwd_kernel launch: %s", hipGetErrorString(e));
     return MSIM_OK;
+}
+
+// number of workgroups that share one owner tile's pair list in the dQ pass (enough to fill the chip twice)
+int smooth_dq_split(int n_q, int Lq, const DeviceInfo &di) {
+    const int tiles = n_q * ((Lq + msim::kTokTile - 1) / msim::kTokTile);
+    int s = (2 * di.cus + tiles - 1) / (tiles > 0 ? tiles : 1);
+    return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
 // ---------------------------------------------------------------- plain similarity matrix
@@ -735,22 +750,36 @@ int msim_smooth_pairs(int dtype, const void *Q, int n_q, int Lq, const void *D, 
     }
 }
 
+size_t msim_smooth_bwd_workspace_bytes(int n_q, int Lq, int dim) {
+    const DeviceInfo *di = nullptr;
+    if (n_q <= 0 || Lq <= 0 || dim <= 0 || device_info(&di)) return 0;
+    const int ns = smooth_dq_split(n_q, Lq, *di);
+    return ns > 1 ? (size_t)ns * n_q * Lq * dim * sizeof(float) : 0;
+}
+
 int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
                           int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g, const float *lse,
-                          int n_pairs, float tau, float *dQ, float *dD, void *stream) {
+                          int n_pairs, float tau, float *dQ, float *dD, void *workspace, void *stream) {
     if (n_q < 0 || n_d < 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
     if (!dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
     if (n_pairs > 0 && (!pairs || !order_by_doc || !g || !lse)) return fail(MSIM_EINVAL, "null pair-list argument");
     if (int rc = check_smooth(Q, D, d_off, dtype, dim, Lq, tau)) return rc;
     if ((max_doc_rows + 31) / 32 > 65535) return fail(MSIM_EUNSUPPORTED, "max_doc_rows=%d too large", max_doc_rows);
     if ((Lq + 31) / 32 > 65535) return fail(MSIM_EUNSUPPORTED, "Lq=%d too large", Lq);
-    msim::SmoothBwdArgs a{n_q, Lq, n_d, n_pairs, dim * elem_bytes(dtype), dim, tau};
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    const int ns = smooth_dq_split(n_q, Lq, *di);
+    if (ns > 1 && !workspace) return fail(MSIM_EINVAL, "workspace required (msim_smooth_bwd_workspace_bytes)");
+    if ((reinterpret_cast<uintptr_t>(dQ) | reinterpret_cast<uintptr_t>(dD) | reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return fail(MSIM_EINVAL, "dQ, dD and the workspace must be 16-byte aligned");
+    msim::SmoothBwdArgs a{n_q, Lq, n_d, n_pairs, dim * elem_bytes(dtype), dim, tau, 1};
     const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
+    float *ws = static_cast<float *>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (dtype) {
-        case MSIM_DTYPE_F32: return smooth_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
-        case MSIM_DTYPE_F16: return smooth_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
-        default: return smooth_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, a, st);
+        case MSIM_DTYPE_F32: return smooth_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, ws, a, ns, st);
+        case MSIM_DTYPE_F16: return smooth_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, ws, a, ns, st);
+        default: return smooth_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, lse, dQ, dD, ws, a, ns, st);
     }
 }
 

@@ -234,42 +234,64 @@ __global__ __launch_bounds__(256) void maxsim_smooth_pairs_kernel(const char *__
 //   out[o,:] += sum_t W[o, t] * X_other[t, :]                   second MFMA (fp32, 32x32x2), 32 output columns per workgroup
 // Workgroup = (owner tile, 32-column block); its 4 waves split the (pair, other tile) work list and are reduced in
 // wave order through LDS.
+// round a FINITE fp32 value to the 16-bit dtype and back, without the NaN branch of bf16_round
+template <int DT>
+__device__ __forceinline__ float round_finite(float x) {
+    if constexpr (DT == kDtypeF16) return (float)(_Float16)x;
+    else {
+        uint32_t u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return __uint_as_float(u & 0xffff0000u);
+    }
+}
+
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+template <int ES> struct BVec;
+template <> struct BVec<4> { typedef i32x4 type; };
+template <> struct BVec<2> { typedef i32x2 type; };
+
 struct SmoothBwdArgs {
     int n_q, Lq, n_d, n_pairs;
     int row_bytes, dim;     // dim = elements per row
     float tau;
+    int n_split;            // dQ: workgroups sharing one owner tile's pair list (partials reduced by smooth_reduce_kernel)
 };
 
-// NW = waves per workgroup: 16 for dQ (few owner tiles, each with a long (pair, slab) list: more waves hide the dependent
-// global loads of the recompute), 4 for dD (thousands of owner tiles).
-constexpr int kSmoothWavesDQ = 16, kSmoothWavesDD = 4;
+// NW = waves per workgroup: 8 for dQ (few owner tiles with long (pair, slab) lists), 4 for dD (thousands of owner tiles).
+constexpr int kSmoothWavesDQ = 8, kSmoothWavesDD = 4;
+constexpr int kSmoothCB = 4;                            // 32-column blocks per workgroup: the weights are computed once per 128 columns
 
+// One workgroup = (owner tile, group of 128 output columns[, slice of the pair list]).  Lane l31 owns the 4 CONSECUTIVE
+// columns 128*g + 4*l31 + {0,1,2,3} (column block cb of the second product = column 4*l31 + cb): one 8- or 16-byte load
+// per other-row fetches its 4 operands, one 16-byte store per row writes its 4 results.
 template <int DT, bool DQ>
-__global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) void maxsim_smooth_bwd_kernel(const char *__restrict__ Q, const char *__restrict__ D,
-                                                                const int32_t *__restrict__ d_off,
-                                                                const int32_t *__restrict__ pairs,         // sorted by query
-                                                                const int32_t *__restrict__ order_by_doc,  // pair ids sorted by doc
-                                                                const float *__restrict__ g,               // [n_pairs]
-                                                                const float *__restrict__ lse,             // [n_pairs, Lq]
-                                                                float *__restrict__ out,                   // dQ or dD
-                                                                SmoothBwdArgs a) {
+__global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) void maxsim_smooth_bwd_kernel(
+    const char *__restrict__ Q, const char *__restrict__ D, const int32_t *__restrict__ d_off,
+    const int32_t *__restrict__ pairs,         // sorted by query
+    const int32_t *__restrict__ order_by_doc,  // pair ids sorted by doc
+    const float *__restrict__ g,               // [n_pairs]
+    const float *__restrict__ lse,             // [n_pairs, Lq]
+    float *__restrict__ out,                   // dQ / dD, or the partial buffers [n_split][rows][dim] when n_split > 1
+    SmoothBwdArgs a) {
     constexpr int ES = elem_size<DT>();
     constexpr int NW = DQ ? kSmoothWavesDQ : kSmoothWavesDD;
-    __shared__ float red[NW - 1][16][64];
+    __shared__ float red[NW - 1][kSmoothCB][16][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int half_off = half * 16;
     const int n_steps = a.row_bytes >> 5;
     const int row_bytes = a.row_bytes;
-    const int col = blockIdx.z * 32 + l31;              // output column of this lane (second MFMA: B column, C column)
-    const bool col_valid = col < a.dim;
+    const int col0 = blockIdx.z * (32 * kSmoothCB) + 4 * l31;      // first of this lane's 4 columns (dim % 4 == 0)
+    const bool col_valid = col0 < a.dim;
+    const int col_c = col_valid ? col0 : 0;
     const float inv_tau = 1.0f / a.tau;
 
-    // ---- owner tile
-    const int own = blockIdx.x;                         // query index (DQ) or document index (DD)
+    // ---- owner tile (and, for dQ, the slice of its pair list)
+    const int own = DQ ? blockIdx.x / a.n_split : blockIdx.x;      // query index (DQ) or document index (DD)
+    const int split = DQ ? blockIdx.x % a.n_split : 0;
     const int own_tile = blockIdx.y;                    // token tile (DQ) or 32-row slab (DD)
-    int own_rows, own_len;                              // rows in the owner entity / valid rows of this tile
+    int own_rows, own_len;
     const char *own_base;
     if constexpr (DQ) {
         own_len = a.Lq;
@@ -283,7 +305,6 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
     const int orow = own_tile * 32 + (l31 < own_rows ? l31 : own_rows - 1);
     const char *own_frag = own_base + (size_t)orow * row_bytes + half_off;
 
-    // ---- this owner's pair range
     int p_lo, p_hi;
     if constexpr (DQ) {
         p_lo = lower_bound_idx(a.n_pairs, own, [&](int k) { return pairs[2 * k]; });
@@ -294,9 +315,11 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
         p_hi = lower_bound_idx(a.n_pairs, own + 1, doc_of);
     }
 
-    f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int item = 0;                                       // running index over (pair, other tile): wave w takes item % 4 == w
-    for (int k = p_lo; k < p_hi; ++k) {
+    f32x16 acc2[kSmoothCB];
+#pragma unroll
+    for (int cb = 0; cb < kSmoothCB; ++cb) acc2[cb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int item = 0;                                       // running index over (pair, other tile): wave w takes item % NW == w
+    for (int k = p_lo + split; k < p_hi; k += (DQ ? a.n_split : 1)) {
         const int p = DQ ? k : order_by_doc[k];
         const int oth = DQ ? pairs[2 * p + 1] : pairs[2 * p];      // the other entity: document (DQ) or query (DD)
         const float gp = g[p];
@@ -317,6 +340,16 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
             if (item % NW != wave) continue;
             const int t0 = ot * 32;
             const int t_rows = oth_len - t0;            // >= 1
+            // ---- the other operand of the second product first: 16 unconditional loads (4 columns each) from clamped,
+            // always valid addresses and NO select on them (the weight of a row that does not exist is exactly 0, a column
+            // beyond dim is never stored; a select would let the compiler sink each load under its own branch)
+            typedef typename BVec<ES>::type bvec_t;     // 4 consecutive elements of a row: 16 B (fp32) or 8 B (16-bit)
+            bvec_t bld[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tr = acc_row(r, lane);
+                bld[r] = *reinterpret_cast<const bvec_t *>(oth_base + ((size_t)(t0 + (tr < t_rows ? tr : 0)) * a.dim + col_c) * ES);
+            }
             // ---- first product: A = other rows (-> accumulator registers), B = owner rows (-> lane column)
             const int trow = t0 + (l31 < t_rows ? l31 : t_rows - 1);
             const char *oth_frag = oth_base + (size_t)trow * row_bytes + half_off;
@@ -327,41 +360,100 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
                 const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(own_frag + j * 32);
                 s = mfma_step<DT>(av, bv, s);
             }
-            // ---- weights (zero for rows that do not exist on either side) and the second product
+            // ---- weights (zero for rows that do not exist on either side)
+            float w[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int tr = acc_row(r, lane);                      // other row inside the tile held by this register
+                const int tr = acc_row(r, lane);
                 const bool valid = tr < t_rows && l31 < own_rows;
                 float ls = lse_own;
                 if constexpr (!DQ) ls = lse_p[t0 + (tr < t_rows ? tr : 0)];   // token = other row
-                const float w = valid ? gp * expf(s[r] * inv_tau - ls) : 0.0f;
-                // B operand: X_other[t0 + row(r, half)][col]; the contraction index of this MFMA is k = half
-                float b = 0.0f;
-                if (col_valid && tr < t_rows) b = load_elem<DT>(oth_base + ((size_t)(t0 + tr) * a.dim + col) * ES);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, acc2, 0, 0, 0);
+                w[r] = valid ? gp * expf(s[r] * inv_tau - ls) : 0.0f;
+            }
+            // ---- second product
+            if constexpr (DT == kDtypeF32) {
+                // fp32 embeddings: exact-fp32 MFMA, one k pair (rows row(r, 0), row(r, 1)) per instruction
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int cb = 0; cb < kSmoothCB; ++cb) {
+                        const int bits = bld[r][cb];   // copy the element first: bit_cast applied to a vector-element lvalue reads element 0
+                        acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], __int_as_float(bits), acc2[cb], 0, 0, 0);
+                    }
+            } else {
+                // 16-bit embeddings: the 16-bit MFMA (16x the fp32 rate).  The weights are split into a 16-bit head and a 16-bit
+                // remainder (two MFMAs per k-step) so that they keep ~16 bits of mantissa; the other operand is the embedding
+                // itself, exact.  Accumulator registers 0..7 / 8..15 of the first product are exactly the k-slices of k-step
+                // 0 / 1 of the second one: element e of the slice <-> other row row(8*kk + e, half).
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 ah, al;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float hi = round_finite<DT>(w[8 * kk + e]);          // w is finite: branch-free rounding
+                        const float lo = round_finite<DT>(w[8 * kk + e] - hi);
+                        if constexpr (DT == kDtypeF16) {
+                            ah[e] = __builtin_bit_cast(short, (_Float16)hi);
+                            al[e] = __builtin_bit_cast(short, (_Float16)lo);
+                        } else {
+                            ah[e] = (short)(__float_as_uint(hi) >> 16);
+                            al[e] = (short)(__float_as_uint(lo) >> 16);
+                        }
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < kSmoothCB; ++cb) {
+                        bf16x8 bo;                                                 // column 4*l31 + cb of the 8 rows of this k-slice
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bo[e] = (short)((uint32_t)bld[8 * kk + e][cb >> 1] >> ((cb & 1) * 16));
+                        acc2[cb] = mfma32<DT == kDtypeF16>(ah, bo, acc2[cb]);
+                        acc2[cb] = mfma32<DT == kDtypeF16>(al, bo, acc2[cb]);
+                    }
+                }
             }
         }
     }
 
-    // ---- fixed-order reduction over the 4 waves, then store: acc2[reg] of lane (col, half) = out[row(reg, half)][col]
+    // ---- fixed-order reduction over the waves, then store: acc2[cb][reg] of lane (l31, half) = out[row(reg, half)][col0 + cb]
     if (wave > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc2[r];
+        for (int cb = 0; cb < kSmoothCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][cb][r][lane] = acc2[cb][r];
     }
     __syncthreads();
     if (wave == 0) {
+        const size_t rows_total = DQ ? (size_t)a.n_q * a.Lq : (size_t)d_off[a.n_d];
+        float *dst = out + (size_t)split * rows_total * a.dim;       // n_split == 1: the gradient itself
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = acc2[r];
+            f32x4 v;
 #pragma unroll
-            for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
+            for (int cb = 0; cb < kSmoothCB; ++cb) {
+                float x = acc2[cb][r];
+#pragma unroll
+                for (int w2 = 0; w2 < NW - 1; ++w2) x += red[w2][cb][r][lane];
+                v[cb] = x;
+            }
             const int orow_out = acc_row(r, lane);
             if (col_valid && orow_out < own_rows) {
                 const size_t base_row = DQ ? (size_t)own * a.Lq : (size_t)d_off[own];
-                out[(base_row + own_tile * 32 + orow_out) * a.dim + col] = v;
+                *reinterpret_cast<f32x4 *>(dst + (base_row + own_tile * 32 + orow_out) * a.dim + col0) = v;
             }
         }
     }
+}
+
+// out[i] = sum_{s < n_split} partial[s][i] in split order (the deterministic second pass of the dQ pair-list split)
+__global__ __launch_bounds__(256) void smooth_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out, long long n,
+                                                            int n_split) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(partial + i);
+    for (int s2 = 1; s2 < n_split; ++s2) {
+        const f32x4 u = *reinterpret_cast<const f32x4 *>(partial + (size_t)s2 * n + i);
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    *reinterpret_cast<f32x4 *>(out + i) = v;
 }
 
 }  // namespace msim

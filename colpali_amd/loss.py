@@ -187,9 +187,11 @@ def _smooth_backward(qc, dc, offsets, pairs, gp, tau):
     order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
     _, lse = smooth_pairs(qc, dc, offsets, pairs, tau, want_scores=False)
     with torch.cuda.device(dev):
+        ws_bytes = L.msim_smooth_bwd_workspace_bytes(B, Lq, dim)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
         rc = L.msim_smooth_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
                                      _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(lse), n_pairs, tau,
-                                     _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+                                     _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws), _lib.current_stream_handle(dev))
     _lib.check(rc, "msim_smooth_pairs_bwd")
     return dq, dd
 

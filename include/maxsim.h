@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 7
+#define MSIM_ABI_VERSION 8
 
 /* error codes */
 #define MSIM_OK 0
@@ -136,6 +136,8 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
  *     dQ[q, i, :]       = sum_{p: q_p = q} g[p] * sum_j w[p,i,j] * D[d_off[c_p] + j, :]
  *     dD[d_off[c]+j, :] = sum_{p: c_p = c} g[p] * sum_i w[p,i,j] * Q[q_p, i, :]
  * Same conventions as msim_pairs_bwd (pairs sorted by query, order_by_doc, full overwrite, deterministic, no atomics).
+ * The dQ pass splits a query's pair list over several workgroups and sums their partial results in a fixed order: it
+ * needs msim_smooth_bwd_workspace_bytes(n_q, Lq, dim) bytes of scratch (16-byte aligned; 0 = none needed).
  */
 int msim_smooth_fwd(int dtype, const void *Q, int n_q, int Lq,
                     const void *D, const int32_t *d_off, int n_d, int dim, float tau,
@@ -144,11 +146,12 @@ int msim_smooth_pairs(int dtype, const void *Q, int n_q, int Lq,
                       const void *D, const int32_t *d_off, int n_d, int dim,
                       const int32_t *pairs, int n_pairs, float tau,
                       float *out_scores, float *out_lse, void *stream);
+size_t msim_smooth_bwd_workspace_bytes(int n_q, int Lq, int dim);
 int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
                           const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
                           const int32_t *pairs, const int32_t *order_by_doc,
                           const float *g, const float *lse, int n_pairs, float tau,
-                          float *dQ, float *dD, void *stream);
+                          float *dQ, float *dD, void *workspace, void *stream);
 
 /*
  * Embedding head: the last three lines of every Col* model forward, producing the scorer's corpus format.
