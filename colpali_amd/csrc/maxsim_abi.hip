@@ -15,10 +15,12 @@
 #include "maxsim_batch.hip"
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
+#include "maxsim_bwd.hip"
 #include "maxsim_panels.hip"
 #include "maxsim_smooth.hip"
 #include "embed_head.hip"
 #include "token_pooling.hip"
+#include "probe_stream.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -271,12 +273,15 @@ template <bool F16>
 void launch_pairs_bwd(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
                       const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
                       const msim::PairsArgs &a, hipStream_t st) {
-    if (a.n_q > 0)
-        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dq_kernel<F16>, dim3(a.n_q), dim3(256), 0, st, D, d_off, pairs, g, argmax, dQ, a);
+    constexpr int DT = F16 ? msim::kDtypeF16 : msim::kDtypeBf16;
+    const char *q = reinterpret_cast<const char *>(Q), *d = reinterpret_cast<const char *>(D);
+    if (a.n_q > 0 && a.Lq > 0)
+        hipLaunchKernelGGL(msim::maxsim_bwd_dq_kernel<DT>, dim3((a.n_q * a.Lq + 3) / 4), dim3(256), 0, st, d, d_off, pairs, g, argmax,
+                           dQ, a, msim::kDim * 2);
     const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
     if (a.n_d > 0 && ry > 0)
-        hipLaunchKernelGGL(msim::maxsim_pairs_bwd_dd_kernel<F16>, dim3(a.n_d, ry), dim3(256), 0, st, Q, d_off, pairs,
-                           order_by_doc, g, argmax, dD, a);
+        hipLaunchKernelGGL(msim::maxsim_bwd_dd_kernel<DT>, dim3(a.n_d, ry, 1), dim3(256), 0, st, q, d_off, pairs, order_by_doc, g,
+                           argmax, dD, a, msim::kDim);
 }
 
 // ---------------------------------------------------------------- generic kernels (K1g)
@@ -358,13 +363,13 @@ template <int DT>
 void generic_pairs_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
                        const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
                        const msim::PairsArgs &a, int dim, hipStream_t st) {
-    if (a.n_q > 0)
-        hipLaunchKernelGGL(msim::maxsim_generic_bwd_dq_kernel<DT>, dim3(a.n_q), dim3(256), 0, st, D, d_off, pairs, g, argmax, dQ, a,
-                           dim);
+    if (a.n_q > 0 && a.Lq > 0)
+        hipLaunchKernelGGL(msim::maxsim_bwd_dq_kernel<DT>, dim3((a.n_q * a.Lq + 3) / 4), dim3(256), 0, st, D, d_off, pairs, g, argmax,
+                           dQ, a, dim * msim::elem_size<DT>());
     const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
     if (a.n_d > 0 && ry > 0)
-        hipLaunchKernelGGL(msim::maxsim_generic_bwd_dd_kernel<DT>, dim3(a.n_d, ry, (dim + 127) / 128), dim3(256), 0, st, Q, d_off,
-                           pairs, order_by_doc, g, argmax, dD, a, dim);
+        hipLaunchKernelGGL(msim::maxsim_bwd_dd_kernel<DT>, dim3(a.n_d, ry, (dim + 127) / 128), dim3(256), 0, st, Q, d_off, pairs,
+                           order_by_doc, g, argmax, dD, a, dim);
 }
 
 // ---------------------------------------------------------------- smooth-max (tau * logsumexp) kernels
@@ -813,7 +818,19 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         return MSIM_OK;
     };
     static std::atomic<int> configured[2][kMaxDevices];
-    const int rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true>, configured[0]) : go(msim::embed_head_kernel<false>, configured[1]);
+    static const int exp_mode = getenv("MSIM_HEAD_EXP") ? atoi(getenv("MSIM_HEAD_EXP")) : 0;   // TEMPORARY
+    static std::atomic<int> cfgx[8][kMaxDevices];
+    int rc;
+    switch (exp_mode) {
+        case 1: rc = go(msim::embed_head_kernel<false, 1>, cfgx[1]); break;
+        case 2: rc = go(msim::embed_head_kernel<false, 2>, cfgx[2]); break;
+        case 3: rc = go(msim::embed_head_kernel<false, 3>, cfgx[3]); break;
+        case 4: rc = go(msim::embed_head_kernel<false, 4>, cfgx[4]); break;
+        case 5: rc = go(msim::embed_head_kernel<false, 5>, cfgx[5]); break;
+        case 6: rc = go(msim::embed_head_kernel<false, 6>, cfgx[6]); break;
+        case 7: rc = go(msim::embed_head_kernel<false, 7>, cfgx[7]); break;
+        default: rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true>, configured[0]) : go(msim::embed_head_kernel<false>, configured[1]);
+    }
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));
@@ -895,6 +912,21 @@ int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(MSIM_ELAUNCH, "pool_reduce_kernel launch: %s", hipGetErrorString(err));
     return MSIM_OK;
+}
+
+int msim_debug_probe(int variant, const void *X, int64_t M, int H, float *sink, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *x = static_cast<const char *>(X);
+    switch (variant) {
+        case 0: return run_probe<128, 32, 4, 8>(x, M, H, sink, st);   // today's K3 pattern: 256 rows/WG, 128-B pieces, 4-deep
+        case 1: return run_probe<256, 32, 2, 8>(x, M, H, sink, st);   // 256-B pieces, 2-deep
+        case 2: return run_probe<512, 16, 2, 8>(x, M, H, sink, st);   // 16 rows per wave, 512-B pieces, 2-deep (128 rows/WG)
+        case 3: return run_probe<256, 16, 4, 8>(x, M, H, sink, st);   // 16 rows per wave, 256-B pieces, 4-deep
+        case 4: return run_probe<1024, 16, 1, 8>(x, M, H, sink, st);  // (no prefetch) 1-KiB pieces
+        case 5: return run_probe<512, 32, 2, 4>(x, M, H, sink, st);   // 4 waves x 32 rows, 512-B pieces, 2-deep
+        case 6: return run_probe<128, 16, 8, 8>(x, M, H, sink, st);   // 16 rows per wave, 128-B pieces, 8-deep
+        default: return -1;
+    }
 }
 
 // ---------------------------------------------------------------- top-k selection

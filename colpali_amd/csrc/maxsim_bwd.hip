@@ -1,0 +1,216 @@
+// Hard-max MaxSim backward for gfx950: what autograd derives for
+//   colpali_engine/loss/late_interaction_losses.py:297-298 (+ :91)   einsum("bnd,csd->bcns").amax(3).sum(2)
+// with an upstream gradient g[p] per (query, document) pair and the arg-max patch of every (pair, query token):
+//   dQ[b, i, :]      = sum over the pairs p of query b      of  g[p] * D[c_p, argmax[p, i], :]
+//   dD[c, s, :]      = sum over the pairs p of document c,
+//                      tokens i with argmax[p, i] == s      of  g[p] * Q[b_p, i, :]
+// Both are gathers of a few hundred KiB ... MiB: latency-bound, not bandwidth-bound.  The kernels are therefore built
+// around loads in flight (independent gather chains, no per-element branches) and a deterministic summation order
+// (no float atomics): dQ sums each query's pairs in pair-list order per lane group and folds the groups in a fixed
+// tree; dD walks each document's (pair, token) entries in list order.
+//
+// Any width (rows a multiple of 32 bytes, up to 4 KiB) and dtype (DT: 0 bf16, 1 fp16, 2 fp32).
+#pragma once
+#include "maxsim_common.hpp"
+#include "maxsim_pairs.hip"
+#include "maxsim_generic.hip"
+
+namespace msim {
+
+// first index k in [0, n) with key(k) >= v (key non-decreasing), searched by the whole wave: 64 probes per round,
+// so 8192 pairs take 3 rounds of one load each instead of 13 dependent loads
+template <class KeyFn>
+__device__ __forceinline__ int lower_bound_wave(int n, int v, int lane, KeyFn key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + lane * step;
+        const bool below = idx < hi && key(idx) < v;
+        const int cnt = __popcll(__ballot(below));          // probes 0 .. cnt-1 are below v, probe cnt (if any) is not
+        if (cnt == 0) break;
+        const int nhi = lo + cnt * step;
+        lo = lo + (cnt - 1) * step + 1;
+        hi = nhi < hi ? nhi : hi;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
+template <int DT>
+__device__ __forceinline__ void piece_to_floats(const uint4 v, float *f) {
+    if constexpr (DT == kDtypeF32) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = elem_to_float<DT == kDtypeF16>((uint16_t)(w[k] & 0xffffu));
+            f[2 * k + 1] = elem_to_float<DT == kDtypeF16>((uint16_t)(w[k] >> 16));
+        }
+    }
+}
+
+// ---- dQ: one wave per (query, token).  A row is split into 16-byte pieces, one per lane; when a row needs fewer than
+// 64 lanes the wave works on 64 / lanes-per-row pairs at once, and four such groups are unrolled, so 4 .. 128
+// independent (argmax -> offset -> row) gather chains are in flight per wave.  `pairs` sorted by query index.
+template <int DT>
+__global__ __launch_bounds__(256) void maxsim_bwd_dq_kernel(const char *__restrict__ D, const int32_t *__restrict__ d_off,
+                                                            const int32_t *__restrict__ pairs, const float *__restrict__ g,
+                                                            const int32_t *__restrict__ argmax, float *__restrict__ dQ,
+                                                            PairsArgs a, int row_bytes) {
+    constexpr int ES = elem_size<DT>();
+    constexpr int EPP = 16 / ES;                         // elements per 16-byte piece
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tok = blockIdx.x * 4 + wave;               // flattened (query, token)
+    if (tok >= a.n_q * a.Lq) return;
+    const int b = tok / a.Lq, i = tok - b * a.Lq;
+    const int s = lower_bound_wave(a.n_pairs, b, lane, [&](int k) { return pairs[2 * k]; });
+    const int e = lower_bound_wave(a.n_pairs, b + 1, lane, [&](int k) { return pairs[2 * k]; });
+    const int pieces = row_bytes >> 4;
+    int pp_log = 1;
+    while ((1 << pp_log) < pieces && pp_log < 6) ++pp_log;
+    const int pp = 1 << pp_log;                          // lanes per pair
+    const int G = 64 >> pp_log;                          // pairs per wave-step
+    const int sub = lane >> pp_log, pc = lane & (pp - 1);
+    float *out = dQ + (size_t)tok * (row_bytes / ES);
+    for (int c0 = 0; c0 < pieces; c0 += 64) {            // more than one round only for rows wider than 1 KiB
+        const int piece = c0 + pc;
+        const bool col_ok = piece < pieces;
+        const int boff = (col_ok ? piece : 0) << 4;
+        float acc[EPP];
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) acc[k] = 0.0f;
+        for (int p0 = s; p0 < e; p0 += 4 * G) {
+            int pj[4], arg[4], doc[4], off[4];
+            float w[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + j * G + sub;
+                ok[j] = p < e;
+                pj[j] = ok[j] ? p : e - 1;                                   // clamped: every load is a valid address
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                arg[j] = argmax[(size_t)pj[j] * a.Lq + i];
+                doc[j] = pairs[2 * pj[j] + 1];
+                w[j] = g[pj[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[j] = d_off[doc[j]];
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool use = ok[j] && arg[j] >= 0;                        // arg < 0: the zero padding row won the max
+                w[j] = use ? w[j] : 0.0f;                                     // the weight is selected, never the loaded row
+                const int row = off[j] + (arg[j] >= 0 ? arg[j] : 0);
+                v[j] = *reinterpret_cast<const uint4 *>(D + (size_t)row * row_bytes + boff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f[EPP];
+                piece_to_floats<DT>(v[j], f);
+#pragma unroll
+                for (int k = 0; k < EPP; ++k) acc[k] += w[j] * f[k];
+            }
+        }
+        for (int m = pp; m < 64; m <<= 1)
+#pragma unroll
+            for (int k = 0; k < EPP; ++k) acc[k] += __shfl_xor(acc[k], m);
+        if (sub == 0 && col_ok) {
+            float *o = out + piece * EPP;
+#pragma unroll
+            for (int k = 0; k < EPP; k += 4) *reinterpret_cast<float4 *>(o + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+        }
+    }
+}
+
+// ---- dD: one workgroup per (document, 64-row range, 128-column chunk).  The document's (pair, token) entries are read
+// 256 at a time with coalesced, independent loads; the ones that land in this row range are compacted (ballot +
+// prefix, list order kept) into an LDS hit list; then every thread adds the hits of its rows to the LDS tile
+// (thread t owns column t & 127 of the rows with parity t >> 7; four hits' query values are in flight at a time;
+// hits of the other parity go to a dummy row instead of a branch).  `order_by_doc` lists pair indices sorted by document.
+template <int DT>
+__global__ __launch_bounds__(256) void maxsim_bwd_dd_kernel(const char *__restrict__ Q, const int32_t *__restrict__ d_off,
+                                                            const int32_t *__restrict__ pairs,
+                                                            const int32_t *__restrict__ order_by_doc, const float *__restrict__ g,
+                                                            const int32_t *__restrict__ argmax, float *__restrict__ dD,
+                                                            PairsArgs a, int dim) {
+    constexpr int ES = elem_size<DT>();
+    __shared__ float tile[kBwdRows + 2][128];            // + one dummy row per parity
+    __shared__ int hit_r[256 + 4], hit_q[256 + 4];
+    __shared__ float hit_g[256 + 4];
+    __shared__ int wave_cnt[4];
+    const int c = blockIdx.x;
+    const int r_lo = blockIdx.y * kBwdRows;
+    const int len = d_off[c + 1] - d_off[c];
+    if (r_lo >= len) return;
+    const int rows = (len - r_lo < kBwdRows) ? (len - r_lo) : kBwdRows;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lc = t & 127, half = t >> 7;
+    const int col = blockIdx.z * 128 + lc;
+    const bool col_ok = col < dim;
+    const int col_c = col_ok ? col : 0;
+    for (int r = half; r < kBwdRows + 2; r += 2) tile[r][lc] = 0.0f;
+    auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
+    const int s = lower_bound_wave(a.n_pairs, c, lane, doc_of);
+    const int e = lower_bound_wave(a.n_pairs, c + 1, lane, doc_of);
+    const int n_ent = (e - s) * a.Lq;
+    for (int base = 0; base < n_ent; base += 256) {
+        const int idx = base + t;
+        bool hit = false;
+        int r = 0, qrow = 0;
+        float gp = 0.0f;
+        if (idx < n_ent) {
+            const int k = idx / a.Lq, i = idx - k * a.Lq;
+            const int p = order_by_doc[s + k];
+            r = argmax[(size_t)p * a.Lq + i] - r_lo;
+            hit = r >= 0 && r < rows;
+            qrow = pairs[2 * p] * a.Lq + i;
+            gp = g[p];
+        }
+        const unsigned long long m = __ballot(hit);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int cnt = wave_cnt[w];
+            woff += w < wave ? cnt : 0;
+            total += cnt;
+        }
+        if (hit) {
+            hit_r[woff + before] = r;
+            hit_q[woff + before] = qrow;
+            hit_g[woff + before] = gp;
+        }
+        if (t < 4) {                                      // pad to a multiple of four: dummy hits (row -1, weight 0)
+            hit_r[total + t] = -1;
+            hit_q[total + t] = 0;
+            hit_g[total + t] = 0.0f;
+        }
+        __syncthreads();
+        for (int h = 0; h < total; h += 4) {
+            int rr[4];
+            float qv[4], gg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rj = hit_r[h + j];
+                const bool mine = rj >= 0 && (rj & 1) == half;
+                rr[j] = mine ? rj : kBwdRows + half;
+                gg[j] = hit_g[h + j];
+                qv[j] = load_elem<DT>(Q + ((size_t)hit_q[h + j] * dim + col_c) * ES);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[rr[j]][lc] += gg[j] * qv[j];
+        }
+        __syncthreads();
+    }
+    // every row of the tile is owned by one half: no barrier needed between accumulate and write-out
+    if (col_ok) {
+        float *out = dD + ((size_t)d_off[c] + r_lo) * dim;
+        for (int r = half; r < rows; r += 2) out[(size_t)r * dim + col] = tile[r][lc];
+    }
+}
+
+}  // namespace msim

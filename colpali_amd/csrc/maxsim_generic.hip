@@ -273,72 +273,6 @@ __global__ __launch_bounds__(256) void maxsim_generic_pairs_argmax_kernel(const 
     }
 }
 
-// dQ[b, i, :] = sum over this query's pairs of g * D[c, argmax, :]  (generic width / dtype).
-// One workgroup per query, one wave per token (strided), lanes stride over the columns.  `dim` = elements per row.
-template <int DT>
-__global__ __launch_bounds__(256) void maxsim_generic_bwd_dq_kernel(const char *__restrict__ D,
-                                                                    const int32_t *__restrict__ d_off,
-                                                                    const int32_t *__restrict__ pairs,
-                                                                    const float *__restrict__ g,
-                                                                    const int32_t *__restrict__ argmax,
-                                                                    float *__restrict__ dQ, PairsArgs a, int dim) {
-    constexpr int ES = elem_size<DT>();
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = lower_bound_idx(a.n_pairs, b, [&](int k) { return pairs[2 * k]; });
-    const int e = lower_bound_idx(a.n_pairs, b + 1, [&](int k) { return pairs[2 * k]; });
-    for (int i = wave; i < a.Lq; i += 4) {
-        for (int col = lane; col < dim; col += 64) {
-            float acc = 0.0f;
-            for (int p = s; p < e; ++p) {
-                const int arg = argmax[(size_t)p * a.Lq + i];
-                if (arg < 0) continue;
-                const int c = pairs[2 * p + 1];
-                acc += g[p] * load_elem<DT>(D + (((size_t)d_off[c] + arg) * dim + col) * ES);
-            }
-            dQ[((size_t)b * a.Lq + i) * dim + col] = acc;
-        }
-    }
-}
-
-// dD rows of document c: one workgroup per (document, 64-row range, 128-column chunk); same ownership scheme as
-// maxsim_pairs_bwd_dd_kernel (thread t owns column col0 + (t & 127) of the rows with parity t >> 7).
-template <int DT>
-__global__ __launch_bounds__(256) void maxsim_generic_bwd_dd_kernel(const char *__restrict__ Q,
-                                                                    const int32_t *__restrict__ d_off,
-                                                                    const int32_t *__restrict__ pairs,
-                                                                    const int32_t *__restrict__ order_by_doc,
-                                                                    const float *__restrict__ g,
-                                                                    const int32_t *__restrict__ argmax,
-                                                                    float *__restrict__ dD, PairsArgs a, int dim) {
-    constexpr int ES = elem_size<DT>();
-    __shared__ float tile[kBwdRows][128];
-    const int c = blockIdx.x;
-    const int r_lo = blockIdx.y * kBwdRows;
-    const int len = d_off[c + 1] - d_off[c];
-    if (r_lo >= len) return;
-    const int rows = (len - r_lo < kBwdRows) ? (len - r_lo) : kBwdRows;
-    const int t = threadIdx.x, lc = t & 127, half = t >> 7;
-    const int col = blockIdx.z * 128 + lc;
-    if (col >= dim) return;
-    for (int r = half; r < kBwdRows; r += 2) tile[r][lc] = 0.0f;
-    auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
-    const int s = lower_bound_idx(a.n_pairs, c, doc_of);
-    const int e = lower_bound_idx(a.n_pairs, c + 1, doc_of);
-    for (int k = s; k < e; ++k) {
-        const int p = order_by_doc[k];
-        const int b = pairs[2 * p];
-        const float gp = g[p];
-        for (int i = 0; i < a.Lq; ++i) {
-            const int r = argmax[(size_t)p * a.Lq + i] - r_lo;
-            if (r < 0 || r >= rows || (r & 1) != half) continue;
-            tile[r][lc] += gp * load_elem<DT>(Q + (((size_t)b * a.Lq + i) * dim + col) * ES);
-        }
-    }
-    float *out = dD + ((size_t)d_off[c] + r_lo) * dim;
-    for (int r = half; r < rows; r += 2) out[(size_t)r * dim + col] = tile[r][lc];
-}
-
 }  // namespace msim
 
 namespace msim {

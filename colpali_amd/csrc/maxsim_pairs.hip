@@ -158,71 +158,6 @@ __device__ __forceinline__ int lower_bound_idx(int n, int v, KeyFn key) {
     return lo;
 }
 
-// dQ[b, i, :] = sum over this query's pairs of g * D[c, argmax, :].  One workgroup per query, one wave per
-// token (strided); lane owns dims 2*lane, 2*lane+1.  `pairs` sorted by query index.
-template <bool F16>
-__global__ __launch_bounds__(256) void maxsim_pairs_bwd_dq_kernel(const uint16_t *__restrict__ D,
-                                                                  const int32_t *__restrict__ d_off,
-                                                                  const int32_t *__restrict__ pairs,
-                                                                  const float *__restrict__ g,
-                                                                  const int32_t *__restrict__ argmax,
-                                                                  float *__restrict__ dQ, PairsArgs a) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = lower_bound_idx(a.n_pairs, b, [&](int k) { return pairs[2 * k]; });
-    const int e = lower_bound_idx(a.n_pairs, b + 1, [&](int k) { return pairs[2 * k]; });
-    for (int i = wave; i < a.Lq; i += 4) {
-        float acc0 = 0.0f, acc1 = 0.0f;
-        for (int p = s; p < e; ++p) {
-            const int arg = argmax[(size_t)p * a.Lq + i];
-            if (arg < 0) continue;
-            const int c = pairs[2 * p + 1];
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(D + ((size_t)d_off[c] + arg) * kDim + 2 * lane);
-            const float gp = g[p];
-            acc0 += gp * elem_to_float<F16>((uint16_t)(w & 0xffffu));
-            acc1 += gp * elem_to_float<F16>((uint16_t)(w >> 16));
-        }
-        *reinterpret_cast<float2 *>(dQ + ((size_t)b * a.Lq + i) * kDim + 2 * lane) = make_float2(acc0, acc1);
-    }
-}
-
-// dD[rows of document c, :]: one workgroup per (document, 64-row range).  The tile is accumulated in LDS;
-// thread t owns column (t & 127) of the rows with parity (t >> 7), and walks this document's
-// (pair, token) entries in a fixed order.  `order_by_doc` lists pair indices sorted by document.
-constexpr int kBwdRows = 64;
-template <bool F16>
-__global__ __launch_bounds__(256) void maxsim_pairs_bwd_dd_kernel(const uint16_t *__restrict__ Q,
-                                                                  const int32_t *__restrict__ d_off,
-                                                                  const int32_t *__restrict__ pairs,
-                                                                  const int32_t *__restrict__ order_by_doc,
-                                                                  const float *__restrict__ g,
-                                                                  const int32_t *__restrict__ argmax,
-                                                                  float *__restrict__ dD, PairsArgs a) {
-    __shared__ float tile[kBwdRows][kDim];
-    const int c = blockIdx.x;
-    const int r_lo = blockIdx.y * kBwdRows;
-    const int len = d_off[c + 1] - d_off[c];
-    if (r_lo >= len) return;
-    const int rows = (len - r_lo < kBwdRows) ? (len - r_lo) : kBwdRows;
-    const int t = threadIdx.x, dim = t & (kDim - 1), half = t >> 7;
-    for (int r = half; r < kBwdRows; r += 2) tile[r][dim] = 0.0f;
-    auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
-    const int s = lower_bound_idx(a.n_pairs, c, doc_of);
-    const int e = lower_bound_idx(a.n_pairs, c + 1, doc_of);
-    for (int k = s; k < e; ++k) {
-        const int p = order_by_doc[k];
-        const int b = pairs[2 * p];
-        const float gp = g[p];
-        for (int i = 0; i < a.Lq; ++i) {
-            const int r = argmax[(size_t)p * a.Lq + i] - r_lo;
-            if (r < 0 || r >= rows || (r & 1) != half) continue;
-            const uint16_t qv = Q[((size_t)b * a.Lq + i) * kDim + dim];
-            tile[r][dim] += gp * elem_to_float<F16>(qv);
-        }
-    }
-    // every row of the tile is owned by one half: no barrier needed between accumulate and write-out
-    float *out = dD + ((size_t)d_off[c] + r_lo) * kDim;
-    for (int r = half; r < rows; r += 2) out[(size_t)r * kDim + dim] = tile[r][dim];
-}
+constexpr int kBwdRows = 64;   // document rows per backward tile (maxsim_bwd.hip)
 
 }  // namespace msim

@@ -1,0 +1,56 @@
+// TEMPORARY measurement aid (not part of the product): how fast can a CU-filling grid stream a row-major [M, H] bf16
+// matrix in K pieces of PIECE bytes per row, W waves per workgroup, each wave owning ROWS rows with a DEPTH-deep private ring?
+#pragma once
+#include "maxsim_common.hpp"
+#include "maxsim_stream.hip"
+namespace msim {
+template <int PIECE, int ROWS, int DEPTH, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void probe_stream_kernel(const char *__restrict__ X, long long M, int H, float *__restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLAB = ROWS * PIECE;
+    constexpr int NI = SLAB / 1024;
+    constexpr int LPR = PIECE / 16;                  // lanes per row piece
+    constexpr int RPI = 64 / LPR;                    // rows per instruction
+    constexpr int TILE = WAVES * ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wave * (DEPTH * SLAB);
+    const int row_bytes = H * 2;
+    const int n_chunks = row_bytes / PIECE;
+    const int n_tiles = (int)(M / TILE);
+    const int src = (wave * ROWS + lane / LPR) * row_bytes + (lane % LPR) * 16;
+    int p_tile = blockIdx.x, p_chunk = 0, p_slot = 0;
+    float acc = 0.f;
+    int c_slot = 0;
+    const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total = my_tiles * n_chunks;
+    for (int it = 0; it < total + DEPTH - 1; ++it) {
+        const bool issue = it < total;
+        if (issue) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)p_tile * TILE * row_bytes), 0, TILE * row_bytes, 0x00020000);
+            char *dst = ring + p_slot * SLAB;
+            const int soff = p_chunk * PIECE;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MSIM_LDS(dst + i * 1024), 16, src, soff + i * RPI * row_bytes, 0, 2);
+            p_slot = p_slot + 1 == DEPTH ? 0 : p_slot + 1;
+            if (++p_chunk == n_chunks) { p_chunk = 0; p_tile += gridDim.x; }
+        }
+        if (it >= DEPTH - 1) {
+            if (issue) wait_vmcnt<NI * (DEPTH - 1)>(); else wait_vmcnt<0>();
+            acc += *reinterpret_cast<float *>(ring + c_slot * SLAB + lane * 16);
+            c_slot = c_slot + 1 == DEPTH ? 0 : c_slot + 1;
+        }
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace msim
+template <int PIECE, int ROWS, int DEPTH, int WAVES>
+int run_probe(const char *X, long long M, int H, float *sink, hipStream_t st) {
+    auto kern = msim::probe_stream_kernel<PIECE, ROWS, DEPTH, WAVES>;
+    constexpr int lds = WAVES * DEPTH * ROWS * PIECE;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds, st, X, M, H, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+

@@ -1,0 +1,3 @@
+#!/bin/bash
+python -m pytest tests/test_gpu_loss.py tests/test_gpu_fuzz.py tests/test_gpu_abi.py -x -q -m gpu 2>&1 | tail -5
+python tools/ab_loss.py 2>&1 | grep -v amdgpu
