@@ -271,6 +271,29 @@ def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg):
     return roof
 
 
+def stream_ceiling(amd, corpus):
+    """The machine's own ceiling for K1s' document stream: the same LDS-DMA loads of the same resident shard with no MFMA, no
+    max/sum and no output (msim_probe_stream, include/maxsim.h).  GB/s of the shard bytes; HIP events on the launch stream."""
+    L = amd._lib.lib()
+    rows = int(corpus.blob.shape[0]) // 256 * 256
+    sink = torch.zeros(4, dtype=torch.float32, device=corpus.blob.device)
+    st = torch.cuda.current_stream()
+    ms = []
+    for i in range(7):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        rc = L.msim_probe_stream(0, corpus.blob.data_ptr(), rows, 128, sink.data_ptr(), st.cuda_stream)
+        b.record(st)
+        torch.cuda.synchronize()
+        if rc != 0:
+            raise RuntimeError(f"msim_probe_stream failed: {L.msim_last_error().decode()}")
+        if i >= 2:
+            ms.append(a.elapsed_time(b))
+    t = sorted(ms)[len(ms) // 2]
+    return {"gbs": rows * 256 / t / 1e6, "ms": t, "what": "msim_probe_stream(MSIM_PROBE_ROWS256B) over the same shard: "
+            "K1s' loads without its arithmetic"}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -326,6 +349,12 @@ def main():
         },
         "roofline": regime_numbers(args.nq, args.q_len, args.docs, args.doc_len, kern_avg),
     }
+    if corpus.blob.shape[1] == 128:
+        ceil_ = stream_ceiling(amd, corpus)
+        out["roofline"]["stream_ceiling_gbs"] = ceil_["gbs"]
+        out["roofline"]["stream_ceiling_what"] = ceil_["what"]
+        if out["roofline"]["bound"] == "hbm":
+            out["roofline"]["frac_of_stream_ceiling"] = out["roofline"]["achieved"] / ceil_["gbs"]
     if rank == 0 and not args.no_parity:
         out["parity_max_rel_err_vs_oracle_sample"] = parity_sample(q, corpus, scores)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -62,7 +62,7 @@ struct HeadArgs {
 
 // row_map[m] (int32, ceil(M / 256) * 256 entries):  v >= 0: write the normalised row to out row v;
 //   v == -1: drop the row;  v <= -2: write a row of zeros to out row (-2 - v)   (a masked position kept in place).
-template <bool F16, int EXP = 0>
+template <bool F16>
 __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
@@ -103,12 +103,12 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             const int soff = (c % n_chunks) * (kHeadBK * 2);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if constexpr (!(EXP & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, MSIM_LDS(dst + i * 1024), 16, w_src[i], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, MSIM_LDS(dst + i * 1024), 16, w_src[i], soff, 0, 0);
         };
         if (total > 0) load_w(0);
         for (int c = 0; c < total; ++c) {
             wait_vmcnt<0>();                 // W chunk c has landed
-            if constexpr (!(EXP & 1)) __builtin_amdgcn_s_barrier();    // consumers may read it; they are done with chunk c - 1, whose slot is free again
+            __builtin_amdgcn_s_barrier();    // consumers may read it; they are done with chunk c - 1, whose slot is free again
             if (c + 1 < total) load_w(c + 1);
         }
         return;
@@ -174,11 +174,10 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             // the slot consumed in the previous iteration is private to this wave and free again: refill it, then wait for
             // this chunk's 4 loads (the rows are this wave's own -- no barrier is involved in the A stream at all)
             if (produce()) wait_vmcnt<4 * (kHeadRingA - 1)>(); else wait_vmcnt<0>();
-            if constexpr (!(EXP & 1)) __builtin_amdgcn_s_barrier();   // W chunk landed (loader wave); everyone finished reading the previous W chunk
+            __builtin_amdgcn_s_barrier();   // W chunk landed (loader wave); everyone finished reading the previous W chunk
             const char *sa = smem + c_slot * kHeadABytes;
             const char *sw = smem + (c_count & 1) * kHeadWBytes;
             c_slot = (c_slot + 1 == kHeadRingA) ? 0 : c_slot + 1;
-            if constexpr (EXP & 4) { if (lane == 0) acc[0][0] += *reinterpret_cast<const float *>(sa + a_rd[0]) + *reinterpret_cast<const float *>(sw + b_rd[0]); } else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + a_rd[ks]);

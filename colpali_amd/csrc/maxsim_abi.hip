@@ -818,19 +818,7 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         return MSIM_OK;
     };
     static std::atomic<int> configured[2][kMaxDevices];
-    static const int exp_mode = getenv("MSIM_HEAD_EXP") ? atoi(getenv("MSIM_HEAD_EXP")) : 0;   // TEMPORARY
-    static std::atomic<int> cfgx[8][kMaxDevices];
-    int rc;
-    switch (exp_mode) {
-        case 1: rc = go(msim::embed_head_kernel<false, 1>, cfgx[1]); break;
-        case 2: rc = go(msim::embed_head_kernel<false, 2>, cfgx[2]); break;
-        case 3: rc = go(msim::embed_head_kernel<false, 3>, cfgx[3]); break;
-        case 4: rc = go(msim::embed_head_kernel<false, 4>, cfgx[4]); break;
-        case 5: rc = go(msim::embed_head_kernel<false, 5>, cfgx[5]); break;
-        case 6: rc = go(msim::embed_head_kernel<false, 6>, cfgx[6]); break;
-        case 7: rc = go(msim::embed_head_kernel<false, 7>, cfgx[7]); break;
-        default: rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true>, configured[0]) : go(msim::embed_head_kernel<false>, configured[1]);
-    }
+    const int rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true>, configured[0]) : go(msim::embed_head_kernel<false>, configured[1]);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));
@@ -914,19 +902,31 @@ int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages
     return MSIM_OK;
 }
 
-int msim_debug_probe(int variant, const void *X, int64_t M, int H, float *sink, void *stream) {
+int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, float *sink, void *stream) {
+    if (!X || !sink) return fail(MSIM_EINVAL, "null pointer argument");
+    if (rows <= 0 || row_elems <= 0) return fail(MSIM_EINVAL, "bad size (rows=%lld row_elems=%d)", (long long)rows, row_elems);
+    if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *x = static_cast<const char *>(X);
+    const int row_bytes = row_elems * 2;
+    int piece = 0, tile_rows = 256;
     switch (variant) {
-        case 0: return run_probe<128, 32, 4, 8>(x, M, H, sink, st);   // today's K3 pattern: 256 rows/WG, 128-B pieces, 4-deep
-        case 1: return run_probe<256, 32, 2, 8>(x, M, H, sink, st);   // 256-B pieces, 2-deep
-        case 2: return run_probe<512, 16, 2, 8>(x, M, H, sink, st);   // 16 rows per wave, 512-B pieces, 2-deep (128 rows/WG)
-        case 3: return run_probe<256, 16, 4, 8>(x, M, H, sink, st);   // 16 rows per wave, 256-B pieces, 4-deep
-        case 4: return run_probe<1024, 16, 1, 8>(x, M, H, sink, st);  // (no prefetch) 1-KiB pieces
-        case 5: return run_probe<512, 32, 2, 4>(x, M, H, sink, st);   // 4 waves x 32 rows, 512-B pieces, 2-deep
-        case 6: return run_probe<128, 16, 8, 8>(x, M, H, sink, st);   // 16 rows per wave, 128-B pieces, 8-deep
-        default: return -1;
+        case MSIM_PROBE_ROWS256B: piece = 256; tile_rows = 128; break;
+        case MSIM_PROBE_PIECES128B: piece = 128; break;
+        case MSIM_PROBE_PIECES512B: piece = 512; tile_rows = 128; break;
+        default: return fail(MSIM_EINVAL, "unknown probe variant %d", variant);
     }
+    if (row_bytes % piece != 0 || rows % tile_rows != 0)
+        return fail(MSIM_EUNSUPPORTED, "probe variant %d needs rows %% %d == 0 and a row of a multiple of %d bytes", variant, tile_rows, piece);
+    if (rows * (int64_t)row_bytes / tile_rows > 0x7fffffff) return fail(MSIM_EUNSUPPORTED, "matrix too large for the probe");
+    int rc;
+    switch (variant) {
+        case MSIM_PROBE_ROWS256B: rc = run_probe<256, 32, 4, 4>(x, rows, row_elems, sink, st); break;     // K1s: 4 waves, 4 slabs of 8 KiB each
+        case MSIM_PROBE_PIECES128B: rc = run_probe<128, 32, 4, 8>(x, rows, row_elems, sink, st); break;   // K3's hidden-state stream
+        default: rc = run_probe<512, 16, 2, 8>(x, rows, row_elems, sink, st); break;
+    }
+    if (rc) return fail(MSIM_ELAUNCH, "probe_stream_kernel launch failed (variant %d)", variant);
+    return MSIM_OK;
 }
 
 // ---------------------------------------------------------------- top-k selection

@@ -1,5 +1,9 @@
-// TEMPORARY measurement aid (not part of the product): how fast can a CU-filling grid stream a row-major [M, H] bf16
-// matrix in K pieces of PIECE bytes per row, W waves per workgroup, each wave owning ROWS rows with a DEPTH-deep private ring?
+// Measurement aid behind msim_probe_stream (include/maxsim.h): the streaming ceiling of THIS machine for the access
+// patterns the kernels use.  A CU-filling persistent grid pulls a row-major [M, H] 16-bit matrix through LDS with the same
+// LDS-DMA instruction, cache policy (nt) and ring discipline as K1s / K3 -- PIECE bytes of ROWS rows per wave and ring
+// slot, DEPTH slots, WAVES waves per workgroup -- and does nothing else (one ds_read per slot keeps the data dependency).
+// bench.py reports it next to the 8 TB/s spec figure: the gap between a kernel and this number is what the kernel's
+// own work costs; the gap between this number and the spec is the machine's.
 #pragma once
 #include "maxsim_common.hpp"
 #include "maxsim_stream.hip"
@@ -49,7 +53,7 @@ template <int PIECE, int ROWS, int DEPTH, int WAVES>
 int run_probe(const char *X, long long M, int H, float *sink, hipStream_t st) {
     auto kern = msim::probe_stream_kernel<PIECE, ROWS, DEPTH, WAVES>;
     constexpr int lds = WAVES * DEPTH * ROWS * PIECE;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
     hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), lds, st, X, M, H, sink);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

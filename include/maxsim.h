@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 8
+#define MSIM_ABI_VERSION 9
 
 /* error codes */
 #define MSIM_OK 0
@@ -203,6 +203,23 @@ int msim_pool_cluster(int dtype, const void *E, const int32_t *d_off, int n_page
                       int32_t *labels, int32_t *n_clusters, void *stream);
 int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages, int dim, int ld_in,
                      const int32_t *labels, const int32_t *out_off, void *out, int ld_out, void *stream);
+
+/*
+ * Measurement aid (no reference counterpart): the streaming ceiling of this machine for the access patterns
+ * of the kernels above.  Pulls the row-major 16-bit matrix X [rows, row_elems] through LDS once with the kernels'
+ * own LDS-DMA instruction, cache policy and ring discipline and does nothing else; the caller times the launch
+ * (bench.py reports bytes / time next to the 8 TB/s spec figure).
+ *   MSIM_PROBE_ROWS256B    256-byte pieces of 32 rows per wave and ring slot; with row_elems = 128 these are whole
+ *                          rows, i.e. msim_fwd's document stream
+ *   MSIM_PROBE_PIECES128B  128-byte pieces of 32 rows per wave                   (msim_embed_head's hidden states)
+ *   MSIM_PROBE_PIECES512B  512-byte pieces of 16 rows per wave                   (the best pattern found for wide rows)
+ * rows must be a multiple of 256 and the row a multiple of the piece; sink = 4 bytes of device memory (never
+ * written in practice: it only keeps the loads alive).
+ */
+#define MSIM_PROBE_ROWS256B 0
+#define MSIM_PROBE_PIECES128B 1
+#define MSIM_PROBE_PIECES512B 2
+int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, float *sink, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

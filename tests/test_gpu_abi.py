@@ -104,3 +104,22 @@ def test_every_other_entry_point_is_graph_capturable(amd):
     torch.cuda.synchronize()
     for got, want in zip(captured, eager):
         assert torch.equal(got, want)
+
+
+def test_probe_stream_runs_and_validates_arguments(amd):
+    """msim_probe_stream (measurement aid): every variant launches on a conforming matrix; bad shapes are refused."""
+    L = amd._lib.lib()
+    dev = torch.device("cuda:0")
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    x128 = torch.randn((4096, 128), device=dev).to(torch.bfloat16)
+    x2k = torch.randn((1024, 2048), device=dev).to(torch.bfloat16)
+    assert L.msim_probe_stream(0, x128.data_ptr(), 4096, 128, sink.data_ptr(), st) == 0
+    assert L.msim_probe_stream(1, x2k.data_ptr(), 1024, 2048, sink.data_ptr(), st) == 0
+    assert L.msim_probe_stream(2, x2k.data_ptr(), 1024, 2048, sink.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert float(sink.abs().sum()) == 0.0
+    assert L.msim_probe_stream(0, x128.data_ptr(), 4000, 128, sink.data_ptr(), st) != 0      # rows % 256
+    assert L.msim_probe_stream(2, x128.data_ptr(), 4096, 128, sink.data_ptr(), st) != 0      # row shorter than a piece
+    assert L.msim_probe_stream(7, x128.data_ptr(), 4096, 128, sink.data_ptr(), st) != 0
+    assert L.msim_probe_stream(0, None, 4096, 128, sink.data_ptr(), st) != 0
