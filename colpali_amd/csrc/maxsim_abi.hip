@@ -167,9 +167,9 @@ int launch_stream(const FwdCall &c) {
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
 
-template <int NT, int TPQ, bool F16>
+template <int TPQ, bool F16>
 int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<NT, TPQ, F16>;
+    auto kern = msim::maxsim_batch_kernel<TPQ, F16>;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, msim::kBatchLds, configured)) return rc;
     msim::BatchArgs a;
@@ -178,7 +178,7 @@ int launch_batch(const FwdCall &c) {
     a.Lq = c.Lq;
     a.n_d = c.n_d;
     a.flags = c.flags;
-    const int q_per_block = msim::kBatchWaves * NT / TPQ;
+    const int q_per_block = msim::kBatchWaves * (4 / TPQ);          // at most; the kernel splits n_q evenly over the blocks
     a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
     const int cus_per_xcd = c.di->cus / 8 > 0 ? c.di->cus / 8 : 1;
@@ -187,7 +187,7 @@ int launch_batch(const FwdCall &c) {
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
     hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), msim::kBatchLds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", NT, TPQ, hipGetErrorString(e));
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
     return MSIM_OK;
 }
 
@@ -208,16 +208,10 @@ int fwd_dispatch(const FwdCall &c) {
     const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int n_q = c.n_q;
     if (n_q * tpq > stream_max_tiles()) {
-        if (tpq == 1) {
-            const int nt = (n_q + 7) / 8;
-            if (nt <= 1) return launch_batch<1, 1, F16>(c);
-            if (nt == 2) return launch_batch<2, 1, F16>(c);
-            if (nt == 3) return launch_batch<3, 1, F16>(c);
-            return launch_batch<4, 1, F16>(c);
-        }
-        if (tpq == 2) return n_q <= 8 ? launch_batch<2, 2, F16>(c) : launch_batch<4, 2, F16>(c);
-        if (tpq == 3) return launch_batch<3, 3, F16>(c);
-        return launch_batch<4, 4, F16>(c);
+        if (tpq == 1) return launch_batch<1, F16>(c);
+        if (tpq == 2) return launch_batch<2, F16>(c);
+        if (tpq == 3) return launch_batch<3, F16>(c);
+        return launch_batch<4, F16>(c);
     }
     switch (n_q * 10 + tpq) {
         case 11: return launch_stream<1, 1, F16>(c);

@@ -4,9 +4,12 @@
 //  colpali_engine/loss/late_interaction_losses.py:297-298), different blocking.
 //
 // Structure
-//   * workgroup = 8 waves (2 per SIMD); every wave keeps NT <= 4 query token tiles (32 tokens x 128
+//   * workgroup = 8 waves (2 per SIMD); every wave keeps up to 4 query token tiles (32 tokens x 128
 //     each) in registers as MFMA B operands -> a workgroup scores a block of up to 32 token tiles
-//     (32 queries of <= 32 tokens) against its document range;
+//     (32 queries of <= 32 tokens) against its document range.  The queries are split EVENLY over the
+//     query blocks and dealt to the waves of a block round-robin (query j of the block -> wave j % 8), and
+//     a wave runs the loop body compiled for the number of tiles it actually holds: 12 queries cost
+//     3 tiles per SIMD, not 4, and 40 queries cost two blocks of 20 (5 per SIMD), not 32 + 8;
 //   * documents are streamed in chunks of 4 slabs (128 patches, 32 KiB) into a 3-deep LDS ring
 //     shared by the 8 waves: each wave issues 4 of the chunk's 32 LDS-DMA wave-instructions
 //     (buffer_load_dwordx4 ... lds, per-document bounds-checked descriptor, XOR-swizzled source);
@@ -35,7 +38,7 @@ constexpr int kBatchLds = kBatchRing * kChunkBytes;      // 96 KiB
 struct BatchArgs {
     long long ld;        // leading dimension of scores
     int n_q, Lq, n_d;
-    int n_qblocks;       // query blocks (of 8 * NT / TPQ queries)
+    int n_qblocks;       // query blocks: block b holds n_q / n_qblocks (+1 for the first n_q % n_qblocks) queries, <= 8 * (4 / TPQ)
     int n_ranges;        // document ranges (multiple of 8: XCD x owns ranges x*sub .. x*sub+sub-1)
     unsigned flags;
 };
@@ -50,9 +53,9 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
     return lo;
 }
 
-// NT : token tiles (32 tokens) per wave, 1..4.  TPQ: token tiles per query (NT % TPQ == 0): a wave holds
-// NT/TPQ whole queries, a workgroup 8*NT/TPQ.
-template <int NT, int TPQ, bool F16>
+// TPQ: token tiles (32 tokens) per query, 1..4.  A wave holds whole queries: up to 4 / TPQ of them (NTMAX = TPQ * (4 / TPQ)
+// token tiles); how many it really holds is a run-time, wave-uniform number that selects the compiled loop body.
+template <int TPQ, bool F16>
 __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
@@ -75,16 +78,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
                                                 : lower_bound_doc(d_off, a.n_d, (total_rows * (range + 1)) / a.n_ranges);
     if (d_lo >= d_hi) return;
 
-    // ---- this wave's 4 token tiles
-    static_assert(NT >= 1 && NT <= 4 && NT % TPQ == 0, "a wave holds whole queries");
-    constexpr int q_per_wave = NT / TPQ;
-    const int q_first = (qblock * kBatchWaves + wave) * q_per_wave;   // first query of this wave
-    bf16x8 qf[NT][kKSteps];
+    // ---- this wave's queries: block-local query j lives in wave j % 8
+    static_assert(TPQ >= 1 && TPQ <= 4, "a wave holds whole queries of at most 4 token tiles");
+    constexpr int QPW = 4 / TPQ;                           // queries per wave at most
+    constexpr int NTMAX = QPW * TPQ;
+    const int q_base = a.n_q / a.n_qblocks, q_extra = a.n_q % a.n_qblocks;
+    const int qb0 = qblock * q_base + (qblock < q_extra ? qblock : q_extra);   // first query of this block
+    const int qb_n = q_base + (qblock < q_extra ? 1 : 0);                       // queries in this block (<= 8 * QPW)
+    const int my_q = wave < qb_n ? (qb_n - 1 - wave) / kBatchWaves + 1 : 0;     // queries of this wave (wave-uniform)
+    bf16x8 qf[NTMAX][kKSteps];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int q = q_first + t / TPQ;
+    for (int t = 0; t < NTMAX; ++t) {
+        const int q = qb0 + wave + kBatchWaves * (t / TPQ);
         const int row = (t % TPQ) * kTokTile + (lane & 31);
-        const bool valid = q < a.n_q && row < a.Lq;
+        const bool valid = t / TPQ < my_q && row < a.Lq;
         const uint16_t *p = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
 #pragma unroll
         for (int ks = 0; ks < kKSteps; ++ks) {
@@ -94,10 +101,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
     }
     wait_vmcnt<0>();
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTMAX; ++t)
 #pragma unroll
         for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
-    const bool wave_has_queries = q_first < a.n_q;
 
     // ---- per-lane address constants (same slab image as K1s)
     const int l16 = lane & 15, l4 = lane >> 4;
@@ -151,16 +157,21 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
     const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
     int c_slot = 0;
 
+    // the walk over [d_lo, d_hi) for a wave that holds NT token tiles (NT = 0: it only feeds the ring and keeps the barriers)
+    auto run = [&](auto nt_c) {
+    constexpr int NT = decltype(nt_c)::value;
+    constexpr bool wave_has_queries = NT > 0;
+    constexpr int NTA = NT > 0 ? NT : 1;                   // array extents (no zero-length arrays)
     for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nchunk = (len + kChunkRows - 1) / kChunkRows;
-        float m[NT];
+        float m[NTA];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) m[t] = -INFINITY;
+        for (int t = 0; t < NTA; ++t) m[t] = -INFINITY;
         // Tiles are processed in two passes per slab (A = tiles 0..NA-1, B = the rest); the 16 -> 1 max fold of a
         // pass is deferred so that its v_max3 run underneath the NEXT pass's MFMAs instead of stalling the matrix
         // pipe: `pend` holds the accumulators of the last pass of the previous slab (all -inf = nothing pending).
-        constexpr int NA = NT < 2 ? NT : 2, NB = NT - NA, NP = NB > 0 ? NB : NA;
+        constexpr int NA = NTA < 2 ? NTA : 2, NB = NTA - NA, NP = NB > 0 ? NB : NA;
         f32x16 pend[NP];
 #pragma unroll
         for (int t = 0; t < NP; ++t)
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
             const int cbuf = c_slot * kChunkBytes;
             c_slot = (c_slot + 1 == kBatchRing) ? 0 : c_slot + 1;
             const int rows_in_chunk = len - ch * kChunkRows;   // >= 1
-            if (wave_has_queries) {
+            if constexpr (wave_has_queries) {
                 const int n_full = rows_in_chunk >= kChunkRows ? kChunkSlabs : rows_in_chunk / kSlabRows;
 #pragma unroll 1
                 for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
@@ -248,15 +259,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
         for (int t = 0; t < NP; ++t) m[(NB > 0 ? NA : 0) + t] = fold_max16(m[(NB > 0 ? NA : 0) + t], pend[t]);
 
         // ---- document epilogue (per wave, its own queries)
-        if (wave_has_queries) {
+        if constexpr (wave_has_queries) {
             bool clamp = false;
             if (clamp0 != nullptr) {
                 const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
                 clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
             }
-            float tile_sum[NT];
+            float tile_sum[NTA];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NTA; ++t) {
                 float v = fmaxf(m[t], __shfl_xor(m[t], 32));
                 if (clamp) v = fmaxf(v, 0.0f);
                 if (ref_bf16) v = round_to_input<F16>(v);
@@ -264,15 +275,24 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
             }
             if (lane == 0) {
 #pragma unroll
-                for (int qq = 0; qq < q_per_wave; ++qq) {
+                for (int qq = 0; qq < NTA / TPQ; ++qq) {
                     float tot = 0.0f;
 #pragma unroll
                     for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[qq * TPQ + tt];
                     if (ref_bf16) tot = round_to_input<F16>(tot);
-                    if (q_first + qq < a.n_q) scores[(size_t)(q_first + qq) * a.ld + c_idx] = tot;
+                    scores[(size_t)(qb0 + wave + kBatchWaves * qq) * a.ld + c_idx] = tot;
                 }
             }
         }
+    }
+    };   // run
+
+    switch (my_q) {                                        // wave-uniform; every body executes the same barriers
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, TPQ>{}); break;
+        case 2: if constexpr (QPW >= 2) run(std::integral_constant<int, 2 * TPQ>{}); break;
+        case 3: if constexpr (QPW >= 3) run(std::integral_constant<int, 3 * TPQ>{}); break;
+        default: if constexpr (QPW >= 4) run(std::integral_constant<int, 4 * TPQ>{}); break;
     }
 }
 
