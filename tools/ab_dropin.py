@@ -27,3 +27,17 @@ for name, lens in (("C2 ColPali 1000 x 1030", [1030] * 1000),
     t_cat = timed(lambda: torch.cat([p.reshape(-1, 128) for p in ps], dim=0))
     print(f"{name}: ours {ours:8.2f} ms ({100*len(ps)/ours/1e3:6.2f} Mpairs/s)  reference on cuda:0 {ref:8.2f} ms  speedup {ref/ours:5.1f}x | "
           f"pack_queries {t_pq:.2f}  pack_passages {t_pp:.2f} (host cat {t_cat:.2f})  kernel {t_k:.3f} ms", flush=True)
+
+# where the drop-in's time goes (C2 geometry): cProfile of one call
+import cProfile, pstats, io
+qs = [unit(32) for _ in range(100)]
+ps = [unit(1030) for _ in range(1000)]
+amd.score_multi_vector(qs, ps, device="cuda:0")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    amd.score_multi_vector(qs, ps, device="cuda:0")
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
+print(s.getvalue()[:6000])
