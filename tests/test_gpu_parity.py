@@ -97,15 +97,17 @@ def _oracle(qs, ps, batch_size):
     (9, 33, 40, 130, 128),       # two token tiles per query
     (2, 100, 30, 90, 128),       # four token tiles per query
     (3, 128, 20, 64, 128),
-    (8, 32, 300, 500, 128),      # K1b<1,1>: one token tile per wave
-    (13, 32, 300, 500, 128),     # K1b<2,1>
-    (20, 32, 100, 400, 128),     # K1b<3,1>
-    (33, 32, 500, 300, 128),     # K1b<4,1>, two query blocks, partial last block
+    (8, 32, 300, 500, 128),      # K1s with 8 token tiles
+    (13, 32, 300, 500, 128),     # K1b<1>: waves with 2 and with 1 tile in one block
+    (20, 32, 100, 400, 128),     # K1b<1>: 3 / 2 tiles per wave
+    (33, 32, 500, 300, 128),     # K1b<1>: two balanced query blocks (17 + 16)
+    (70, 32, 150, 300, 128),     # K1b<1>: three blocks (24 + 23 + 23)
     (100, 32, 200, 1100, 5),     # many queries, long ragged documents, small reference blocks (clamp0 everywhere)
-    (17, 64, 90, 260, 128),      # K1b<4,2>
-    (6, 50, 120, 200, 128),      # K1b<2,2>
-    (10, 96, 60, 200, 128),      # K1b<3,3>
-    (12, 128, 40, 150, 128),     # K1b<4,4>
+    (17, 64, 90, 260, 128),      # K1b<2>: two blocks of 9 + 8 two-tile queries
+    (40, 64, 60, 200, 128),      # K1b<2>: three blocks (14 + 13 + 13)
+    (6, 50, 120, 200, 128),      # K1b<2>: idle waves in the only block
+    (10, 96, 60, 200, 128),      # K1b<3>: one three-tile query per wave, two blocks
+    (12, 128, 40, 150, 128),     # K1b<4>
 ])
 def test_random_ragged_against_oracle(amd, n_q, lq_max, n_d, ld_max, bs):
     qs, ps = _random_case(1000 + n_q * 7 + n_d, n_q, lq_max, n_d, ld_max)
