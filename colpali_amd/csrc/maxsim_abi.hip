@@ -935,13 +935,24 @@ static int topk_first_segment(int n_q, long long n, int k) {
     return seg;
 }
 static inline long long topk_level_out(long long n, int seg, int k) { return ((n + seg - 1) / seg) * (long long)k; }
+// Later levels: the smallest legal segment.  A bitonic sort of s candidates costs ~log2(s)^2 / 2 barrier-separated stages of s / 512
+// passes each, so two levels of 512 (45 stages + a tiny final sort) beat one 4096-candidate sort (78 stages x 8 passes) several
+// times over -- the single-workgroup last level was 157 us of a 200 us top-k at 4 queries x 125 000 documents.
+static int topk_later_segment(int k) {
+    int seg = 512;
+    while (seg < 4 * k) seg <<= 1;
+    return seg;
+}
+// one more workgroup-per-segment level only while the row is longer than two segments; otherwise one workgroup finishes the row
+static inline bool topk_is_last(long long n, int seg) { return n <= 2LL * seg && n <= msim::kTopkSeg; }
 
 size_t msim_topk_workspace_bytes(int n_q, int64_t n, int k) {
     if (n_q <= 0 || k <= 0 || k > msim::kTopkMaxK) return 0;
     const int seg0 = topk_first_segment(n_q, n, k);
-    if (n <= seg0) return 0;
+    if (topk_is_last(n, seg0)) return 0;
+    const int seg1 = topk_later_segment(k);
     const long long na = topk_level_out(n, seg0, k);
-    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, msim::kTopkSeg, k) : 0;
+    const long long nb = topk_is_last(na, seg1) ? 0 : topk_level_out(na, seg1, k);
     return align16((size_t)n_q * na * 4) + align16((size_t)n_q * na * 8) + align16((size_t)n_q * nb * 4) +
            align16((size_t)n_q * nb * 8);
 }
@@ -954,11 +965,12 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
     if (k > msim::kTopkMaxK) return fail(MSIM_EUNSUPPORTED, "k=%d > %d", k, msim::kTopkMaxK);
     if (ld < n) return fail(MSIM_EINVAL, "ld=%lld < n=%lld", (long long)ld, (long long)n);
     const int seg0 = topk_first_segment(n_q, n, k);
-    if (n > seg0 && !workspace) return fail(MSIM_EINVAL, "workspace required (msim_topk_workspace_bytes)");
+    const int seg1 = topk_later_segment(k);
+    if (!topk_is_last(n, seg0) && !workspace) return fail(MSIM_EINVAL, "workspace required (msim_topk_workspace_bytes)");
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    const long long na = n > seg0 ? topk_level_out(n, seg0, k) : 0;
-    const long long nb = na > msim::kTopkSeg ? topk_level_out(na, msim::kTopkSeg, k) : 0;
+    const long long na = topk_is_last(n, seg0) ? 0 : topk_level_out(n, seg0, k);
+    const long long nb = (na == 0 || topk_is_last(na, seg1)) ? 0 : topk_level_out(na, seg1, k);
     char *w = static_cast<char *>(workspace);
     float *bufs_s[2];
     int64_t *bufs_i[2];
@@ -976,7 +988,7 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
     long long in_n = n, in_ld = ld, in_base = id_base;
     int which = 0, seg = seg0;
     for (;;) {
-        const bool last = in_n <= seg;
+        const bool last = topk_is_last(in_n, seg);
         const long long segs = last ? 1 : (in_n + seg - 1) / seg;
         float *o_s = last ? out_scores : bufs_s[which];
         int64_t *o_i = last ? out_ids : bufs_i[which];
@@ -997,7 +1009,7 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
         in_ld = o_ld;
         in_base = 0;
         which ^= 1;
-        seg = msim::kTopkSeg;
+        seg = seg1;
     }
     return MSIM_OK;
 }
