@@ -438,10 +438,15 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
                msim::SmoothBwdArgs a, int n_split, hipStream_t st) {
     const int tpq = (a.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int cg = (a.dim + 32 * msim::kSmoothCB - 1) / (32 * msim::kSmoothCB);
+    const bool hoist = a.row_bytes <= 256;                       // the owner tile's fragments fit 8 registers quads
     if (a.n_q > 0) {
         a.n_split = n_split;
-        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true>), dim3(a.n_q * n_split, tpq, cg), dim3(msim::kSmoothWavesDQ * 64), 0,
-                           st, Q, D, d_off, pairs, order_by_doc, g, lse, n_split > 1 ? workspace : dQ, a);
+        const dim3 grid(a.n_q * n_split, tpq, cg), block(msim::kSmoothWavesDQ * 64);
+        float *dst = n_split > 1 ? workspace : dQ;
+        if (hoist)
+            hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true, true>), grid, block, 0, st, Q, D, d_off, pairs, order_by_doc, g, lse, dst, a);
+        else
+            hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, true, false>), grid, block, 0, st, Q, D, d_off, pairs, order_by_doc, g, lse, dst, a);
         if (n_split > 1) {
             const long long n = (long long)a.n_q * a.Lq * a.dim;
             hipLaunchKernelGGL(msim::smooth_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, workspace, dQ, n, n_split);
@@ -450,8 +455,11 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
     const int slabs = (max_doc_rows + 31) / 32;
     if (a.n_d > 0 && slabs > 0) {
         a.n_split = 1;
-        hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false>), dim3(a.n_d, slabs, cg), dim3(msim::kSmoothWavesDD * 64), 0, st, Q,
-                           D, d_off, pairs, order_by_doc, g, lse, dD, a);
+        const dim3 grid(a.n_d, slabs, cg), block(msim::kSmoothWavesDD * 64);
+        if (hoist)
+            hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false, true>), grid, block, 0, st, Q, D, d_off, pairs, order_by_doc, g, lse, dD, a);
+        else
+            hipLaunchKernelGGL((msim::maxsim_smooth_bwd_kernel<DT, false, false>), grid, block, 0, st, Q, D, d_off, pairs, order_by_doc, g, lse, dD, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_bwd_kernel launch: %s", hipGetErrorString(e));
@@ -730,6 +738,39 @@ int msim_smooth_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, co
     }
 }
 
+}  // extern "C"
+
+namespace {
+template <int TPQ, bool F16>
+int launch_smooth_pairs_stream(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const int32_t *pairs, float *out_scores,
+                               float *out_lse, const msim::PairsArgs &a, float tau, const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_smooth_pairs_stream_kernel<TPQ, F16>;
+    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    const int wg_needed = (a.n_pairs + 3) / 4;
+    const int wg_cap = di.cus * (di.lds_per_cu / lds);
+    hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, st, Q, D, d_off, pairs, out_scores, out_lse,
+                       a, tau);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_pairs_stream_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+template <bool F16>
+int smooth_pairs_stream_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const int32_t *pairs,
+                                 float *out_scores, float *out_lse, const msim::PairsArgs &a, float tau, const DeviceInfo &di,
+                                 hipStream_t st) {
+    switch (tpq) {
+        case 1: return launch_smooth_pairs_stream<1, F16>(Q, D, d_off, pairs, out_scores, out_lse, a, tau, di, st);
+        case 2: return launch_smooth_pairs_stream<2, F16>(Q, D, d_off, pairs, out_scores, out_lse, a, tau, di, st);
+        case 3: return launch_smooth_pairs_stream<3, F16>(Q, D, d_off, pairs, out_scores, out_lse, a, tau, di, st);
+        default: return launch_smooth_pairs_stream<4, F16>(Q, D, d_off, pairs, out_scores, out_lse, a, tau, di, st);
+    }
+}
+}  // namespace
+
+extern "C" {
+
 int msim_smooth_pairs(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
                       const int32_t *pairs, int n_pairs, float tau, float *out_scores, float *out_lse, void *stream) {
     if (n_q < 0 || n_d < 0 || n_pairs < 0) return fail(MSIM_EINVAL, "negative size");
@@ -742,6 +783,12 @@ int msim_smooth_pairs(int dtype, const void *Q, int n_q, int Lq, const void *D, 
     const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
     const int rb = dim * elem_bytes(dtype);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+    if (dim == msim::kDim && dtype != MSIM_DTYPE_F32 && tpq <= 4) {   // 128 x 16-bit rows: the LDS-DMA pipeline
+        const uint16_t *q16 = static_cast<const uint16_t *>(Q), *d16 = static_cast<const uint16_t *>(D);
+        return dtype == MSIM_DTYPE_F16 ? smooth_pairs_stream_dispatch<true>(tpq, q16, d16, d_off, pairs, out_scores, out_lse, a, tau, *di, st)
+                                       : smooth_pairs_stream_dispatch<false>(tpq, q16, d16, d_off, pairs, out_scores, out_lse, a, tau, *di, st);
+    }
     switch (dtype) {
         case MSIM_DTYPE_F32: return smooth_pairs<msim::kDtypeF32>(qc, dc, d_off, pairs, out_scores, out_lse, a, rb, tau, *di, st);
         case MSIM_DTYPE_F16: return smooth_pairs<msim::kDtypeF16>(qc, dc, d_off, pairs, out_scores, out_lse, a, rb, tau, *di, st);

@@ -21,6 +21,7 @@
 #pragma once
 #include "maxsim_common.hpp"
 #include "maxsim_generic.hip"
+#include "maxsim_pairs.hip"
 
 namespace msim {
 
@@ -31,6 +32,11 @@ struct SmoothArgs {
     float tau;
 };
 
+// exp through the hardware exp2 (v_exp_f32, ~1 ulp) instead of libm's range-reduced expf: the arguments are <= 0 differences to a
+// running maximum, so the result is in [0, 1] and the extra rounding of x * log2(e) costs < 1e-6 relative on the terms that matter
+// (the tests pin the scores to 1e-5 against a float64 logsumexp); 17 exponentials per 32 x 32 tile made expf the largest VALU item.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 // running (max, sum of exp) update with the 16 accumulator values of one 32x32 tile, x = sim / tau
 __device__ __forceinline__ void lse_update16(float &m, float &l, const f32x16 &x) {
     float mx = m;
@@ -38,8 +44,8 @@ __device__ __forceinline__ void lse_update16(float &m, float &l, const f32x16 &x
     const float ref = mx == -INFINITY ? 0.0f : mx;   // every value masked so far: keep l = 0 without producing NaN
     float s = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += expf(x[r] - ref);
-    l = l * expf(m - ref) + s;
+    for (int r = 0; r < 16; ++r) s += fast_exp(x[r] - ref);
+    l = l * fast_exp(m - ref) + s;
     m = mx;
 }
 
@@ -48,7 +54,7 @@ __device__ __forceinline__ float lse_finish(float m, float l) {
     const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32);
     const float M = fmaxf(m, m2);
     const float ref = M == -INFINITY ? 0.0f : M;
-    const float L = l * expf(m - ref) + l2 * expf(m2 - ref);
+    const float L = l * fast_exp(m - ref) + l2 * fast_exp(m2 - ref);
     return ref + logf(L);
 }
 
@@ -207,11 +213,20 @@ __global__ __launch_bounds__(256) void maxsim_smooth_pairs_kernel(const char *__
                 row = row < len ? row : len - 1;
                 const char *arow = doc + (size_t)row * row_bytes + half_off;
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                // 8 k-steps at a time: 16 independent loads in flight (clamped addresses, no select), then the MFMAs -- one memory
+                // round trip per 8 steps instead of one per step
 #pragma unroll 1
-                for (int j = 0; j < n_steps; ++j) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8 *>(arow + j * 32);
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(qrow + j * 32);
-                    acc = mfma_step<DT>(av, bv, acc);
+                for (int j0 = 0; j0 < n_steps; j0 += 8) {
+                    bf16x8 av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u < n_steps ? j0 + u : n_steps - 1;
+                        av[u] = *reinterpret_cast<const bf16x8 *>(arow + j * 32);
+                        bv[u] = *reinterpret_cast<const bf16x8 *>(qrow + j * 32);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < n_steps) acc = mfma_step<DT>(av[u], bv[u], acc);
                 }
                 const int rows_left = len - s0;
 #pragma unroll
@@ -219,6 +234,111 @@ __global__ __launch_bounds__(256) void maxsim_smooth_pairs_kernel(const char *__
                 lse_update16(m, l, acc);
             }
             const float lse = lse_finish(m, l);
+            if (out_lse != nullptr && lane < 32 && tok_valid) out_lse[(size_t)p * a.Lq + tok] = lse;
+            total += half_wave_sum(tok_valid ? tau * lse : 0.0f);
+        }
+        if (out_scores != nullptr && lane == 0) out_scores[p] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same pair-list forward for 128 x 16-bit rows on the K1s pipeline (one wave per pair, wave-private LDS ring filled by
+// LDS-DMA, operands through ds_read): fragment-shaped global loads of the kernel above run at ~4 TB/s out of L2 / MALL,
+// whole-row LDS-DMA at ~11 (measured on the arg-max twin of this kernel, maxsim_pairs_argmax_kernel).
+template <int TPQ, bool F16>
+__global__ __launch_bounds__(256) void maxsim_smooth_pairs_stream_kernel(const uint16_t *__restrict__ Q,
+                                                                         const uint16_t *__restrict__ D,
+                                                                         const int32_t *__restrict__ d_off,
+                                                                         const int32_t *__restrict__ pairs,
+                                                                         float *__restrict__ out_scores,   // [n_pairs] or null
+                                                                         float *__restrict__ out_lse,      // [n_pairs, Lq] or null
+                                                                         PairsArgs a, float tau) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wave * (kPairsRing * kSlabBytes);
+    const int gw = blockIdx.x * 4 + wave;
+    const int GW = gridDim.x * 4;
+    const float inv_tau = 1.0f / tau;
+
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+
+    for (int p = gw; p < a.n_pairs; p += GW) {
+        const int q = pairs[2 * p], c = pairs[2 * p + 1];
+        if (q < 0 || q >= a.n_q || c < 0 || c >= a.n_d) continue;   // caller error: leave the outputs untouched
+        bf16x8 qf[TPQ][kKSteps];
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+            const int row = t * kTokTile + (lane & 31);
+            const bool valid = row < a.Lq;
+            const uint16_t *qp = Q + ((size_t)q * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                bf16x8 v = *reinterpret_cast<const bf16x8 *>(qp + ks * 16);
+                qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        wait_vmcnt<0>();   // also retires every LDS-DMA / store of the previous pair
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+
+        const int r0 = d_off[c];
+        const int len = d_off[c + 1] - r0;
+        const int nslab = (len + kSlabRows - 1) / kSlabRows;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * kDim), 0, len * kRowBytes, 0x00020000);
+        int p_s = 0, p_slot = 0, c_slot = 0;
+        auto produce = [&]() -> bool {
+            if (p_s >= nslab) return false;
+            char *dst = ring + p_slot * kSlabBytes;
+            const int soff = p_s * kSlabBytes;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
+            p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
+            ++p_s;
+            return true;
+        };
+#pragma unroll
+        for (int i = 0; i < kPairsRing - 1; ++i) produce();
+
+        float m[TPQ], l[TPQ];
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) { m[t] = -INFINITY; l[t] = 0.0f; }
+
+        for (int s = 0; s < nslab; ++s) {
+            if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
+            const char *src = ring + c_slot * kSlabBytes;
+            c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
+            bf16x8 af[kKSteps];
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+            const int rows_left = len - s * kSlabRows;
+#pragma unroll
+            for (int t = 0; t < TPQ; ++t) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(af[ks], qf[t][ks], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = (acc_row(r, lane) < rows_left) ? acc[r] * inv_tau : -INFINITY;
+                lse_update16(m[t], l[t], acc);
+            }
+        }
+
+        float total = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+            const int tok = t * kTokTile + (lane & 31);
+            const bool tok_valid = tok < a.Lq;
+            const float lse = lse_finish(m[t], l[t]);
             if (out_lse != nullptr && lane < 32 && tok_valid) out_lse[(size_t)p * a.Lq + tok] = lse;
             total += half_wave_sum(tok_valid ? tau * lse : 0.0f);
         }
@@ -264,7 +384,9 @@ constexpr int kSmoothCB = 4;                            // 32-column blocks per 
 // One workgroup = (owner tile, group of 128 output columns[, slice of the pair list]).  Lane l31 owns the 4 CONSECUTIVE
 // columns 128*g + 4*l31 + {0,1,2,3} (column block cb of the second product = column 4*l31 + cb): one 8- or 16-byte load
 // per other-row fetches its 4 operands, one 16-byte store per row writes its 4 results.
-template <int DT, bool DQ>
+// HOIST: the rows are at most 8 k-steps (256 bytes) wide, so the owner tile's 8 operand fragments are loaded once per workgroup and
+// kept in registers instead of being re-fetched for every (pair, other tile) item.
+template <int DT, bool DQ, bool HOIST>
 __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) void maxsim_smooth_bwd_kernel(
     const char *__restrict__ Q, const char *__restrict__ D, const int32_t *__restrict__ d_off,
     const int32_t *__restrict__ pairs,         // sorted by query
@@ -304,6 +426,12 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
     if (own_rows <= 0) return;
     const int orow = own_tile * 32 + (l31 < own_rows ? l31 : own_rows - 1);
     const char *own_frag = own_base + (size_t)orow * row_bytes + half_off;
+
+    bf16x8 own_reg[8];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) own_reg[u] = *reinterpret_cast<const bf16x8 *>(own_frag + (u < n_steps ? u : n_steps - 1) * 32);
+    }
 
     int p_lo, p_hi;
     if constexpr (DQ) {
@@ -354,11 +482,21 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
             const int trow = t0 + (l31 < t_rows ? l31 : t_rows - 1);
             const char *oth_frag = oth_base + (size_t)trow * row_bytes + half_off;
             f32x16 s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // 8 k-steps at a time: their 16 operand loads are issued together with the 16 `bld` loads above (one memory round trip
+            // per tile for 128 x 16-bit rows instead of nine)
 #pragma unroll 1
-            for (int j = 0; j < n_steps; ++j) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(oth_frag + j * 32);
-                const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(own_frag + j * 32);
-                s = mfma_step<DT>(av, bv, s);
+            for (int j0 = 0; j0 < n_steps; j0 += 8) {
+                bf16x8 av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u < n_steps ? j0 + u : n_steps - 1;
+                    av[u] = *reinterpret_cast<const bf16x8 *>(oth_frag + j * 32);
+                    if constexpr (HOIST) bv[u] = own_reg[u];
+                    else bv[u] = *reinterpret_cast<const bf16x8 *>(own_frag + j * 32);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < n_steps) s = mfma_step<DT>(av[u], bv[u], s);
             }
             // ---- weights (zero for rows that do not exist on either side)
             float w[16];
@@ -368,7 +506,7 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
                 const bool valid = tr < t_rows && l31 < own_rows;
                 float ls = lse_own;
                 if constexpr (!DQ) ls = lse_p[t0 + (tr < t_rows ? tr : 0)];   // token = other row
-                w[r] = valid ? gp * expf(s[r] * inv_tau - ls) : 0.0f;
+                w[r] = valid ? gp * fast_exp(s[r] * inv_tau - ls) : 0.0f;
             }
             // ---- second product
             if constexpr (DT == kDtypeF32) {

@@ -173,8 +173,24 @@ def smooth_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
     return scores, lse
 
 
-def _smooth_backward(qc, dc, offsets, pairs, gp, tau):
-    """(dQ, dD) fp32 for the listed pairs (sorted by query) with upstream gradients gp."""
+_all_pairs_cache = {}
+
+
+def _all_pairs(B: int, C: int, device: torch.device) -> torch.Tensor:
+    """int32 [B*C, 2]: every (query, doc) pair in row-major order (cached per shape and device)."""
+    key = (B, C, str(device))
+    t = _all_pairs_cache.get(key)
+    if t is None:
+        if len(_all_pairs_cache) > 16:
+            _all_pairs_cache.clear()
+        b = torch.arange(B, dtype=torch.int32, device=device).repeat_interleave(C)
+        c = torch.arange(C, dtype=torch.int32, device=device).repeat(B)
+        t = _all_pairs_cache[key] = torch.stack([b, c], dim=1).contiguous()
+    return t
+
+
+def _smooth_backward(qc, dc, offsets, pairs, gp, tau, lse=None):
+    """(dQ, dD) fp32 for the listed pairs (sorted by query) with upstream gradients gp; `lse` [n_pairs, Lq] if the forward kept it."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C, Ld, _ = dc.shape
@@ -185,7 +201,8 @@ def _smooth_backward(qc, dc, offsets, pairs, gp, tau):
     if n_pairs == 0:
         return dq.zero_(), dd.zero_()
     order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
-    _, lse = smooth_pairs(qc, dc, offsets, pairs, tau, want_scores=False)
+    if lse is None:
+        _, lse = smooth_pairs(qc, dc, offsets, pairs, tau, want_scores=False)
     with torch.cuda.device(dev):
         ws_bytes = L.msim_smooth_bwd_workspace_bytes(B, Lq, dim)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
@@ -206,22 +223,33 @@ class _MaxSimSmooth(torch.autograd.Function):
         corpus = _dense_corpus(dc)
         B, Lq, dim = qc.shape
         C = dc.shape[0]
+        ctx.tau = tau
+        if any(ctx.needs_input_grad[:2]) and B * C > 0:
+            # training: the pair-list kernel over ALL pairs returns the scores and the per-token logsumexp the backward needs in one
+            # pass (the dense kernel would have to be followed by exactly this recompute when the gradient arrives)
+            pairs = _all_pairs(B, C, qc.device)
+            flat, lse = smooth_pairs(qc, dc, corpus.offsets, pairs, tau)
+            ctx.save_for_backward(qc, dc, corpus.offsets, lse)
+            return flat.view(B, C)
         scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)
         with torch.cuda.device(qc.device):
             rc = L.msim_smooth_fwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(corpus.offsets), C, dim,
                                    tau, _lib.ptr(scores), max(C, 1), _lib.current_stream_handle(qc.device))
         _lib.check(rc, "msim_smooth_fwd")
-        ctx.save_for_backward(qc, dc, corpus.offsets)
-        ctx.tau = tau
+        ctx.save_for_backward(qc, dc, corpus.offsets, None)
         return scores
 
     @staticmethod
     def backward(ctx, grad_scores: torch.Tensor):
-        qc, dc, offsets = ctx.saved_tensors
+        qc, dc, offsets, lse = ctx.saved_tensors
+        B, C = qc.shape[0], dc.shape[0]
         g = grad_scores.to(torch.float32)
         pairs64 = torch.nonzero(g)                      # row-major = sorted by query, then doc (one host sync)
-        gp = g[pairs64[:, 0], pairs64[:, 1]].contiguous()
-        dq, dd = _smooth_backward(qc, dc, offsets, pairs64.to(torch.int32).contiguous(), gp, ctx.tau)
+        if lse is not None and pairs64.shape[0] == B * C:
+            pairs, gp = _all_pairs(B, C, qc.device), g.reshape(-1).contiguous()     # dense gradient: the forward's list and LSE
+        else:
+            pairs, gp, lse = pairs64.to(torch.int32).contiguous(), g[pairs64[:, 0], pairs64[:, 1]].contiguous(), None
+        dq, dd = _smooth_backward(qc, dc, offsets, pairs, gp, ctx.tau, lse=lse)
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
                 dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
 

@@ -2,7 +2,7 @@
 # per-kernel time of each loss step (separate traces so the shared kernels are attributed)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for w in pairwise infonce smooth; do
+for w in ${1:-pairwise infonce smooth}; do
   rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_loss_$w -o p -- python $R/tools/prof_loss.py $w > $R/gpurun_out/prof_loss_$w.log 2>&1
   f=$(find $R/gpurun_out/prof_loss_$w -name "*kernel_stats.csv" | head -1)
   echo "== $w"; python - "$f" <<'PY'
