@@ -53,33 +53,44 @@ def _widen(x: torch.Tensor) -> torch.Tensor:
 
 
 class _MaxSim(torch.autograd.Function):
-    """scores[b, c] = sum_n max_s <Q[b,n], D[c,s]> with a sparse recompute backward."""
+    """scores[b, c] = sum_n max_s <Q[b,n], D[c,s]> with a recompute backward.
+
+    `dense_grad` is the caller's hint that every (query, doc) pair will receive a gradient (softmax / sigmoid losses): the
+    forward then runs the arg-max pair kernel over all pairs once and keeps the [B*C, Lq] int32 routing, instead of the
+    score-only kernel now and the same arg-max pass again when the gradient arrives."""
 
     @staticmethod
-    def forward(ctx, q: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor, dense_grad: bool = False) -> torch.Tensor:
         qc, dc = q.contiguous(), d.contiguous()
         corpus = _dense_corpus(dc)
+        B, C = qc.shape[0], dc.shape[0]
+        if dense_grad and any(ctx.needs_input_grad[:2]) and B * C > 0:
+            scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)   # returned as is (not a view: callers modify it in place)
+            _, argmax = maxsim_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, qc.device), scores_out=scores)
+            ctx.save_for_backward(qc, dc, corpus.offsets, argmax)
+            return scores
         scores = maxsim_scores(qc, corpus)
-        ctx.save_for_backward(qc, dc, corpus.offsets)
+        ctx.save_for_backward(qc, dc, corpus.offsets, None)
         return scores
 
     @staticmethod
     def backward(ctx, grad_scores: torch.Tensor):
-        qc, dc, offsets = ctx.saved_tensors
-        dq, dd = maxsim_backward(qc, dc, offsets, grad_scores)
+        qc, dc, offsets, argmax = ctx.saved_tensors
+        dq, dd = maxsim_backward(qc, dc, offsets, grad_scores, argmax_all=argmax)
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
-                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None)
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
 
 
 def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pairs: torch.Tensor,
-                 want_scores: bool = True, want_argmax: bool = True):
-    """MaxSim (+ arg-max routing) for an int32 [n_pairs, 2] list of (query, doc) index pairs."""
+                 want_scores: bool = True, want_argmax: bool = True, scores_out=None):
+    """MaxSim (+ arg-max routing) for an int32 [n_pairs, 2] list of (query, doc) index pairs.
+    `scores_out`: a contiguous fp32 tensor of n_pairs elements to write the scores into (any shape)."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C = offsets.numel() - 1
     n_pairs = pairs.shape[0]
     dev = qc.device
-    scores = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if want_scores else None
+    scores = (scores_out if scores_out is not None else torch.empty((n_pairs,), dtype=torch.float32, device=dev)) if want_scores else None
     argmax = torch.empty((n_pairs, Lq), dtype=torch.int32, device=dev) if want_argmax else None
     with torch.cuda.device(dev):
         rc = L.msim_pairs_argmax(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), None, C,
@@ -89,8 +100,9 @@ def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
     return scores, argmax
 
 
-def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor):
-    """(dQ fp32 [B,Lq,width], dD fp32 [C,Ld,width]) for upstream dLoss/dscores [B, C]."""
+def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor, argmax_all=None):
+    """(dQ fp32 [B,Lq,width], dD fp32 [C,Ld,width]) for upstream dLoss/dscores [B, C].  `argmax_all`: the [B*C, Lq] routing
+    of every pair in row-major order when the forward kept it (used when the gradient is dense)."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C, Ld, _ = dc.shape
@@ -102,10 +114,14 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
     dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
     if n_pairs == 0:
         return dq.zero_(), dd.zero_()
-    gp = g[pairs64[:, 0], pairs64[:, 1]].contiguous()
-    pairs = pairs64.to(torch.int32).contiguous()
-    order = torch.sort(pairs64[:, 1], stable=True).indices.to(torch.int32).contiguous()
-    _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
+    if argmax_all is not None and n_pairs == B * C:
+        gp, pairs, argmax = g.reshape(-1).contiguous(), _all_pairs(B, C, dev), argmax_all
+        order = _all_pairs_order(B, C, dev)
+    else:
+        gp = g[pairs64[:, 0], pairs64[:, 1]].contiguous()
+        pairs = pairs64.to(torch.int32).contiguous()
+        order = torch.sort(pairs64[:, 1], stable=True).indices.to(torch.int32).contiguous()
+        _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
     with torch.cuda.device(dev):
         rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
                               _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), n_pairs,
@@ -157,14 +173,14 @@ def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, 
 
 
 def smooth_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pairs: torch.Tensor, tau: float,
-                 want_scores: bool = True, want_lse: bool = True):
+                 want_scores: bool = True, want_lse: bool = True, scores_out=None):
     """Smooth-max score (+ per-token logsumexp of sim / tau) for an int32 [n_pairs, 2] list of (query, doc) pairs."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C = offsets.numel() - 1
     n_pairs = pairs.shape[0]
     dev = qc.device
-    scores = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if want_scores else None
+    scores = (scores_out if scores_out is not None else torch.empty((n_pairs,), dtype=torch.float32, device=dev)) if want_scores else None
     lse = torch.empty((n_pairs, Lq), dtype=torch.float32, device=dev) if want_lse else None
     with torch.cuda.device(dev):
         rc = L.msim_smooth_pairs(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim,
@@ -186,6 +202,15 @@ def _all_pairs(B: int, C: int, device: torch.device) -> torch.Tensor:
         b = torch.arange(B, dtype=torch.int32, device=device).repeat_interleave(C)
         c = torch.arange(C, dtype=torch.int32, device=device).repeat(B)
         t = _all_pairs_cache[key] = torch.stack([b, c], dim=1).contiguous()
+    return t
+
+
+def _all_pairs_order(B: int, C: int, device: torch.device) -> torch.Tensor:
+    """int32 [B*C]: indices of the row-major all-pairs list sorted by document, then query (what a stable sort by doc gives)."""
+    key = ("order", B, C, str(device))
+    t = _all_pairs_cache.get(key)
+    if t is None:
+        t = _all_pairs_cache[key] = torch.arange(B * C, dtype=torch.int32, device=device).view(B, C).t().contiguous().view(-1)
     return t
 
 
@@ -227,10 +252,10 @@ class _MaxSimSmooth(torch.autograd.Function):
         if any(ctx.needs_input_grad[:2]) and B * C > 0:
             # training: the pair-list kernel over ALL pairs returns the scores and the per-token logsumexp the backward needs in one
             # pass (the dense kernel would have to be followed by exactly this recompute when the gradient arrives)
-            pairs = _all_pairs(B, C, qc.device)
-            flat, lse = smooth_pairs(qc, dc, corpus.offsets, pairs, tau)
+            scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)   # returned as is (not a view: callers modify it in place)
+            _, lse = smooth_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, qc.device), tau, scores_out=scores)
             ctx.save_for_backward(qc, dc, corpus.offsets, lse)
-            return flat.view(B, C)
+            return scores
         scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)
         with torch.cuda.device(qc.device):
             rc = L.msim_smooth_fwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(corpus.offsets), C, dim,
@@ -311,11 +336,12 @@ def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
     return q, d
 
 
-def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torch.Tensor:
-    """Differentiable fused MaxSim: fp32 [B, C] (late_interaction_losses.py:297-298 without the 4-D tensor)."""
+def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, dense_grad: bool = False) -> torch.Tensor:
+    """Differentiable fused MaxSim: fp32 [B, C] (late_interaction_losses.py:297-298 without the 4-D tensor).
+    `dense_grad=True`: the caller expects a gradient on every pair (see _MaxSim)."""
     query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
-    return _MaxSim.apply(_widen(query_embeddings), _widen(doc_embeddings))
+    return _MaxSim.apply(_widen(query_embeddings), _widen(doc_embeddings), dense_grad)
 
 
 class ColbertModule(torch.nn.Module):
@@ -357,12 +383,12 @@ class ColbertModule(torch.nn.Module):
         scores[too_high] *= self.filter_factor
 
     # -- shared front end of every in-batch loss: lengths, fused MaxSim, optional normalisation / filtering
-    def _inbatch_scores(self, query_embeddings, doc_embeddings, offset):
+    def _inbatch_scores(self, query_embeddings, doc_embeddings, offset, dense_grad=False):
         lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)          # :296 -- first component, not a norm test
         if self.use_smooth_max:                                        # :88-89: tau * logsumexp(raw / tau) instead of amax
             scores = maxsim_smooth(query_embeddings, doc_embeddings, self.tau)
         else:
-            scores = maxsim(query_embeddings, doc_embeddings)
+            scores = maxsim(query_embeddings, doc_embeddings, dense_grad)
         if self.normalize_scores:
             scores = self._apply_normalization(scores, lengths)
         rows, pos_idx = self._get_idx(scores.size(0), offset, scores.device)
@@ -406,7 +432,7 @@ class ColbertLoss(ColbertModule):
         self.ce_loss = torch.nn.CrossEntropyLoss()
 
     def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
-        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset)
+        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset, dense_grad=True)
         return self.ce_loss(scores / self.temperature, pos_idx).to(query_embeddings.dtype)   # :164
 
 
@@ -424,7 +450,7 @@ class ColbertSigmoidLoss(ColbertModule):
         self.ce_loss = torch.nn.CrossEntropyLoss()
 
     def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
-        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset)
+        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset, dense_grad=True)
         n = scores.size(0)
         sign = -torch.ones(n * n, device=scores.device)                 # :457-459: +1 on the positives of the flattened square
         sign[pos_idx * (n + 1)] = 1.0
