@@ -167,25 +167,27 @@ int launch_stream(const FwdCall &c) {
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
 
-template <int TPQ, bool F16>
+template <int TPQ, bool F16, int NW>
 int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<TPQ, F16>;
+    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW>;
+    constexpr int lds = msim::kBatchRing * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves)
+    constexpr int wg_per_cu = 8 / NW;
     static std::atomic<int> configured[kMaxDevices];
-    if (int rc = allow_lds(kern, msim::kBatchLds, configured)) return rc;
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
     msim::BatchArgs a;
     a.ld = c.ld;
     a.n_q = c.n_q;
     a.Lq = c.Lq;
     a.n_d = c.n_d;
     a.flags = c.flags;
-    const int q_per_block = msim::kBatchWaves * (4 / TPQ);          // at most; the kernel splits n_q evenly over the blocks
+    const int q_per_block = NW * (4 / TPQ);                         // at most; the kernel splits n_q evenly over the blocks
     a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
-    const int cus_per_xcd = c.di->cus / 8 > 0 ? c.di->cus / 8 : 1;
+    const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
     const int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
     a.n_ranges = 8 * sub;
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
-    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), msim::kBatchLds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
     return MSIM_OK;
@@ -208,10 +210,12 @@ int fwd_dispatch(const FwdCall &c) {
     const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int n_q = c.n_q;
     if (n_q * tpq > stream_max_tiles()) {
-        if (tpq == 1) return launch_batch<1, F16>(c);
-        if (tpq == 2) return launch_batch<2, F16>(c);
-        if (tpq == 3) return launch_batch<3, F16>(c);
-        return launch_batch<4, F16>(c);
+        // up to 24 token tiles: two 4-wave workgroups per CU cover each other's chunk barriers; above: one 8-wave workgroup
+        const bool small = n_q * tpq <= 24;
+        if (tpq == 1) return small ? launch_batch<1, F16, 4>(c) : launch_batch<1, F16, 8>(c);
+        if (tpq == 2) return small ? launch_batch<2, F16, 4>(c) : launch_batch<2, F16, 8>(c);
+        if (tpq == 3) return small ? launch_batch<3, F16, 4>(c) : launch_batch<3, F16, 8>(c);
+        return small ? launch_batch<4, F16, 4>(c) : launch_batch<4, F16, 8>(c);
     }
     switch (n_q * 10 + tpq) {
         case 11: return launch_stream<1, 1, F16>(c);

@@ -28,7 +28,7 @@
 
 namespace msim {
 
-constexpr int kBatchWaves = 8;
+constexpr int kBatchWaves = 8;                           // K1bP (maxsim_panels.hip); K1b takes its wave count as a template parameter
 constexpr int kChunkSlabs = 4;
 constexpr int kChunkRows = kChunkSlabs * kSlabRows;      // 128 patches
 constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;    // 32 KiB
@@ -55,13 +55,20 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 
 // TPQ: token tiles (32 tokens) per query, 1..4.  A wave holds whole queries: up to 4 / TPQ of them (NTMAX = TPQ * (4 / TPQ)
 // token tiles); how many it really holds is a run-time, wave-uniform number that selects the compiled loop body.
-template <int TPQ, bool F16>
-__global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
+// NW : waves per workgroup.  8 = one workgroup per CU, 128-row chunks (the MFMA-bound end: fewest query blocks per corpus pass);
+//      4 = two workgroups per CU with 64-row chunks and half the queries each: while one sits at its chunk barrier the other
+//      computes (+5 % at 9..16 queries, -2..-4 % from 64 queries up, where the doubled number of query blocks costs more).
+template <int TPQ, bool F16, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
                                                                const uint8_t *__restrict__ clamp0,
                                                                float *__restrict__ scores, BatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kB1Waves = NW;
+    constexpr int kChunkSlabs = NW / 2;                    // every wave fills half a slab of each chunk (shadows the 8-wave constants)
+    constexpr int kChunkRows = kChunkSlabs * kSlabRows;
+    constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -85,11 +92,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
     const int q_base = a.n_q / a.n_qblocks, q_extra = a.n_q % a.n_qblocks;
     const int qb0 = qblock * q_base + (qblock < q_extra ? qblock : q_extra);   // first query of this block
     const int qb_n = q_base + (qblock < q_extra ? 1 : 0);                       // queries in this block (<= 8 * QPW)
-    const int my_q = wave < qb_n ? (qb_n - 1 - wave) / kBatchWaves + 1 : 0;     // queries of this wave (wave-uniform)
+    const int my_q = wave < qb_n ? (qb_n - 1 - wave) / kB1Waves + 1 : 0;     // queries of this wave (wave-uniform)
     bf16x8 qf[NTMAX][kKSteps];
 #pragma unroll
     for (int t = 0; t < NTMAX; ++t) {
-        const int q = qb0 + wave + kBatchWaves * (t / TPQ);
+        const int q = qb0 + wave + kB1Waves * (t / TPQ);
         const int row = (t % TPQ) * kTokTile + (lane & 31);
         const bool valid = t / TPQ < my_q && row < a.Lq;
         const uint16_t *p = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_kernel(const uint16_t *__
 #pragma unroll
                     for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[qq * TPQ + tt];
                     if (ref_bf16) tot = round_to_input<F16>(tot);
-                    scores[(size_t)(qb0 + wave + kBatchWaves * qq) * a.ld + c_idx] = tot;
+                    scores[(size_t)(qb0 + wave + kB1Waves * qq) * a.ld + c_idx] = tot;
                 }
             }
         }
