@@ -119,6 +119,14 @@ def cpu_baseline(q_len, doc_len):
     }
 
 
+def reference_scorer(qs, ps, device):
+    """The reference's blocked scorer (oracle/torch_port.py restates processing_utils.py:132-187 with its own torch calls) on
+    `device`: the baseline legs of this file and of tools/ab_dropin.py go through here, nothing else does."""
+    from oracle import torch_port
+
+    return torch_port.score_multi_vector_cpu(qs, ps, device=device)
+
+
 def torch_gpu_reference(q_len, doc_len):
     """What the unmodified reference does on this same GPU (its torch einsum/max/sum with host-side padding and
     H2D per block, processing_utils.py:170-180): informational, not the optimisation target."""

@@ -3,8 +3,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
+import bench
 import colpali_amd as amd
-from oracle import torch_port
 
 g = torch.Generator().manual_seed(1)
 def unit(n): return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16)
@@ -18,7 +18,7 @@ for name, lens in (("C2 ColPali 1000 x 1030", [1030] * 1000),
             torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         return sorted(ts)[len(ts) // 2] * 1e3
     ours = timed(lambda: amd.score_multi_vector(qs, ps, device="cuda:0"))
-    ref = timed(lambda: torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0"), reps=3)
+    ref = timed(lambda: bench.reference_scorer(qs, ps, "cuda:0"), reps=3)
     dev = torch.device("cuda:0")
     t_pq = timed(lambda: amd.pack_queries(qs, dev))
     t_pp = timed(lambda: amd.pack_passages(ps, dev))

@@ -4,7 +4,6 @@ import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
 import colpali_amd as amd
-from oracle import li_loss_oracle  # noqa: F401  (only to assert availability of the checker in tools)
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
