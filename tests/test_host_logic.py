@@ -145,3 +145,56 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_all_pairs_list_and_document_order():
+    """The dense-gradient losses hand the kernels the row-major all-pairs list and its by-document order (loss.py)."""
+    from colpali_amd import loss
+
+    B, C = 3, 5
+    pairs = loss._all_pairs(B, C, torch.device("cpu"))
+    assert pairs.dtype == torch.int32 and pairs.shape == (B * C, 2)
+    assert pairs.tolist() == [[b, c] for b in range(B) for c in range(C)]
+    order = loss._all_pairs_order(B, C, torch.device("cpu"))
+    want = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32)     # what the sparse path computes
+    assert torch.equal(order, want)
+    assert loss._all_pairs(B, C, torch.device("cpu")) is pairs                              # cached
+
+
+def test_topk_workspace_plan_is_consistent():
+    """msim_topk_workspace_bytes follows the level plan of msim_topk_f32: none when one workgroup finishes a row, otherwise the
+    ping-pong buffers of the first two levels (12 bytes per surviving candidate), monotone in the row length."""
+    import ctypes
+    from colpali_amd import _lib
+
+    L = _lib.lib()
+
+    def later_seg(k):
+        s = 512
+        while s < 4 * k:
+            s *= 2
+        return s
+
+    def first_seg(n_q, n, k):
+        s = later_seg(k)
+        while s < 4096 and n_q * -(-n // s) > 1024:
+            s *= 2
+        return s
+
+    def is_last(n, seg):
+        return n <= 2 * seg and n <= 4096
+
+    def a16(x):
+        return (x + 15) // 16 * 16
+
+    for n_q, n, k in [(1, 100, 10), (4, 125000, 10), (4, 125000, 100), (1000, 125000, 10), (1, 1_000_000, 1000), (7, 4097, 1), (3, 1024, 10)]:
+        got = L.msim_topk_workspace_bytes(n_q, n, k)
+        s0, s1 = first_seg(n_q, n, k), later_seg(k)
+        if is_last(n, s0):
+            want = 0
+        else:
+            na = -(-n // s0) * k
+            nb = 0 if is_last(na, s1) else -(-na // s1) * k
+            want = a16(n_q * na * 4) + a16(n_q * na * 8) + a16(n_q * nb * 4) + a16(n_q * nb * 8)
+        assert got == want, (n_q, n, k, got, want)
+    assert L.msim_topk_workspace_bytes(4, 125000, 5000) == 0     # k above the kernel's limit: rejected, no plan
