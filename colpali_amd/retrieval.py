@@ -29,11 +29,12 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def topk(scores: torch.Tensor, k: int, id_base: int = 0, ids: Optional[torch.Tensor] = None
-         ) -> Tuple[torch.Tensor, torch.Tensor]:
+def topk(scores: torch.Tensor, k: int, id_base: int = 0, ids: Optional[torch.Tensor] = None,
+         out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Row-wise top-k on the GPU, ordered by (score desc, id asc); pads with (-inf, -1).
 
     scores: fp32 [n_q, n] (device). ids: optional int64 [n_q, n] candidate ids (default id_base + column).
+    out: optional preallocated contiguous (fp32 [n_q, k], int64 [n_q, k]) to write into.
     """
     L = _lib.lib()
     if scores.dim() != 2 or scores.dtype != torch.float32 or scores.device.type != "cuda":
@@ -50,8 +51,14 @@ def topk(scores: torch.Tensor, k: int, id_base: int = 0, ids: Optional[torch.Ten
             scores = scores.contiguous()
             ld = max(n, 1)
     dev = scores.device
-    out_s = torch.empty((n_q, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((n_q, k), dtype=torch.int64, device=dev)
+    if out is not None:
+        out_s, out_i = out
+        if (out_s.shape != (n_q, k) or out_i.shape != (n_q, k) or out_s.dtype != torch.float32 or out_i.dtype != torch.int64
+                or not out_s.is_contiguous() or not out_i.is_contiguous() or out_s.device != dev or out_i.device != dev):
+            raise ValueError("out must be contiguous (fp32 [n_q, k], int64 [n_q, k]) tensors on the scores' device")
+    else:
+        out_s = torch.empty((n_q, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((n_q, k), dtype=torch.int64, device=dev)
     ws_bytes = L.msim_topk_workspace_bytes(n_q, n, k)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     with torch.cuda.device(dev):
@@ -77,15 +84,27 @@ def shard_topk(scores: torch.Tensor, k: int, id_base: int, world: int = 1, dist=
     `scores` [n_q, n_local]: column j is document id_base + j.  Returns the same global
     (scores [n_q, k], ids [n_q, k]) on every rank.
     """
-    loc_s, loc_i = select(scores, k, id_base, None)
     if world <= 1:
-        return loc_s, loc_i
-    n_q = loc_s.shape[0]
-    all_s = torch.empty((world * n_q, k), dtype=loc_s.dtype, device=loc_s.device)   # rank-major concatenation
-    all_i = torch.empty((world * n_q, k), dtype=loc_i.dtype, device=loc_i.device)
-    dist.all_gather_into_tensor(all_s, loc_s.contiguous(), group=group)   # RCCL all-gather over xGMI (nccl backend)
-    dist.all_gather_into_tensor(all_i, loc_i.contiguous(), group=group)
-    all_s, all_i = all_s.view(world, n_q, k), all_i.view(world, n_q, k)
+        return select(scores, k, id_base, None)
+    # one message per rank: [scores fp32 n_q*k | pad to 8 | ids int64 n_q*k] -- ONE all-gather of 12 bytes per candidate
+    n_q = scores.shape[0]
+    sb = n_q * k * 4
+    sbp = (sb + 7) // 8 * 8
+    nbytes = sbp + n_q * k * 8
+    mine = torch.empty((nbytes,), dtype=torch.uint8, device=scores.device)
+    my_s = mine[:sb].view(torch.float32).view(n_q, k)
+    my_i = mine[sbp:].view(torch.int64).view(n_q, k)
+    if select is topk:
+        topk(scores, k, id_base, None, out=(my_s, my_i))                    # the selection kernel writes the message in place
+    else:
+        loc_s, loc_i = select(scores, k, id_base, None)
+        my_s.copy_(loc_s)
+        my_i.copy_(loc_i)
+    flat = torch.empty((world * nbytes,), dtype=torch.uint8, device=scores.device)     # rank-major concatenation
+    dist.all_gather_into_tensor(flat, mine, group=group)                   # RCCL all-gather over xGMI (nccl backend)
+    gathered = flat.view(world, nbytes)
+    all_s = gathered[:, :sb].view(torch.float32).view(world, n_q, k)
+    all_i = gathered[:, sbp:].view(torch.int64).view(world, n_q, k)
     return merge_gathered(all_s, all_i, k, select)
 
 

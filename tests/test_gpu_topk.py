@@ -57,3 +57,37 @@ def test_virtual_shards_on_one_gpu_equal_unsharded(amd):
             parts.append(amd.topk(amd.maxsim_scores(q, shard), k, id_base=lo))
         ms, mi = amd.merge_gathered(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
         assert torch.equal(mi, fi) and torch.equal(ms, fs)
+
+
+class _FakeDist:
+    """Stands in for torch.distributed inside one process: rank r's message is whatever virtual shard r produced."""
+
+    def __init__(self, messages, me):
+        self.messages, self.me = messages, me
+
+    def all_gather_into_tensor(self, out, mine, group=None):
+        self.messages[self.me] = mine.clone()
+        out.copy_(torch.cat([m.reshape(-1) for m in self.messages]))
+
+
+def test_shard_topk_single_packed_message_equals_unsharded(amd):
+    # the N > 1 path of shard_topk on one GPU: the selection kernel writes (scores | ids) straight into the rank's message,
+    # one all-gather of that byte buffer, strided views of the gathered bytes go into the merge
+    g = torch.Generator().manual_seed(11)
+    n_docs, k, world = 900, 7, 3                         # n_q * k * 4 = 140 bytes: not a multiple of 8 -> exercises the padding
+    docs = [torch.nn.functional.normalize(torch.randn(48, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_docs)]
+    q = torch.nn.functional.normalize(torch.randn(5, 32, 128, generator=g), dim=-1).to(torch.bfloat16).cuda()
+    dev = torch.device("cuda:0")
+    fs, fi = amd.topk(amd.maxsim_scores(q, amd.pack_passages(docs, dev, batch_size=None)), k)
+    shards = []
+    for r in range(world):
+        lo, hi = amd.shard_range(n_docs, world, r)
+        shards.append((lo, amd.maxsim_scores(q, amd.pack_passages(docs[lo:hi], dev, batch_size=None, id_base=lo))))
+    n_q = q.shape[0]
+    nbytes = (n_q * k * 4 + 7) // 8 * 8 + n_q * k * 8
+    messages = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+    for r in range(world):                               # first pass fills every rank's message, second pass merges with all of them
+        amd.shard_topk(shards[r][1], k, shards[r][0], world, _FakeDist(messages, r))
+    for r in range(world):
+        ms, mi = amd.shard_topk(shards[r][1], k, shards[r][0], world, _FakeDist(messages, r))
+        assert torch.equal(mi, fi) and torch.equal(ms, fs)
