@@ -443,6 +443,39 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
     const int tpq = (a.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int cg = (a.dim + 32 * msim::kSmoothCB - 1) / (32 * msim::kSmoothCB);
     const bool hoist = a.row_bytes <= 256;                       // the owner tile's fragments fit 8 registers quads
+    static const bool no_stage = getenv("MSIM_SMOOTH_NO_STAGE") != nullptr;   // A/B knob, not part of the ABI
+    const int slabs = (max_doc_rows + 31) / 32;
+    if constexpr (DT != msim::kDtypeF32) {
+        if (a.row_bytes == msim::kRowBytes && a.dim == msim::kDim && !no_stage) {   // 128 x 16-bit rows: staged "other" tiles
+            constexpr bool F16 = DT == msim::kDtypeF16;
+            if (a.n_q > 0) {
+                a.n_split = n_split;
+                auto kern = msim::maxsim_smooth_bwd_staged_kernel<F16, true>;
+                constexpr int lds = msim::kSmoothWavesDQ * msim::kSmoothStageBytes;
+                static std::atomic<int> configured[kMaxDevices];
+                if (int rc = allow_lds(kern, lds, configured)) return rc;
+                hipLaunchKernelGGL(kern, dim3(a.n_q * n_split, tpq, 1), dim3(msim::kSmoothWavesDQ * 64), lds, st, Q, D, d_off, pairs,
+                                   order_by_doc, g, lse, n_split > 1 ? workspace : dQ, a);
+                if (n_split > 1) {
+                    const long long n = (long long)a.n_q * a.Lq * a.dim;
+                    hipLaunchKernelGGL(msim::smooth_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, workspace, dQ, n,
+                                       n_split);
+                }
+            }
+            if (a.n_d > 0 && slabs > 0) {
+                a.n_split = 1;
+                auto kern = msim::maxsim_smooth_bwd_staged_kernel<F16, false>;
+                constexpr int lds = msim::kSmoothWavesDD * msim::kSmoothStageBytes;
+                static std::atomic<int> configured[kMaxDevices];
+                if (int rc = allow_lds(kern, lds, configured)) return rc;
+                hipLaunchKernelGGL(kern, dim3(a.n_d, slabs, 1), dim3(msim::kSmoothWavesDD * 64), lds, st, Q, D, d_off, pairs, order_by_doc, g,
+                                   lse, dD, a);
+            }
+            hipError_t es = hipGetLastError();
+            if (es != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_smooth_bwd_staged_kernel launch: %s", hipGetErrorString(es));
+            return MSIM_OK;
+        }
+    }
     if (a.n_q > 0) {
         a.n_split = n_split;
         const dim3 grid(a.n_q * n_split, tpq, cg), block(msim::kSmoothWavesDQ * 64);
@@ -456,7 +489,6 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
             hipLaunchKernelGGL(msim::smooth_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, workspace, dQ, n, n_split);
         }
     }
-    const int slabs = (max_doc_rows + 31) / 32;
     if (a.n_d > 0 && slabs > 0) {
         a.n_split = 1;
         const dim3 grid(a.n_d, slabs, cg), block(msim::kSmoothWavesDD * 64);

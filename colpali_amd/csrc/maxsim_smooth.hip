@@ -581,6 +581,234 @@ __global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same backward for 128 x 16-bit rows with the "other" tile STAGED: the generic kernel above fetches every other tile twice
+// (once in MFMA-fragment form, 32-byte pieces of 32 rows, and once in column form) straight from L2; here the tile's 32 whole rows
+// (8 KiB) arrive ONCE by LDS-DMA in a wave-private, double-buffered slot with the K1s swizzle, and both operand forms are read from
+// LDS (ds_read_b128 for the first product, ds_read_b64 for the second).  The next item's tile and pair data are requested before the
+// current item is computed.  Arithmetic, summation order and the cross-wave reduction are those of the generic kernel: the two are
+// bit-identical.
+constexpr int kSmoothStageBytes = 2 * kSlabBytes;      // per wave: two 8 KiB slots
+
+template <bool F16, bool DQ>
+__global__ __launch_bounds__(DQ ? kSmoothWavesDQ * 64 : kSmoothWavesDD * 64) void maxsim_smooth_bwd_staged_kernel(
+    const char *__restrict__ Q, const char *__restrict__ D, const int32_t *__restrict__ d_off,
+    const int32_t *__restrict__ pairs, const int32_t *__restrict__ order_by_doc, const float *__restrict__ g,
+    const float *__restrict__ lse, float *__restrict__ out, SmoothBwdArgs a) {
+    constexpr int DT = F16 ? kDtypeF16 : kDtypeBf16;
+    constexpr int NW = DQ ? kSmoothWavesDQ : kSmoothWavesDD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NW x 16 KiB of tile slots, re-used for the final reduction
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int col0 = 4 * l31;                                       // dim = 128: one group of 128 columns, lane owns 4 of them
+    const float inv_tau = 1.0f / a.tau;
+    char *slots = smem + wave * kSmoothStageBytes;
+
+    const int own = DQ ? blockIdx.x / a.n_split : blockIdx.x;
+    const int split = DQ ? blockIdx.x % a.n_split : 0;
+    const int own_tile = blockIdx.y;
+    int own_len;
+    const char *own_base;
+    if constexpr (DQ) {
+        own_len = a.Lq;
+        own_base = Q + (size_t)own * a.Lq * kRowBytes;
+    } else {
+        own_len = d_off[own + 1] - d_off[own];
+        own_base = D + (size_t)d_off[own] * kRowBytes;
+    }
+    const int own_rows = own_len - own_tile * 32;
+    if (own_rows <= 0) return;
+    const int orow = own_tile * 32 + (l31 < own_rows ? l31 : own_rows - 1);
+    bf16x8 own_reg[kKSteps];
+#pragma unroll
+    for (int u = 0; u < kKSteps; ++u) own_reg[u] = *reinterpret_cast<const bf16x8 *>(own_base + (size_t)orow * kRowBytes + half * 16 + u * 32);
+
+    int p_lo, p_hi;
+    if constexpr (DQ) {
+        p_lo = lower_bound_idx(a.n_pairs, own, [&](int k) { return pairs[2 * k]; });
+        p_hi = lower_bound_idx(a.n_pairs, own + 1, [&](int k) { return pairs[2 * k]; });
+    } else {
+        auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
+        p_lo = lower_bound_idx(a.n_pairs, own, doc_of);
+        p_hi = lower_bound_idx(a.n_pairs, own + 1, doc_of);
+    }
+
+    // ---- LDS addressing (K1s slab image: logical 16-byte chunk c of row r at chunk c ^ (r & 15))
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(l31, 2 * ks + half);
+
+    // ---- this wave's items: (pair, other tile) with running index % NW == wave, in list order
+    struct Item {
+        const char *base;      // first row of the other entity
+        const float *lse_p;    // per-token LSE of the pair
+        float gp;
+        int len, t0;
+        bool valid;
+    };
+    int it_k = p_lo + split, it_ot = 0, it_ntiles = 0, it_item = 0;
+    bool it_open = false;
+    Item info{nullptr, nullptr, 0.0f, 0, 0, false};
+    const int k_stride = DQ ? a.n_split : 1;
+    auto next_item = [&]() -> Item {
+        for (;;) {
+            if (!it_open) {
+                if (it_k >= p_hi) return Item{nullptr, nullptr, 0.0f, 0, 0, false};
+                const int p = DQ ? it_k : order_by_doc[it_k];
+                const int oth = DQ ? pairs[2 * p + 1] : pairs[2 * p];
+                info.gp = g[p];
+                info.lse_p = lse + (size_t)p * a.Lq;
+                if constexpr (DQ) {
+                    info.len = d_off[oth + 1] - d_off[oth];
+                    info.base = D + (size_t)d_off[oth] * kRowBytes;
+                } else {
+                    info.len = a.Lq;
+                    info.base = Q + (size_t)oth * a.Lq * kRowBytes;
+                }
+                it_ntiles = (info.len + 31) >> 5;
+                it_ot = 0;
+                it_open = true;
+            }
+            if (it_ot >= it_ntiles) {
+                it_open = false;
+                it_k += k_stride;
+                continue;
+            }
+            const bool mine = (it_item % NW) == wave;
+            Item r = info;
+            r.t0 = it_ot * 32;
+            r.valid = true;
+            ++it_ot;
+            ++it_item;
+            if (mine) return r;
+        }
+    };
+    auto issue = [&](const Item &it, int slot) {       // 8 LDS-DMA wave-instructions: rows t0 .. t0+31 (rows past the end read as zeros)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)it.base, 0, it.len * kRowBytes, 0x00020000);
+        char *dst = slots + slot * kSlabBytes;
+        const int soff = it.t0 * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
+    };
+
+    f32x16 acc2[kSmoothCB];
+#pragma unroll
+    for (int cb = 0; cb < kSmoothCB; ++cb) acc2[cb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    Item cur = next_item();
+    if (cur.valid) issue(cur, 0);
+    int slot = 0;
+    while (cur.valid) {
+        const int t_rows = cur.len - cur.t0;            // >= 1
+        // ---- this item's LSE values first (ordinary loads), then the NEXT item's tile: waiting for all but the last 8 loads
+        // leaves exactly that tile in flight under the arithmetic below
+        float ls[16];
+        if constexpr (DQ) {
+            const float v = cur.lse_p[orow];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ls[r] = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tr = acc_row(r, lane);
+                ls[r] = cur.lse_p[cur.t0 + (tr < t_rows ? tr : 0)];
+            }
+        }
+        const Item nxt = next_item();
+        if (nxt.valid) {
+            issue(nxt, slot ^ 1);
+            wait_vmcnt<8>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        const char *tile = slots + slot * kSlabBytes;
+        // ---- first product: A = other rows (from LDS), B = owner rows (registers)
+        f32x16 sacc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8 *>(tile + rd_off[ks]);
+            sacc = mfma32<F16>(av, own_reg[ks], sacc);
+        }
+        float w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tr = acc_row(r, lane);
+            const bool valid = tr < t_rows && l31 < own_rows;
+            w[r] = valid ? cur.gp * fast_exp(sacc[r] * inv_tau - ls[r]) : 0.0f;
+        }
+        // ---- the other operand of the second product: columns 4*l31 .. +3 of other row row(r, half) = 8 bytes of logical chunk l31 >> 1
+        i32x2 bld[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tr = acc_row(r, lane);
+            bld[r] = *reinterpret_cast<const i32x2 *>(tile + slab_swizzled_off(tr, l31 >> 1) + (l31 & 1) * 8);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ah, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float hi = round_finite<DT>(w[8 * kk + e]);
+                const float lo = round_finite<DT>(w[8 * kk + e] - hi);
+                if constexpr (F16) {
+                    ah[e] = __builtin_bit_cast(short, (_Float16)hi);
+                    al[e] = __builtin_bit_cast(short, (_Float16)lo);
+                } else {
+                    ah[e] = (short)(__float_as_uint(hi) >> 16);
+                    al[e] = (short)(__float_as_uint(lo) >> 16);
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < kSmoothCB; ++cb) {
+                bf16x8 bo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bo[e] = (short)((uint32_t)bld[8 * kk + e][cb >> 1] >> ((cb & 1) * 16));
+                acc2[cb] = mfma32<F16>(ah, bo, acc2[cb]);
+                acc2[cb] = mfma32<F16>(al, bo, acc2[cb]);
+            }
+        }
+        cur = nxt;
+        slot ^= 1;
+    }
+
+    // ---- fixed-order reduction over the waves through the (now idle) tile slots, then store
+    __syncthreads();
+    float(*red)[kSmoothCB][16][64] = reinterpret_cast<float(*)[kSmoothCB][16][64]>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int cb = 0; cb < kSmoothCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][cb][r][lane] = acc2[cb][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const size_t rows_total = DQ ? (size_t)a.n_q * a.Lq : (size_t)d_off[a.n_d];
+        float *dst = out + (size_t)split * rows_total * kDim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 v;
+#pragma unroll
+            for (int cb = 0; cb < kSmoothCB; ++cb) {
+                float x = acc2[cb][r];
+#pragma unroll
+                for (int w2 = 0; w2 < NW - 1; ++w2) x += red[w2][cb][r][lane];
+                v[cb] = x;
+            }
+            const int orow_out = acc_row(r, lane);
+            if (orow_out < own_rows) {
+                const size_t base_row = DQ ? (size_t)own * a.Lq : (size_t)d_off[own];
+                *reinterpret_cast<f32x4 *>(dst + (base_row + own_tile * 32 + orow_out) * kDim + col0) = v;
+            }
+        }
+    }
+}
+
 // out[i] = sum_{s < n_split} partial[s][i] in split order (the deterministic second pass of the dQ pair-list split)
 __global__ __launch_bounds__(256) void smooth_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out, long long n,
                                                             int n_split) {
