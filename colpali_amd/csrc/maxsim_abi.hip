@@ -129,10 +129,10 @@ int stream_nt() {
     return v;
 }
 
-template <int QT, int TPQ, bool F16, int AUX, bool IL>
+template <int QT, int TPQ, bool F16, int AUX, bool IL, int RING = kStreamRing>
 int launch_stream_aux(const FwdCall &c) {
-    auto kern = msim::maxsim_stream_kernel<QT, TPQ, kStreamRing, F16, AUX, IL>;
-    constexpr int lds = 4 * kStreamRing * msim::kSlabBytes;
+    auto kern = msim::maxsim_stream_kernel<QT, TPQ, RING, F16, AUX, IL>;
+    constexpr int lds = 4 * RING * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     msim::StreamArgs a;
@@ -163,6 +163,13 @@ int stream_il() {
 
 template <int QT, int TPQ, bool F16>
 int launch_stream(const FwdCall &c) {
+    // 3-4 token tiles: a 2-slab ring (64 KiB per workgroup) lets TWO workgroups share a CU -- two waves per SIMD, one covering the
+    // other's DMA issue / operand reads / max folds: 4 queries 6.51-6.55 -> 6.82 TB/s (85 % of spec); 1-2 tiles are at the stream
+    // ceiling either way, 5+ tiles need more than 256 registers per wave (one wave per SIMD) and keep the deeper ring.
+    // MSIM_STREAM_RING=2|4 forces one of them (tuning knob, not part of the ABI).
+    static const int ring_env = getenv("MSIM_STREAM_RING") ? atoi(getenv("MSIM_STREAM_RING")) : 0;
+    const int ring = ring_env ? ring_env : ((QT == 3 || QT == 4) ? 2 : kStreamRing);
+    if (ring == 2) return launch_stream_aux<QT, TPQ, F16, 2, true, 2>(c);
     if (stream_il() && stream_nt()) return launch_stream_aux<QT, TPQ, F16, 2, true>(c);
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
