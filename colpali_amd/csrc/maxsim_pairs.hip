@@ -22,7 +22,7 @@
 
 namespace msim {
 
-constexpr int kPairsRing = 4;
+constexpr int kPairsRing = 2;
 
 struct PairsArgs {
     int n_q, Lq, n_d, n_pairs;
