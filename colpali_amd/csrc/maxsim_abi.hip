@@ -116,7 +116,7 @@ struct FwdCall {
     hipStream_t st;
 };
 
-constexpr int kStreamRing = 4;  // slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup
+constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup (launch_stream picks 2 for 3-4 tiles)
 
 // Cache policy of K1s's document stream: every byte is read once by one CU, so the LDS-DMA loads carry `nt`
 // (do not allocate in L2 / MALL).  Measured on MI355X, 16 GiB shard: 6.31 -> 7.02 TB/s at 1 query, 6.08 -> 6.45 TB/s

@@ -1,5 +1,5 @@
 // K1s -- "stream" MaxSim kernel for gfx950 (MI355X), the HBM-bound regime:
-// a handful of queries (<= 4 token tiles of 32 tokens) scored against a large
+// a handful of queries (<= 8 token tiles of 32 tokens) scored against a large
 // resident corpus.  Every byte of the corpus is read from HBM exactly once.
 //
 // Reference arithmetic replaced (no [b,c,n,s] tensor is ever materialised):
@@ -10,7 +10,8 @@
 //   * the query token tiles live in registers for the whole kernel as the MFMA
 //     B operand (32 VGPRs per 32-token tile);
 //   * each wave walks its own documents; a document is streamed in 32-patch
-//     slabs (8 KiB) into a wave-private LDS ring by LDS-DMA
+//     slabs (8 KiB) into a wave-private LDS ring (RING slabs: 4, or 2 for 3-4 token tiles
+//     so that two workgroups share a CU -- see launch_stream in maxsim_abi.hip) by LDS-DMA
 //     (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, fully
 //     coalesced, bounds-checked by a per-document buffer descriptor);
 //   * the slab image is XOR-swizzled on the SOURCE address so the ds_read_b128
