@@ -140,3 +140,42 @@ def test_loss_oracle_equals_the_live_reference_modules(c):
     assert torch.all(((dq.float() - q.grad) * mask).abs() <= tol_q)
     if not (c["pad_queries"] and c["Lq"] > 1 and not c["use_smooth_max"]):
         assert torch.all((dd.float() - d.grad).abs() <= tol_d)
+
+
+neg_case = st.fixed_dictionaries({
+    "seed": st.integers(0, 2**31 - 1),
+    "kind": st.sampled_from(["negative_ce", "pairwise_negative_ce"]),
+    "B": st.integers(2, 4),
+    "n_neg": st.integers(1, 3),
+    "Lq": st.integers(1, 4),
+    "Ld": st.integers(1, 6),
+    "Ln": st.integers(1, 5),
+    "normalize_scores": st.booleans(),
+    "use_smooth_max": st.booleans(),
+    "in_batch_term_weight": st.sampled_from([0.0, 0.3, 0.5]),
+})
+_NEG_CLS = {"negative_ce": "ColbertNegativeCELoss", "pairwise_negative_ce": "ColbertPairwiseNegativeCELoss"}
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(neg_case)
+def test_explicit_negative_loss_oracle_equals_the_live_reference_modules(c):
+    """late_interaction_losses.py:167-252 / :316-398 (paired contractions "bnd,bsd->bns" and "bnd,blsd->blns")."""
+    _, L = refimport.load()
+    g = torch.Generator().manual_seed(c["seed"])
+    B, dim = c["B"], 8
+    Q = torch.nn.functional.normalize(torch.randn(B, c["Lq"], dim, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(B, c["Ld"], dim, generator=g), dim=-1)
+    N = torch.nn.functional.normalize(torch.randn(B, c["n_neg"], c["Ln"], dim, generator=g), dim=-1)
+    kw = dict(normalize_scores=c["normalize_scores"], use_smooth_max=c["use_smooth_max"],
+              in_batch_term_weight=c["in_batch_term_weight"])
+    q, d, n = (t.clone().requires_grad_(True) for t in (Q, D, N))
+    want = getattr(L, _NEG_CLS[c["kind"]])(**kw)(q, d, n)
+    want.backward()
+    loss, dq, dd, dn = lo.negatives_loss_and_grads(c["kind"], Q, D, N, **kw)
+    w = float(want.detach())
+    assert abs(float(loss) - w) <= 2e-5 * max(1.0, abs(w))
+    for got, ref in ((dq, q.grad), (dd, d.grad), (dn, n.grad)):
+        ref = ref if ref is not None else torch.zeros_like(got, dtype=torch.float32)
+        tol = 2e-4 * ref.abs() + 2e-6 * max(1.0, float(ref.abs().max()))
+        assert torch.all((got.float() - ref).abs() <= tol)
