@@ -179,3 +179,29 @@ def test_explicit_negative_loss_oracle_equals_the_live_reference_modules(c):
         ref = ref if ref is not None else torch.zeros_like(got, dtype=torch.float32)
         tol = 2e-4 * ref.abs() + 2e-6 * max(1.0, float(ref.abs().max()))
         assert torch.all((got.float() - ref).abs() <= tol)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Token pooling: oracle/pooling_oracle.py (a restatement of SciPy's Ward NN-chain / fcluster) against the live reference pooler
+from oracle import pooling_oracle as po  # noqa: E402
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(st.integers(0, 2**31 - 1), st.integers(2, 40), st.sampled_from([8, 32]), st.sampled_from([1, 2, 3, 5]), st.booleans())
+def test_pooling_oracle_equals_the_live_reference_pooler(seed, n, dim, pool_factor, duplicates):
+    """hierarchical_token_pooling.py:83-146 on random pages, including pages with repeated rows (exact distance ties)."""
+    Pooler = refimport.load_token_pooler()
+    g = torch.Generator().manual_seed(seed)
+    e = torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=-1)
+    if duplicates and n >= 4:
+        e[n // 2] = e[0]
+        e[-1] = e[1]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # SciPy's "looks like an uncondensed distance matrix": the reference passes one on purpose
+        want_pooled, want_map = Pooler()._pool_single_embedding(e, pool_factor)
+    got_pooled, got_map = po.pool_single_embedding(e.numpy(), pool_factor)
+    assert sorted(got_map) == sorted(want_map)
+    for c in want_map:
+        np.testing.assert_array_equal(np.sort(np.asarray(got_map[c])), np.sort(want_map[c][0].numpy()), err_msg=f"cluster {c}")
+    np.testing.assert_allclose(got_pooled, want_pooled.numpy(), rtol=2e-6, atol=1e-7)
