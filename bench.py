@@ -1,8 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- MaxSim (query, doc) pairs scored per second on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` (N>1 is launched through
-torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL.  Either the caller launches the ranks (torch.distributed.run: WORLD_SIZE
+/ RANK / LOCAL_RANK in the environment) or -- when `--gpus N` is given without a launcher -- this file re-executes
+itself under `python -m torch.distributed.run --nproc-per-node N` (launch_ranks below).  It refuses to run N ranks
+on fewer than N visible GPUs (exit code 2) unless BENCH_SHARE_GPU=1 is set, which is a plumbing check, never a
+measurement.  The N > 1 line carries `rccl_ranks` (an all-reduce of 1 over the process group) and every rank's
+kernel time, so a run that silently degraded to fewer ranks cannot pass for a scaling point.
 
 Workload (BASELINE.json: "MaxSim (query,doc) pairs scored/sec; achieved HBM GB/s vs peak",
 synthetic 32-token-query x 1024-patch-doc x d=128): every rank holds a resident shard of a
@@ -77,27 +82,13 @@ def make_queries(n_q, q_len, device, seed):
     return q.to(device)
 
 
-def parity_sample(q, corpus, scores, n_sample=48):
-    """Re-score a random sample of the shard's documents with the CPU oracle."""
-    from oracle import maxsim_oracle as mo
-
-    n = len(corpus)
-    idx = torch.randperm(n, generator=torch.Generator().manual_seed(7))[:n_sample].tolist()
-    L = int(corpus.lengths[0])
-    docs = [corpus.blob[i * L : (i + 1) * L].float().cpu().numpy() for i in idx]
-    want = mo.score_multi_vector([x.float().cpu().numpy() for x in q], docs, batch_size=10**9, mode="f32")
-    got = scores[:, idx].float().cpu().numpy()
-    import numpy as np
-
-    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
-
-
 def cpu_baseline(q_len, doc_len):
-    """Reference CPU scorer (torch port) on a bounded sample: 32 queries x 512 docs, bf16 and fp32."""
+    """Reference CPU scorer (torch port of processing_utils.py:163-186) on the slice SURVEY 8(d) names: 128 queries x 1024
+    docs (131 072 pairs, one 128 x 128 block row of the reference's blocking x 8), bf16 and fp32 inputs, best of 2."""
     from oracle import torch_port
 
     g = torch.Generator().manual_seed(11)
-    n_q, n_d = 32, 512
+    n_q, n_d = 128, 1024
     qs = [torch.nn.functional.normalize(torch.randn(q_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_q)]
     ps = [torch.nn.functional.normalize(torch.randn(doc_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_d)]
     best = {}
@@ -105,7 +96,7 @@ def cpu_baseline(q_len, doc_len):
         a, b = [cast(t) for t in qs], [cast(t) for t in ps]
         torch_port.score_multi_vector_cpu(a[:4], b[:16])
         ts = []
-        for _ in range(3):
+        for _ in range(2):
             t0 = time.perf_counter()
             torch_port.score_multi_vector_cpu(a, b)
             ts.append(time.perf_counter() - t0)
@@ -114,8 +105,8 @@ def cpu_baseline(q_len, doc_len):
     return {
         "value": best[kind], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": f"{n_q} queries x {n_d} docs ({q_len}x128 vs {doc_len}x128), reference blocking batch_size=128, "
-                  f"best of 3, torch CPU einsum/max/sum; bf16 inputs {best['bf16']:.0f} pairs/s, fp32 inputs {best['fp32']:.0f} pairs/s",
-        "host_cpus": os.cpu_count(),
+                  f"best of 2, torch CPU einsum/max/sum; bf16 inputs {best['bf16']:.0f} pairs/s, fp32 inputs {best['fp32']:.0f} pairs/s",
+        "host_cpus": os.cpu_count(), "torch_num_threads": torch.get_num_threads(),
     }
 
 
@@ -178,8 +169,24 @@ def dropin_numbers(amd):
 
         ours = timed(lambda: amd.score_multi_vector(qs, ps, device="cuda:0"), 5)
         ref = timed(lambda: torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0"), 3)
+        # parity of the two results that were just timed: ours (fp32-accurate scores of the bf16 inputs) against the
+        # reference's own torch calls on this GPU -- on fp32 upcasts of the same inputs (its truth tier) and on the raw bf16
+        # tensors (its literal tier: every similarity and the sum rounded to bf16, SURVEY finding 3)
+        got = amd.score_multi_vector(qs, ps, device="cuda:0")
+        ref32 = torch_port.score_multi_vector_cpu([t.float() for t in qs], [t.float() for t in ps], device="cuda:0")
+        ref16 = torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0")
+        rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1.0)).max())   # noqa: E731
+        e32, e16 = rel(got, ref32), rel(got, ref16)
+        k = 10
+        same_top = float((got.topk(k, dim=1).indices == ref32.topk(k, dim=1).indices).all(dim=1).float().mean())
+        if e32 > 1e-3:
+            raise SystemExit(f"drop-in result differs from the reference's fp32 scorer on this GPU: max rel err {e32}")
         out[name] = {"pairs": 100 * len(ps), "ms": ours * 1e3, "pairs_per_s": 100 * len(ps) / ours,
-                     "reference_on_this_gpu_ms": ref * 1e3, "speedup_vs_reference_on_this_gpu": ref / ours}
+                     "reference_on_this_gpu_ms": ref * 1e3, "speedup_vs_reference_on_this_gpu": ref / ours,
+                     "max_rel_err_vs_reference_fp32_on_this_gpu": e32, "max_rel_err_vs_reference_bf16_on_this_gpu": e16,
+                     "frac_queries_with_identical_top10_vs_reference_fp32": same_top}
+    out["device_note"] = ("BASELINE config 1 reads 'on CPU'; colpali_amd has no CPU path by design, so configs 1-3 are run with "
+                          "device='cuda:0' and return the reference's CPU fp32 tensor")
     return out
 
 
@@ -216,7 +223,8 @@ def embed_head_numbers(amd, dev):
 
 
 def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
-    """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list)."""
+    """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list, the last
+    step's score matrix, the last step's (top scores, top ids))."""
     dev = q.device
     scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=dev)
 
@@ -226,17 +234,18 @@ def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
         amd.maxsim_scores(q, corpus, out=scores)
         if ev is not None:
             ev[1].record()
-        return amd.shard_topk(scores, topk, corpus.id_base, world, dist) if hasattr(amd, "shard_topk") else None
+        return amd.shard_topk(scores, topk, corpus.id_base, world, dist)
 
+    top = None
     for _ in range(warmup):
-        step()
+        top = step()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(evs[i])
+        top = step(evs[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -246,7 +255,7 @@ def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = [a.elapsed_time(b) for a, b in evs]
-    return dt, kern_ms, scores
+    return dt, kern_ms, scores, top
 
 
 def pmc_traffic(n_q, n_docs, doc_len):
@@ -273,7 +282,9 @@ def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg):
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
     else:
         roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
-    roof.update({"traffic": pmc_traffic(n_q, n_docs, doc_len), "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
+    roof.update({"traffic": pmc_traffic(n_q, n_docs, doc_len),
+                 "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this workload; not re-measured in this run)",
+                 "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
                  "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops,
                  "hbm_gbs": gbs, "mfma_tflops": tf})
     return roof
@@ -302,19 +313,98 @@ def stream_ceiling(amd, corpus):
             "K1s' loads without its arithmetic"}
 
 
+def topk_parity(amd, q, corpus, scores, top_s, top_i, k, n_queries=2, n_random=1000):
+    """SURVEY 8(d) C4-ii on this rank's shard: for `n_queries` sampled queries re-score the returned per-shard top-k plus
+    `n_random` random documents with the CPU oracle (truth tier: fp32 inputs, double accumulate) and compare rankings.
+
+    `ids_equal`: at every rank r the oracle score of the returned id equals the r-th best oracle score of the candidate set
+    within twice the measured score error (a different id is only accepted between documents the two computations cannot
+    tell apart); `ids_exact_equal`: the id lists are identical to the oracle's (score desc, id asc) ranking."""
+    import numpy as np
+
+    from oracle import maxsim_oracle as mo
+    from oracle import topk_oracle
+
+    n = len(corpus)
+    gq = torch.Generator().manual_seed(17)
+    qsel = torch.randperm(q.shape[0], generator=gq)[:n_queries].tolist()
+    off = corpus.offsets.cpu().numpy().astype(np.int64)
+    ids_equal, exact, max_err, n_cand = True, True, 0.0, 0
+    for qi in qsel:
+        ret = top_i[qi].cpu().numpy()
+        ret_local = ret[ret >= 0] - corpus.id_base
+        rnd = torch.randperm(n, generator=gq)[:n_random].numpy()
+        cand = np.unique(np.concatenate([ret_local, rnd]))            # sorted local ids
+        docs = [corpus.blob[int(off[c]):int(off[c + 1])].float().cpu().numpy() for c in cand]
+        want = mo.score_multi_vector([q[qi].float().cpu().numpy()], docs, batch_size=10**9, mode="f32")[0]
+        got = scores[qi, torch.from_numpy(cand).to(scores.device)].float().cpu().numpy()
+        err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
+        max_err = max(max_err, err)
+        kk = int(min(k, len(ret_local)))
+        # the returned list must be the top-k of the candidate set (every returned id is in it; a random non-returned
+        # document that out-scores a returned one is a ranking error)
+        _, w_ids = topk_oracle.topk(want[None, :], kk, ids=(cand + corpus.id_base)[None, :])
+        exact = exact and bool(np.array_equal(w_ids[0], ret[:kk]))
+        order = np.argsort(-want, kind="stable")[:kk]
+        pos = np.searchsorted(cand, ret_local[:kk])
+        tol = 2.0 * err + 1e-7
+        ids_equal = ids_equal and bool(np.all(np.abs(want[pos] - want[order]) <= tol * np.maximum(np.abs(want[order]), 1.0)))
+        n_cand += len(cand)
+    return {"checked_queries": len(qsel), "candidates_rescored": n_cand, "k": k, "ids_equal": ids_equal,
+            "ids_exact_equal": exact, "max_rel_err": max_err,
+            "what": "returned top-k + random docs of this rank's shard re-scored by the CPU oracle (fp32 inputs, double "
+                    "accumulate); ids_equal tolerates swaps only between docs closer than 2 x max_rel_err"}
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n_gpus):
+    """`--gpus N` without a launcher: run N ranks of this file under torch.distributed.run (one per GPU, RCCL) and forward
+    rank 0's JSON line.  Refuses (exit code 2) when fewer than N GPUs are visible, unless BENCH_SHARE_GPU=1."""
+    import subprocess
+
+    visible = torch.cuda.device_count()
+    if visible < n_gpus and os.environ.get("BENCH_SHARE_GPU") != "1":
+        sys.stderr.write(f"bench.py: --gpus {n_gpus} requested but only {visible} GPU(s) are visible; refusing to run "
+                         f"{n_gpus} ranks on fewer devices (set BENCH_SHARE_GPU=1 for a plumbing-only run)\n")
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # BENCH_SHARE_GPU=1 + BENCH_DIST_BACKEND=gloo: plumbing test of the N>1 path on a 1-GPU box (not a measurement)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start one rank per GPU")
+    # BENCH_SHARE_GPU=1 (+ BENCH_DIST_BACKEND=gloo): plumbing test of the N>1 path on a 1-GPU box (not a measurement)
     share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: no GPU is visible to torch (there is no CPU fallback)")
+    if world > n_dev and not share_gpu:
+        raise SystemExit(f"{world} ranks but only {n_dev} visible GPU(s) (BENCH_SHARE_GPU=1 allows it for plumbing checks only)")
+    dev_index = local_rank % n_dev if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist  # "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -332,7 +422,7 @@ def main():
     q = make_queries(args.nq, args.q_len, dev, seed=99)
     torch.cuda.synchronize()
 
-    dt, kern_ms, scores = run_regime(amd, q, corpus, args.steps, args.warmup, args.topk, world, rank, dist)
+    dt, kern_ms, scores, top = run_regime(amd, q, corpus, args.steps, args.warmup, args.topk, world, rank, dist)
     kern_avg = sum(kern_ms) / len(kern_ms)
     pairs_per_step = args.nq * args.docs * world
     out = {
@@ -357,14 +447,61 @@ def main():
         },
         "roofline": regime_numbers(args.nq, args.q_len, args.docs, args.doc_len, kern_avg),
     }
+    if world > 1:
+        # proof that the collective really spans `world` ranks, and every rank's own kernel time
+        ones = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        out["rccl_ranks"] = int(ones.item())
+        out["dist_backend"] = "rccl (torch 'nccl')" if backend == "nccl" else backend
+        mine = torch.tensor([kern_avg, float(dev_index)], dtype=torch.float64, device=ones.device)
+        allk = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        out["per_rank_kernel_ms"] = [float(t[0]) for t in allk]
+        out["per_rank_device_index"] = [int(t[1]) for t in allk]
+        out["gpus_visible_per_rank"] = n_dev
+        out["shared_gpu_plumbing_run"] = bool(share_gpu)
+        out["launched_by"] = "bench.py (self-spawned torch.distributed.run)" if os.environ.get("BENCH_SELF_LAUNCHED") else "external launcher"
+        if out["rccl_ranks"] != args.gpus:
+            raise SystemExit(f"process group spans {out['rccl_ranks']} ranks, --gpus {args.gpus} requested")
     if corpus.blob.shape[1] == 128:
         ceil_ = stream_ceiling(amd, corpus)
         out["roofline"]["stream_ceiling_gbs"] = ceil_["gbs"]
         out["roofline"]["stream_ceiling_what"] = ceil_["what"]
         if out["roofline"]["bound"] == "hbm":
             out["roofline"]["frac_of_stream_ceiling"] = out["roofline"]["achieved"] / ceil_["gbs"]
-    if rank == 0 and not args.no_parity:
-        out["parity_max_rel_err_vs_oracle_sample"] = parity_sample(q, corpus, scores)
+    if not args.no_parity:
+        # every rank checks its own shard (the CPU oracle as the checker); the verdicts are combined below
+        local_top = amd.topk(scores, args.topk, corpus.id_base)
+        par = topk_parity(amd, q, corpus, scores, local_top[0], local_top[1], args.topk)
+        par100 = topk_parity(amd, q, corpus, scores, *amd.topk(scores, 100, corpus.id_base), 100, n_queries=1)
+        par["k100"] = {k_: par100[k_] for k_ in ("checked_queries", "ids_equal", "ids_exact_equal", "max_rel_err")}
+        if world > 1:
+            flags = torch.tensor([int(par["ids_equal"]), int(par["ids_exact_equal"]), int(par100["ids_equal"]),
+                                  int(par100["ids_exact_equal"])], dtype=torch.int32, device=ones.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            err = torch.tensor([max(par["max_rel_err"], par100["max_rel_err"])], dtype=torch.float64, device=ones.device)
+            dist.all_reduce(err, op=dist.ReduceOp.MAX)
+            par["ids_equal"], par["ids_exact_equal"] = bool(flags[0]), bool(flags[1])
+            par["k100"]["ids_equal"], par["k100"]["ids_exact_equal"] = bool(flags[2]), bool(flags[3])
+            par["max_rel_err"] = float(err.item())
+            # the merge: the global list every rank holds must be the (score desc, id asc) top-k of the gathered local lists
+            from oracle import topk_oracle
+
+            msg = torch.cat([local_top[0].double().reshape(-1), local_top[1].double().reshape(-1)]).to(ones.device)
+            allm = [torch.empty_like(msg) for _ in range(world)]
+            dist.all_gather(allm, msg)
+            nk = args.nq * args.topk
+            cs = torch.stack([m[:nk].view(args.nq, args.topk) for m in allm], 1).reshape(args.nq, -1).float().cpu().numpy()
+            ci = torch.stack([m[nk:].view(args.nq, args.topk) for m in allm], 1).reshape(args.nq, -1).long().cpu().numpy()
+            ws, wi = topk_oracle.topk(cs, args.topk, ids=ci)
+            ok = bool((wi == top[1].cpu().numpy()).all() and (ws == top[0].cpu().numpy()).all())
+            okt = torch.tensor([int(ok)], dtype=torch.int32, device=ones.device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            par["merge_equals_oracle_merge_on_all_ranks"] = bool(okt.item())
+            par["ranks_checked"] = world
+        if rank == 0:
+            out["topk_parity"] = par
+            out["parity_max_rel_err_vs_oracle_sample"] = par["max_rel_err"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
         out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)
@@ -376,7 +513,7 @@ def main():
     for nq in [int(x) for x in args.regimes.split(",") if x]:
         qq = make_queries(nq, args.q_len, dev, seed=5 + nq)
         steps = max(3, min(args.steps, 2000 // max(nq, 1)))
-        d, km, _ = run_regime(amd, qq, corpus, steps, 2, args.topk, world, rank, dist)
+        d, km, _, _ = run_regime(amd, qq, corpus, steps, 2, args.topk, world, rank, dist)
         r = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(km) / len(km))
         regimes.append({"n_queries": nq, "steps": steps, "pairs_per_s": nq * args.docs * world * steps / d,
                         "ms_per_step": d / steps * 1e3, "kernel_ms": r["kernel_ms"], "bound": r["bound"],
@@ -385,7 +522,7 @@ def main():
     out["regimes"] = regimes
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

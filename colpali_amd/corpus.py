@@ -93,16 +93,30 @@ def _copy_pool():
     return _pool
 
 
-class _Staging:
-    """One reusable pinned host buffer for the drop-in's host -> device upload (grown on demand, never shrunk).
+STAGING_BYTES = int(os.environ.get("COLPALI_AMD_STAGING_MB", "512")) << 20     # pinned host memory per staging buffer (two halves)
 
-    Pinning memory costs ~0.1 s per call at this size, so the buffer is kept; an event recorded behind the asynchronous
-    H2D copy guards its reuse."""
+
+class _Staging:
+    """Bounded, reusable pinned host buffer for the drop-in's host -> device upload.
+
+    The passages are memcpy'd into one half of the buffer while the other half is on its way to the GPU (asynchronous H2D
+    into the preallocated device blob), so the pinned memory this process holds is STAGING_BYTES whatever the corpus size
+    -- the reference's own footprint is O(batch) too (processing_utils.py:175-178).  Pinning costs ~0.1 s per call at this
+    size, so the buffer is kept; an event per half guards its reuse."""
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
-        self.event = None
+        self.events = [None, None]
         self.lock = threading.Lock()
+
+    def _halves(self, want: int):
+        half = max(min(want, STAGING_BYTES // 2), 1 << 20)
+        if self.buf is None or self.buf.numel() < 2 * half:
+            for ev in self.events:
+                if ev is not None:
+                    ev.synchronize()
+            self.buf = torch.empty((2 * half,), dtype=torch.uint8, pin_memory=True)
+        return self.buf.numel() // 2
 
     def upload(self, ps: Sequence[torch.Tensor], dim: int, device: torch.device,
                slot_rows: Optional[int] = None) -> torch.Tensor:
@@ -112,40 +126,60 @@ class _Staging:
         es = ps[0].element_size()
         total = sum(int(p.shape[0]) for p in ps) if slot_rows is None else len(ps) * slot_rows
         nbytes = total * dim * es
+        dev = torch.empty((total, dim), dtype=dtype, device=device)
+        if nbytes == 0:
+            return dev
+        dev_bytes = dev.view(torch.uint8).view(-1)
         with self.lock:
-            if self.event is not None:
-                self.event.synchronize()           # the previous upload has left the buffer
-            if self.buf is None or self.buf.numel() < nbytes:
-                self.buf = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, pin_memory=True)
+            half = self._halves(nbytes)
             base = self.buf.data_ptr()
-            # plain memcpy per passage (no tensor-op dispatch); ctypes releases the GIL inside memmove, so a few threads
-            # copy disjoint runs of passages in parallel -- one thread moves ~6 GB/s, the upload that follows 50+
-            jobs = []
+            # (destination offset in the image, source pointer, bytes, keep-alive) per passage, split at chunk borders so that
+            # every chunk fits one half of the staging buffer
+            pieces = []
             o = 0
-            if slot_rows is not None:
-                ctypes.memset(base, 0, nbytes)
             for p in ps:
                 n = int(p.shape[0]) * dim * es
                 if n:
                     src = p if p.is_contiguous() else p.contiguous()
-                    jobs.append((base + o, src.data_ptr(), n, src))   # src kept alive until the copy is done
+                    sp, done = src.data_ptr(), 0
+                    while done < n:
+                        room = half - ((o + done) % half)
+                        take = min(room, n - done)
+                        pieces.append((o + done, sp + done, take, src))
+                        done += take
                 o += n if slot_rows is None else slot_rows * dim * es
-            n_thr = min(_COPY_THREADS, max(1, nbytes >> 22))           # below ~4 MiB per thread it is not worth a hand-off
-            if n_thr <= 1 or len(jobs) < 2 * n_thr:
-                for dst, srcp, n, _ in jobs:
-                    ctypes.memmove(dst, srcp, n)
-            else:
-                def run(chunk):
-                    for dst, srcp, n, _ in chunk:
-                        ctypes.memmove(dst, srcp, n)
-                per = (len(jobs) + n_thr - 1) // n_thr
-                futures = [_copy_pool().submit(run, jobs[k : k + per]) for k in range(0, len(jobs), per)]
-                for f in futures:
-                    f.result()
-            host = self.buf[:nbytes].view(dtype).view(total, dim)
-            dev = host.to(device, non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record(torch.cuda.current_stream(device))
+            stream = torch.cuda.current_stream(device)
+            k = 0
+            for c0 in range(0, nbytes, half):
+                c1 = min(nbytes, c0 + half)
+                h = (c0 // half) & 1
+                hb = base + h * half
+                if self.events[h] is not None:
+                    self.events[h].synchronize()          # the previous upload has left this half
+                if slot_rows is not None:
+                    ctypes.memset(hb, 0, c1 - c0)
+                jobs = []
+                while k < len(pieces) and pieces[k][0] < c1:
+                    dst_off, sp, n, keep = pieces[k]
+                    jobs.append((hb + (dst_off - c0), sp, n, keep))
+                    k += 1
+                # plain memcpy per passage (no tensor-op dispatch); ctypes releases the GIL inside memmove, so a few threads
+                # copy disjoint runs of passages in parallel -- one thread moves ~6 GB/s, the upload that follows 50+
+                n_thr = min(_COPY_THREADS, max(1, (c1 - c0) >> 22))       # below ~4 MiB per thread it is not worth a hand-off
+                if n_thr <= 1 or len(jobs) < 2 * n_thr:
+                    for dst, sp, n, _ in jobs:
+                        ctypes.memmove(dst, sp, n)
+                else:
+                    def run(chunk):
+                        for dst, sp, n, _ in chunk:
+                            ctypes.memmove(dst, sp, n)
+                    per = (len(jobs) + n_thr - 1) // n_thr
+                    futures = [_copy_pool().submit(run, jobs[j : j + per]) for j in range(0, len(jobs), per)]
+                    for f in futures:
+                        f.result()
+                dev_bytes[c0:c1].copy_(self.buf[h * half : h * half + (c1 - c0)], non_blocking=True)
+                self.events[h] = torch.cuda.Event()
+                self.events[h].record(stream)
         return dev
 
 

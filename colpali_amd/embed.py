@@ -127,9 +127,14 @@ class CorpusWriter:
         if hidden_states.dtype != self.blob.dtype or hidden_states.device != self.device:
             raise ValueError("hidden states must have the writer's dtype and device")
         B, S, _ = hidden_states.shape
+        if self._rows_upper + B * S > self.capacity:
+            # the bound counts masked positions too (no sync per append); reconcile it with the exact device-side count once
+            # before refusing -- a rejected append leaves the writer unchanged
+            self._rows_upper = self.rows_written()
+            if self._rows_upper + B * S > self.capacity:
+                raise RuntimeError(f"CorpusWriter capacity of {self.capacity} rows exceeded: {self._rows_upper} rows written, "
+                                   f"the batch may add up to {B * S}")
         self._rows_upper += B * S
-        if self._rows_upper > self.capacity:
-            raise RuntimeError(f"CorpusWriter capacity of {self.capacity} rows exceeded (upper bound {self._rows_upper})")
         keep = attention_mask != 0
         if extra_mask is not None:
             keep = keep & (extra_mask.reshape(B, S) != 0)
@@ -146,6 +151,11 @@ class CorpusWriter:
         self._counts.append(counts)
         self._padded_lens.append(torch.full((B,), S, dtype=torch.int64))
         return B
+
+    def rows_written(self) -> int:
+        """Exact number of rows written so far (one host synchronisation); also tightens the host-side bound."""
+        self._rows_upper = int(self._rows_dev.item())
+        return self._rows_upper
 
     def finish(self, id_base: int = 0) -> PackedCorpus:
         """One host synchronisation (the page lengths are needed on the host for the block flags)."""

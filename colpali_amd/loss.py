@@ -162,13 +162,31 @@ class _MaxSimPairs(torch.autograd.Function):
                 dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
 
 
-def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, pairs: torch.Tensor) -> torch.Tensor:
+def _check_pairs(pairs: torch.Tensor, B: int, C: int) -> None:
+    """Range check of a caller-supplied pair list (one host sync): the kernels index Q, D and the routing with these numbers."""
+    if pairs.dim() != 2 or pairs.shape[1] != 2 or pairs.dtype != torch.int32 or not pairs.is_contiguous():
+        raise ValueError("pairs must be a contiguous int32 [n_pairs, 2] tensor of (query, doc) indices")
+    if pairs.shape[0] == 0:
+        return
+    lo = pairs.amin(dim=0).tolist()
+    hi = pairs.amax(dim=0).tolist()
+    if lo[0] < 0 or lo[1] < 0 or hi[0] >= B or hi[1] >= C:
+        raise ValueError(f"pairs index outside [0, {B}) x [0, {C}): queries {lo[0]}..{hi[0]}, docs {lo[1]}..{hi[1]}")
+    if pairs.shape[0] > 1 and bool((pairs[1:, 0] < pairs[:-1, 0]).any()):
+        raise ValueError("pairs must be sorted by query index")
+
+
+def maxsim_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, pairs: torch.Tensor,
+                  validate: bool = True) -> torch.Tensor:
     """Differentiable MaxSim of listed (query, doc) pairs: fp32 [n_pairs].  `pairs` int32 [n,2], sorted by query.
 
     Fused form of the paired contractions "bnd,bsd->bns" / "bnd,blsd->blns" followed by amax/sum
-    (late_interaction_losses.py:235-240, :381-386)."""
+    (late_interaction_losses.py:235-240, :381-386).  `validate=False` skips the range check of `pairs` (and its host
+    sync) for lists that are valid by construction."""
     query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
+    if validate:
+        _check_pairs(pairs, query_embeddings.shape[0], doc_embeddings.shape[0])
     return _MaxSimPairs.apply(_widen(query_embeddings), _widen(doc_embeddings), pairs)
 
 
@@ -314,10 +332,12 @@ def maxsim_smooth(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, 
 
 
 def maxsim_smooth_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, pairs: torch.Tensor,
-                         tau: float) -> torch.Tensor:
+                         tau: float, validate: bool = True) -> torch.Tensor:
     """Differentiable smooth-max score of listed (query, doc) pairs: fp32 [n_pairs]; `pairs` int32 [n,2] sorted by query."""
     query_embeddings, doc_embeddings = _autocast_inputs(query_embeddings, doc_embeddings)
     _check_embeddings(query_embeddings, doc_embeddings)
+    if validate:
+        _check_pairs(pairs, query_embeddings.shape[0], doc_embeddings.shape[0])
     return _MaxSimPairsSmooth.apply(_widen32(query_embeddings), _widen32(doc_embeddings), pairs, float(tau))
 
 
@@ -334,6 +354,20 @@ def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
             if d.dtype in (torch.float32, torch.bfloat16, torch.float16) and d.dtype != lowp:
                 d = d.to(lowp)
     return q, d
+
+
+def _loss_dtype(query_embeddings: torch.Tensor) -> torch.dtype:
+    """Dtype of the scalar the reference returns: the embeddings' own dtype (bf16 in -> bf16 loss), except
+    under torch.autocast, where its token sum / softplus / cross_entropy are autocast-to-fp32 ops and the loss is fp32."""
+    return torch.float32 if torch.is_autocast_enabled("cuda") else query_embeddings.dtype
+
+
+def _check_offset(B: int, C: int, offset: int) -> None:
+    """The reference fails on shapes when the positives [offset, offset + B) do not fit the C gathered documents
+    (`scores.diagonal(offset)` / `scores[idx, pos_idx]` / `doc_embeddings[offset:offset+B]`); say so instead of indexing
+    past the score matrix."""
+    if offset < 0 or offset + B > C:
+        raise IndexError(f"offset {offset} + batch {B} exceeds the {C} documents given (positives must lie in [offset, offset + B))")
 
 
 def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, dense_grad: bool = False) -> torch.Tensor:
@@ -384,6 +418,7 @@ class ColbertModule(torch.nn.Module):
 
     # -- shared front end of every in-batch loss: lengths, fused MaxSim, optional normalisation / filtering
     def _inbatch_scores(self, query_embeddings, doc_embeddings, offset, dense_grad=False):
+        _check_offset(query_embeddings.shape[0], doc_embeddings.shape[0], offset)
         lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)          # :296 -- first component, not a norm test
         if self.use_smooth_max:                                        # :88-89: tau * logsumexp(raw / tau) instead of amax
             scores = maxsim_smooth(query_embeddings, doc_embeddings, self.tau)
@@ -415,7 +450,7 @@ class ColbertPairwiseCELoss(ColbertModule):
         best2 = scores.topk(2, dim=1).values                            # :310
         neg = torch.where(best2[:, 0] == pos, best2[:, 1], best2[:, 0])  # :311 exact-equality selection
         loss = F.softplus((neg - pos) / self.temperature).mean()        # :313
-        return loss.to(query_embeddings.dtype)
+        return loss.to(_loss_dtype(query_embeddings))
 
 
 class ColbertLoss(ColbertModule):
@@ -433,7 +468,7 @@ class ColbertLoss(ColbertModule):
 
     def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
         scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset, dense_grad=True)
-        return self.ce_loss(scores / self.temperature, pos_idx).to(query_embeddings.dtype)   # :164
+        return self.ce_loss(scores / self.temperature, pos_idx).to(_loss_dtype(query_embeddings))   # :164
 
 
 class ColbertSigmoidLoss(ColbertModule):
@@ -455,7 +490,7 @@ class ColbertSigmoidLoss(ColbertModule):
         sign = -torch.ones(n * n, device=scores.device)                 # :457-459: +1 on the positives of the flattened square
         sign[pos_idx * (n + 1)] = 1.0
         flat = scores.view(-1) / self.temperature                       # :462 (requires C == B, like the reference)
-        return F.softplus(-flat * sign).mean().to(query_embeddings.dtype)
+        return F.softplus(-flat * sign).mean().to(_loss_dtype(query_embeddings))
 
 
 class _ExplicitNegativesMixin:
@@ -464,10 +499,13 @@ class _ExplicitNegativesMixin:
 
     def _explicit_negative_term(self, query_embeddings, doc_embeddings, neg_doc_embeddings, offset):
         if self.use_smooth_max:
-            paired = lambda q, d, pairs: maxsim_smooth_paired(q, d, pairs, self.tau)   # noqa: E731
+            paired = lambda q, d, pairs: maxsim_smooth_paired(q, d, pairs, self.tau, validate=False)   # noqa: E731
         else:
-            paired = maxsim_paired
+            paired = lambda q, d, pairs: maxsim_paired(q, d, pairs, validate=False)                    # noqa: E731
         B = query_embeddings.size(0)
+        _check_offset(B, doc_embeddings.shape[0], offset)
+        if neg_doc_embeddings.dim() != 4 or neg_doc_embeddings.size(0) != B:
+            raise ValueError("expected neg_doc_embeddings [B, n_neg, L_neg, dim] with the queries' batch size")
         n_neg = neg_doc_embeddings.size(1)
         dev = query_embeddings.device
         lengths = (query_embeddings[:, :, 0] != 0).sum(dim=1)
@@ -512,7 +550,7 @@ class ColbertNegativeCELoss(_ExplicitNegativesMixin, ColbertModule):
         if self.in_batch_term_weight > 0:                                                   # :248-250
             loss_ib = self.inner_loss(query_embeddings, doc_embeddings, offset).to(loss.dtype)
             loss = loss * (1 - self.in_batch_term_weight) + loss_ib * self.in_batch_term_weight
-        return loss.to(query_embeddings.dtype)
+        return loss.to(_loss_dtype(query_embeddings))
 
 
 class ColbertPairwiseNegativeCELoss(_ExplicitNegativesMixin, ColbertModule):
@@ -542,4 +580,4 @@ class ColbertPairwiseNegativeCELoss(_ExplicitNegativesMixin, ColbertModule):
         if self.in_batch_term_weight > 0:                                                   # :394-396
             loss_ib = self.inner_pairwise(query_embeddings, doc_embeddings, offset).to(loss.dtype)
             loss = loss * (1 - self.in_batch_term_weight) + loss_ib * self.in_batch_term_weight
-        return loss.to(query_embeddings.dtype)
+        return loss.to(_loss_dtype(query_embeddings))

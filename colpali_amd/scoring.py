@@ -9,6 +9,7 @@ All arithmetic runs in the hand-written gfx950 kernels behind the C ABI
 from __future__ import annotations
 
 import logging
+import os
 from typing import List, Optional, Union
 
 import torch
@@ -99,10 +100,46 @@ def score_multi_vector(
         raise ValueError("No passages provided")
     dev = _require_gpu(device)
     q = pack_queries(qs, dev)
-    corpus = pack_passages(ps, dev, batch_size=batch_size)
-    scores = maxsim_scores(q, corpus).cpu()
+    cols = []
+    for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
+        corpus = pack_passages(ps[lo:hi], dev, batch_size=batch_size)
+        cols.append(maxsim_scores(q, corpus).cpu())
+        del corpus
+    scores = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
     assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
     return scores.to(torch.float32)
+
+
+def _corpus_budget_bytes(dev: torch.device) -> int:
+    """Device memory one packed passage range may take: COLPALI_AMD_CORPUS_BUDGET_MB, else 60 % of the free HBM."""
+    mb = os.environ.get("COLPALI_AMD_CORPUS_BUDGET_MB")
+    if mb:
+        return int(mb) << 20
+    free, _ = torch.cuda.mem_get_info(dev)
+    return int(free * 0.6)
+
+
+def passage_ranges(ps, batch_size: int, budget_bytes: int):
+    """Contiguous passage ranges [lo, hi) whose packed rows fit `budget_bytes`, cut at multiples of `batch_size` so that
+    every passage keeps the block mates the reference pads it with (processing_utils.py:175-178).  A corpus that fits --
+    the normal case on 288 GB -- is one range: packed and uploaded once.  A single block above the budget is still one range
+    (the reference needs that block on the device too)."""
+    n = len(ps)
+    if isinstance(ps, torch.Tensor):
+        per = [ps.shape[1] * ps.shape[2] * ps.element_size()] * n
+    else:
+        per = [p.shape[0] * p.shape[1] * p.element_size() for p in ps]
+    if sum(per) <= budget_bytes:
+        return [(0, n)]
+    ranges, lo, acc = [], 0, 0
+    for b0 in range(0, n, batch_size):
+        blk = sum(per[b0 : b0 + batch_size])
+        if acc and acc + blk > budget_bytes:
+            ranges.append((lo, b0))
+            lo, acc = b0, 0
+        acc += blk
+    ranges.append((lo, n))
+    return ranges
 
 
 def similarity_matrix(a: torch.Tensor, b: torch.Tensor, *, ref_rounding: bool = False,

@@ -336,8 +336,62 @@ def pooling_golden():
     save("token_pooling.npz", **out)
 
 
+def planted_inputs(seed, n_q, Lq, n_d, Ld_lo, Ld_hi, n_planted, dim=128):
+    """Planted-retrieval inputs: unit-row random queries and documents; for every query `n_planted` documents
+    carry a noisy copy of each of its tokens at a random row.  The noise vector of planted copy j has norm 0.3 .. 0.75
+    (cosine 0.96 .. 0.80), so the planted documents out-score every random one (score ~ 9) by a wide margin and each other
+    by ~0.5: the top-`n_planted` ranking is decided far above any summation-order noise.  Regenerated from the seed by the
+    tests (tests/helpers.py:planted_inputs restates this function); the sha256 pins the torch RNG stream."""
+    g = torch.Generator().manual_seed(seed)
+    qs = [unit_rows(Lq, dim, g) for _ in range(n_q)]
+    lens = [Ld_lo] * n_d if Ld_lo == Ld_hi else torch.randint(Ld_lo, Ld_hi + 1, (n_d,), generator=g).tolist()
+    ps = [unit_rows(n, dim, g).float() for n in lens]
+    slots = torch.randperm(n_d, generator=g)[: n_q * n_planted].view(n_q, n_planted)
+    for qi in range(n_q):
+        for j in range(n_planted):
+            d = int(slots[qi, j])
+            sigma = 0.3 + 0.05 * j
+            noisy = F.normalize(qs[qi].float() + sigma * torch.randn(Lq, dim, generator=g) / dim**0.5, dim=-1)
+            rows = torch.randperm(lens[d], generator=g)[:Lq]
+            ps[d][rows] = noisy
+    ps = [p.to(torch.bfloat16) for p in ps]
+    return qs, ps, slots
+
+
+def topk_golden():
+    """(13) end-to-end ranking (north star: "bit-exact top-k doc indices"): the live reference's fp32 scorer
+    (processing_utils.py:132-187 on .float() copies, device="cpu") followed by torch.topk, as scripts/compute_hardnegs.py:92-94
+    (k = 100) and processing_utils.py:189-219 (k = 10) rank.  Two planted corpora, inputs regenerated from the seed:
+        python tests/golden/make_golden.py topk"""
+    out = {}
+    for tag, (seed, n_q, Lq, n_d, lo, hi, n_pl) in {"dense": (4242, 8, 32, 2000, 256, 256, 10),
+                                                    "ragged": (4343, 8, 32, 1000, 267, 779, 10)}.items():
+        qs, ps, slots = planted_inputs(seed, n_q, Lq, n_d, lo, hi, n_pl)
+        h = hashlib.sha256()
+        for t in qs + ps:
+            h.update(bits(t).tobytes())
+        scores = P.score_multi_vector([q.float() for q in qs], [p.float() for p in ps], batch_size=10**9, device="cpu")
+        blocked = P.score_multi_vector([q.float() for q in qs], [p.float() for p in ps], device="cpu")   # default blocking
+        out[f"{tag}_params"] = np.array([seed, n_q, Lq, n_d, lo, hi, n_pl], np.int64)
+        out[f"{tag}_sha256"] = np.frombuffer(h.digest(), dtype=np.uint8)
+        out[f"{tag}_scores"] = scores.numpy()
+        out[f"{tag}_scores_bs128"] = blocked.numpy()
+        out[f"{tag}_planted"] = slots.numpy()
+        for k in (10, 100):
+            out[f"{tag}_top{k}"] = scores.topk(k, dim=1).indices.numpy()
+            out[f"{tag}_top{k}_bs128"] = blocked.topk(k, dim=1).indices.numpy()
+        top10 = scores.topk(10, dim=1)
+        gaps = (top10.values[:, :-1] - top10.values[:, 1:]).min()
+        print(tag, "min gap inside the planted top-10:", float(gaps), "10th vs 11th:",
+              float((scores.topk(11, dim=1).values[:, 9] - scores.topk(11, dim=1).values[:, 10]).min()))
+        assert sorted(top10.indices[0].tolist()) == sorted(slots[0].tolist())
+    save("topk_planted.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "pooling":
+    if len(sys.argv) > 1 and sys.argv[1] == "topk":
+        topk_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pooling":
         pooling_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "sim":
         sim_golden()
@@ -354,3 +408,4 @@ if __name__ == "__main__":
         head_golden()
         sim_golden()
         pooling_golden()
+        topk_golden()

@@ -65,3 +65,48 @@ def topk_tie_aware_equal(got_idx, truth_scores, k, rtol=1e-6):
     want = truth_scores[order]
     got = truth_scores[np.asarray(got_idx[:k], dtype=np.int64)]
     return bool(np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), 1e-6)))
+
+
+def planted_inputs(z, tag):
+    """Regenerate the planted-retrieval inputs of topk_planted.npz (tests/golden/make_golden.py:planted_inputs, restated
+    here because that file imports the live reference) and check their sha256.  Returns (queries, docs) as bf16 tensors."""
+    import hashlib
+
+    import torch
+    import torch.nn.functional as F
+
+    seed, n_q, Lq, n_d, lo, hi, n_pl = (int(v) for v in z[f"{tag}_params"])
+    dim = 128
+    g = torch.Generator().manual_seed(seed)
+
+    def unit(n):
+        return F.normalize(torch.randn(n, dim, generator=g), dim=-1).to(torch.bfloat16)
+
+    qs = [unit(Lq) for _ in range(n_q)]
+    lens = [lo] * n_d if lo == hi else torch.randint(lo, hi + 1, (n_d,), generator=g).tolist()
+    ps = [unit(n).float() for n in lens]
+    slots = torch.randperm(n_d, generator=g)[: n_q * n_pl].view(n_q, n_pl)
+    for qi in range(n_q):
+        for j in range(n_pl):
+            d = int(slots[qi, j])
+            sigma = 0.3 + 0.05 * j
+            noisy = F.normalize(qs[qi].float() + sigma * torch.randn(Lq, dim, generator=g) / dim**0.5, dim=-1)
+            rows = torch.randperm(lens[d], generator=g)[:Lq]
+            ps[d][rows] = noisy
+    ps = [p.to(torch.bfloat16) for p in ps]
+    h = hashlib.sha256()
+    for t in qs + ps:
+        h.update(t.contiguous().view(torch.int16).numpy().tobytes())
+    assert h.digest() == z[f"{tag}_sha256"].tobytes(), "torch RNG stream changed: regenerate tests/golden/topk_planted.npz"
+    return qs, ps
+
+
+def ranking_tolerance(got_scores, truth_scores, cap=2e-6):
+    """Tolerance for the tie-aware ranking comparison: two documents may swap ranks only if their truth scores are closer
+    than twice the largest relative score error actually measured (two computations that agree to e cannot disagree on the
+    order of scores further apart than 2e).  The measured error itself must stay under cap / 2."""
+    got = np.asarray(got_scores, dtype=np.float64)
+    truth = np.asarray(truth_scores, dtype=np.float64)
+    e = float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), 1e-6)))
+    assert 2 * e <= cap, f"score error {e:.3e} too large for a meaningful ranking comparison"
+    return 2 * e + 1e-9

@@ -159,3 +159,23 @@ def test_corpus_writer_equals_the_reference_road_to_the_scorer(amd):
     from oracle import maxsim_oracle as mo
     want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().cpu().numpy() for p in pages], batch_size=128, mode="f32")
     assert np.max(np.abs(direct.numpy() - want) / np.maximum(np.abs(want), 1.0)) <= 1e-5
+
+
+def test_corpus_writer_rejected_append_leaves_the_writer_usable(amd):
+    # the host-side row bound counts masked positions; a rejected append must not inflate it, and the exact device-side count
+    # is what decides in the end
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    H = 256
+    w = (torch.randn(128, H, generator=g) / H**0.5).to(torch.bfloat16).to(dev)
+    writer = amd.CorpusWriter(capacity_rows=100, device=dev)
+    h = torch.randn(2, 40, H, generator=g).to(torch.bfloat16).to(dev)
+    mask = torch.ones(2, 40, dtype=torch.long, device=dev)
+    mask[:, 10:] = 0                                       # 20 real rows out of 80 positions
+    assert writer.append(h, w, None, mask) == 2
+    big = torch.randn(3, 40, H, generator=g).to(torch.bfloat16).to(dev)
+    with pytest.raises(RuntimeError, match="capacity"):
+        writer.append(big, w, None, torch.ones(3, 40, dtype=torch.long, device=dev))      # 20 + 120 > 100
+    assert writer.rows_written() == 20
+    assert writer.append(h, w, None, torch.ones(2, 40, dtype=torch.long, device=dev)) == 2   # 20 + 80 fits
+    assert len(writer.finish()) == 4

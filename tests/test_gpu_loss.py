@@ -395,3 +395,101 @@ def test_sigmoid_loss_fp32_against_reference_goldens_and_bf16_against_oracle(amd
         loss.backward()
         assert grads_close(q.grad, want_dq, None if smooth else q_real.expand_as(want_dq), paths=2), (vname, "dQ bf16")
         assert grads_close(d.grad, want_dd, None if smooth else d_real.expand_as(want_dd), paths=2), (vname, "dD bf16")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at its stated per-rank shape: bs 256 over 8 ranks -> B = 32 local queries, C = world * B = 256 gathered
+# documents, offset = rank * B (trainer/contrastive_trainer.py:143-160), Lq = 32, Ld = 780 (ColQwen2, left padded).
+
+def _config5_inputs(offset, seed=0):
+    g = torch.Generator().manual_seed(5000 + offset + seed)
+    B, C, Lq, Ld = 32, 256, 32, 780
+    Q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1)
+    q_pad = torch.randint(0, 12, (B,), generator=g)
+    d_pad = torch.randint(0, 500, (C,), generator=g)
+    for b in range(B):                                   # left padding, rows exactly zero (modeling_colqwen2.py:36, :69)
+        Q[b, : int(q_pad[b])] = 0
+    for c in range(C):
+        D[c, : int(d_pad[c])] = 0
+    for b in range(B):                                   # the positives: noisy copies of the query's tokens inside the page
+        c = offset + b
+        lo = int(d_pad[c])
+        rows = lo + torch.randperm(Ld - lo, generator=g)[:Lq]
+        D[c, rows] = torch.nn.functional.normalize(Q[b] + 0.6 * torch.randn(Lq, 128, generator=g), dim=-1) * (Q[b].abs().sum(-1, keepdim=True) > 0)
+    # a hard negative for a few queries: another rank's page that out-scores the positive
+    for b in (3, 17):
+        c = (offset + b + 40) % C
+        lo = int(d_pad[c])
+        rows = lo + torch.randperm(Ld - lo, generator=g)[:Lq]
+        D[c, rows] = torch.nn.functional.normalize(Q[b] + 0.3 * torch.randn(Lq, 128, generator=g), dim=-1) * (Q[b].abs().sum(-1, keepdim=True) > 0)
+    return Q, D
+
+
+@pytest.mark.parametrize("offset", [0, 96, 224])
+@pytest.mark.parametrize("cls,kind", [("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_config5_full_shape_loss_and_grads(amd, offset, cls, kind, dtype):
+    Q, D = _config5_inputs(offset)
+    Qx, Dx = Q.to(dtype), D.to(dtype)
+    kw = dict(normalize_scores=False) if kind == "pairwise" else dict()         # shipped configs / class defaults
+    want_loss, want_dq, want_dd = lo.loss_and_grads(kind, Qx.float(), Dx.float(), offset=offset, **kw)
+    q_real = (Qx.float().abs().sum(-1, keepdim=True) > 0)
+    d_real = (Dx.float().abs().sum(-1, keepdim=True) > 0)
+    q, d = Qx.cuda().requires_grad_(True), Dx.cuda().requires_grad_(True)
+    loss = getattr(amd, cls)(**kw)(query_embeddings=q, doc_embeddings=d, offset=offset)   # keyword call, contrastive_trainer.py:160
+    assert loss.dtype == dtype and loss.dim() == 0
+    loss.backward()
+    if dtype == torch.float32:
+        assert abs(float(loss.detach()) - float(want_loss)) <= 1e-5 * abs(float(want_loss)) + 1e-6
+        for got, want, mask in ((q.grad, want_dq, q_real), (d.grad, want_dd, d_real)):
+            bad = ((got.cpu().double() - want).abs() > 1e-4 * want.abs() + 1e-6) & mask.expand_as(want)
+            assert int(bad.sum()) == 0
+    else:
+        assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6
+        assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq))
+        assert grads_close(d.grad, want_dd, d_real.expand_as(want_dd))
+    if kind == "pairwise":
+        assert (d.grad.float().abs().sum(dim=(1, 2)) > 0).sum().item() <= 2 * Q.shape[0]
+
+
+def test_positional_three_argument_call_of_the_evaluation_path(amd):
+    """trainer/contrastive_trainer.py:221-224: prediction_step calls loss_func(query, doc, neg_doc) / loss_func(query, doc)
+    positionally, without `offset`."""
+    z = load_golden("loss_negatives.npz")
+    Q, D, N = (torch.from_numpy(z[k]) for k in ("Q", "D", "N"))
+    for cls in ("ColbertNegativeCELoss", "ColbertPairwiseNegativeCELoss"):
+        loss = getattr(amd, cls)()(Q.cuda(), D.cuda(), N.cuda())                   # positional, offset defaults to 0
+        want = float(z[f"{cls}_default_off0_loss"])
+        assert abs(float(loss) - want) <= 1e-5 * abs(want) + 1e-6
+    zs = load_golden("loss_small.npz")
+    for cls in ("ColbertPairwiseCELoss", "ColbertLoss"):
+        loss = getattr(amd, cls)()(Q.cuda(), D.cuda())                             # two positional arguments
+        want = float(zs[f"{cls}_default_off0_loss"])
+        assert abs(float(loss) - want) <= 1e-5 * abs(want) + 1e-6
+
+
+def test_offset_beyond_the_gathered_documents_raises_like_the_reference(amd):
+    # the reference fails on shapes when offset + B > C (diagonal / index out of range); never a silent garbage loss
+    Q = torch.nn.functional.normalize(torch.randn(4, 8, 128), dim=-1).to(torch.bfloat16).cuda()
+    D = torch.nn.functional.normalize(torch.randn(6, 16, 128), dim=-1).to(torch.bfloat16).cuda()
+    N = torch.nn.functional.normalize(torch.randn(4, 2, 16, 128), dim=-1).to(torch.bfloat16).cuda()
+    for cls in ("ColbertPairwiseCELoss", "ColbertLoss"):
+        with pytest.raises((RuntimeError, IndexError, ValueError)):
+            getattr(amd, cls)()(Q, D, offset=3)
+    for cls in ("ColbertNegativeCELoss", "ColbertPairwiseNegativeCELoss"):
+        with pytest.raises((RuntimeError, IndexError, ValueError)):
+            getattr(amd, cls)()(Q, D, N, offset=3)
+    bad = torch.tensor([[0, 0], [1, 6]], dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        amd.maxsim_paired(Q, D, bad)
+
+
+def test_loss_is_fp32_under_autocast_like_the_reference(amd):
+    # with bf16 embeddings under torch.autocast the reference's sum / softplus / cross_entropy run in fp32 (autocast fp32 ops)
+    Q = torch.nn.functional.normalize(torch.randn(4, 8, 128), dim=-1).to(torch.bfloat16).cuda()
+    D = torch.nn.functional.normalize(torch.randn(4, 16, 128), dim=-1).to(torch.bfloat16).cuda()
+    for cls in ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss"):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert getattr(amd, cls)()(Q, D).dtype == torch.float32
+        assert getattr(amd, cls)()(Q, D).dtype == torch.bfloat16

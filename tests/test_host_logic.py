@@ -198,3 +198,70 @@ def test_topk_workspace_plan_is_consistent():
             want = a16(n_q * na * 4) + a16(n_q * na * 8) + a16(n_q * nb * 4) + a16(n_q * nb * 8)
         assert got == want, (n_q, n, k, got, want)
     assert L.msim_topk_workspace_bytes(4, 125000, 5000) == 0     # k above the kernel's limit: rejected, no plan
+
+
+def test_bounded_staging_upload_reproduces_cat_and_padding(monkeypatch):
+    """The drop-in's host -> device upload goes through a pinned buffer of bounded size in double-buffered chunks; chunk
+    borders fall inside passages.  Exercised on the CPU with the two CUDA-only pieces (pinning, events) stubbed."""
+    class _Ev:
+        def synchronize(self):
+            pass
+
+        def record(self, stream):
+            pass
+
+    real_empty = torch.empty
+    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: None)
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{kk: v for kk, v in k.items() if kk != "pin_memory"}))
+    monkeypatch.setattr(C, "STAGING_BYTES", 2 << 20)
+    st = C._Staging()
+    ps = [bf(n, seed=n) for n in (5000, 1, 0, 3000, 7000, 12, 9000)]          # 6 MiB through two 1 MiB halves
+    out = st.upload(ps, 128, torch.device("cpu"))
+    assert torch.equal(out, torch.cat(ps)) and st.buf.numel() == 2 << 20
+    qs = [bf(n, seed=n) for n in (5, 32, 17)] * 300
+    out = st.upload(qs, 128, torch.device("cpu"), slot_rows=32)
+    assert torch.equal(out, torch.nn.utils.rnn.pad_sequence(qs, batch_first=True).reshape(-1, 128))
+    assert st.buf.numel() == 2 << 20                                           # never grown past the cap
+
+
+def test_passage_ranges_cut_at_block_multiples():
+    from colpali_amd.scoring import passage_ranges
+
+    ps = [bf(10)] * 10                                                        # 2560 bytes each
+    assert passage_ranges(ps, 4, 10**9) == [(0, 10)]
+    assert passage_ranges(ps, 4, 2560 * 8) == [(0, 8), (8, 10)]
+    assert passage_ranges(ps, 4, 2560 * 5) == [(0, 4), (4, 8), (8, 10)]
+    assert passage_ranges(ps, 4, 1) == [(0, 4), (4, 8), (8, 10)]             # a block above the budget is still one range
+    t = torch.zeros(7, 3, 128, dtype=torch.bfloat16)
+    assert passage_ranges(t, 2, 3 * 256 * 4) == [(0, 4), (4, 7)]
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus():
+    """`python bench.py --gpus 2` must never degrade silently to one rank: without two visible GPUs (none here) and without
+    the explicit BENCH_SHARE_GPU=1 plumbing override it exits non-zero before spawning anything."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+    # a launcher that started the wrong number of ranks is an error too
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env2, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_loss_offset_and_pair_checks_run_before_any_device_work():
+    from colpali_amd import loss as Lm
+
+    with pytest.raises(IndexError):
+        Lm._check_offset(4, 6, 3)
+    Lm._check_offset(4, 7, 3)
+    with pytest.raises(ValueError):
+        Lm._check_pairs(torch.tensor([[0, 0], [1, 6]], dtype=torch.int32), 4, 6)
+    with pytest.raises(ValueError):
+        Lm._check_pairs(torch.tensor([[1, 0], [0, 1]], dtype=torch.int32), 4, 6)          # not sorted by query
+    Lm._check_pairs(torch.tensor([[0, 5], [3, 0]], dtype=torch.int32), 4, 6)
