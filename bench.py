@@ -441,7 +441,7 @@ def main():
         "config": {
             "workload": f"{args.nq} query x {args.q_len} tokens vs resident pre-embedded shard of {args.docs} docs x "
                         f"{args.doc_len} patches x d=128 bf16 per GPU ({args.docs * args.doc_len * 256 / 2**30:.1f} GiB/GPU), "
-                        f"fused MaxSim + per-shard top-{args.topk}" + (" + RCCL all-gather merge" if world > 1 else ""),
+                        f"fused MaxSim + per-shard top-{args.topk}" + ((" + RCCL all-gather merge" if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" else " + gloo all-gather merge (plumbing run)") if world > 1 else ""),
             "docs_per_gpu": args.docs, "doc_len": args.doc_len, "n_queries": args.nq, "q_len": args.q_len,
             "top_k": args.topk, "parallelism": f"corpus-sharded x{world}",
         },

@@ -64,7 +64,7 @@ def topk_tie_aware_equal(got_idx, truth_scores, k, rtol=1e-6):
     order = np.argsort(-truth_scores, kind="stable")[:k]
     want = truth_scores[order]
     got = truth_scores[np.asarray(got_idx[:k], dtype=np.int64)]
-    return bool(np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), 1e-6)))
+    return bool(np.all(np.abs(got - want) <= rtol * np.maximum(np.abs(want), 1.0)))
 
 
 def planted_inputs(z, tag):
@@ -107,6 +107,6 @@ def ranking_tolerance(got_scores, truth_scores, cap=2e-6):
     order of scores further apart than 2e).  The measured error itself must stay under cap / 2."""
     got = np.asarray(got_scores, dtype=np.float64)
     truth = np.asarray(truth_scores, dtype=np.float64)
-    e = float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), 1e-6)))
+    e = float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), 1.0)))     # same error measure as every score test
     assert 2 * e <= cap, f"score error {e:.3e} too large for a meaningful ranking comparison"
     return 2 * e + 1e-9
