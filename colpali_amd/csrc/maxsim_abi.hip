@@ -21,6 +21,7 @@
 #include "embed_head.hip"
 #include "token_pooling.hip"
 #include "probe_stream.hip"
+#include "probe_mfma.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -174,10 +175,10 @@ int launch_stream(const FwdCall &c) {
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
 
-template <int TPQ, bool F16, int NW>
+template <int TPQ, bool F16, int NW, int RING = 3, bool ONEPASS = false>
 int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW>;
-    constexpr int lds = msim::kBatchRing * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves)
+    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING, ONEPASS>;
+    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves) / 32 KiB (2 waves, ring of 4)
     constexpr int wg_per_cu = 8 / NW;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -212,11 +213,33 @@ int stream_max_tiles() {
     return v;
 }
 
+// MSIM_BATCH_EXP="NW,RING,ONEPASS": forces one K1b variant for 32-token bf16 queries (A/B measurements only; not part of the ABI)
+int batch_exp(const FwdCall &c) {
+    static const char *e = getenv("MSIM_BATCH_EXP");
+    if (!e) return 1;
+    int nw = 0, ring = 0, one = 0;
+    if (sscanf(e, "%d,%d,%d", &nw, &ring, &one) != 3) return 1;
+    switch (nw * 100 + ring * 10 + one) {
+        case 241: return launch_batch<1, false, 2, 4, true>(c);
+        case 240: return launch_batch<1, false, 2, 4, false>(c);
+        case 231: return launch_batch<1, false, 2, 3, true>(c);
+        case 251: return launch_batch<1, false, 2, 5, true>(c);
+        case 431: return launch_batch<1, false, 4, 3, true>(c);
+        case 441: return launch_batch<1, false, 4, 4, true>(c);
+        case 831: return launch_batch<1, false, 8, 3, true>(c);
+        default: return 1;
+    }
+}
+
 template <bool F16>
 int fwd_dispatch(const FwdCall &c) {
     const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int n_q = c.n_q;
     if (n_q * tpq > stream_max_tiles()) {
+        if (!F16 && tpq == 1) {
+            const int rc = batch_exp(c);
+            if (rc <= 0) return rc;
+        }
         // up to 24 token tiles: two 4-wave workgroups per CU cover each other's chunk barriers; above: one 8-wave workgroup
         const bool small = n_q * tpq <= 24;
         if (tpq == 1) return small ? launch_batch<1, F16, 4>(c) : launch_batch<1, F16, 8>(c);
@@ -1010,6 +1033,24 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
         default: rc = run_probe<512, 16, 2, 8>(x, rows, row_elems, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_stream_kernel launch failed (variant %d)", variant);
+    return MSIM_OK;
+}
+
+int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *sink, void *stream) {
+    if (!X || !sink) return fail(MSIM_EINVAL, "null pointer argument");
+    if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
+    if (rows < 256LL * 8 * 5 * 32) return fail(MSIM_EINVAL, "the MFMA probe needs at least %d rows of operands", 256 * 8 * 5 * 32);
+    if (iters <= 0 || variant < 0 || variant > 3) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *x = static_cast<const uint16_t *>(X);
+    int rc;
+    switch (variant) {
+        case 0: rc = run_probe_mfma<false, false>(x, iters, sink, st); break;
+        case 1: rc = run_probe_mfma<true, false>(x, iters, sink, st); break;
+        case 2: rc = run_probe_mfma<false, true>(x, iters, sink, st); break;
+        default: rc = run_probe_mfma<true, true>(x, iters, sink, st); break;
+    }
+    if (rc) return fail(MSIM_ELAUNCH, "probe_mfma_kernel launch failed (variant %d)", variant);
     return MSIM_OK;
 }
 

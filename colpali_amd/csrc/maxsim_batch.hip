@@ -58,7 +58,12 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 // NW : waves per workgroup.  8 = one workgroup per CU, 128-row chunks (the MFMA-bound end: fewest query blocks per corpus pass);
 //      4 = two workgroups per CU with 64-row chunks and half the queries each: while one sits at its chunk barrier the other
 //      computes (+5 % at 9..16 queries, -2..-4 % from 64 queries up, where the doubled number of query blocks costs more).
-template <int TPQ, bool F16, int NW>
+// RING: chunks in the shared LDS ring.  ONEPASS: the operand fragments of a slab are read from LDS once and kept in registers for
+//      all of the wave's tiles, each tile's 16 -> 1 fold running underneath the next tile's MFMAs (K1s' body; fits 256 registers
+//      for up to 4 tiles) instead of the two-pass body that re-reads them.
+// NW = 2 is the "pair" form for 5..8 token tiles: two waves share one document stream (one 32-row slab per barrier, the
+//      barrier spans two waves only), four such pairs per CU -- two waves per SIMD where K1s at 5..8 tiles has one.
+template <int TPQ, bool F16, int NW, int RING = 3, bool ONEPASS = false>
 __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
@@ -66,6 +71,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
                                                                float *__restrict__ scores, BatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kB1Waves = NW;
+    constexpr int kBatchRing = RING;                       // (shadows the namespace constant)
     constexpr int kChunkSlabs = NW / 2;                    // every wave fills half a slab of each chunk (shadows the 8-wave constants)
     constexpr int kChunkRows = kChunkSlabs * kSlabRows;
     constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;
@@ -187,6 +193,24 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
 
         auto slab = [&](int src_lds, auto tail, int rows_left) {   // src_lds: LDS byte address of the slab (wave-uniform)
             constexpr bool kTail = decltype(tail)::value;
+            if constexpr (ONEPASS) {
+                bf16x8 af[kKSteps];
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) {
+                    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(af[ks], qf[t][ks], acc);
+                    if constexpr (kTail) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
+                    }
+                    m[t] = fold_max16(m[t], acc);
+                }
+                return;
+            }
             // ---- region 1: pass A MFMAs, with the previous slab's pending fold underneath them
             f32x16 accA[NA];
 #pragma unroll
@@ -262,8 +286,10 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             }
         }
         // fold what is still pending from the document's last slab
+        if constexpr (!ONEPASS) {
 #pragma unroll
-        for (int t = 0; t < NP; ++t) m[(NB > 0 ? NA : 0) + t] = fold_max16(m[(NB > 0 ? NA : 0) + t], pend[t]);
+            for (int t = 0; t < NP; ++t) m[(NB > 0 ? NA : 0) + t] = fold_max16(m[(NB > 0 ? NA : 0) + t], pend[t]);
+        }
 
         // ---- document epilogue (per wave, its own queries)
         if constexpr (wave_has_queries) {

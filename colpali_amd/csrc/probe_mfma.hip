@@ -1,0 +1,86 @@
+// Measurement aid behind msim_probe_mfma (include/maxsim.h): the matrix-core ceiling of THIS machine, under its own power
+// budget, for the instruction mix of the MaxSim kernels on REAL operand values.  Every SIMD of the chip runs
+// v_mfma_f32_32x32x16_bf16 back to back on operand fragments taken from the caller's matrix (unit-norm bf16 rows: the values the
+// scorer multiplies), two waves per SIMD like K1b, with nothing else in the way:
+//   bit 0 of `variant`: the A operand comes from LDS (one conflict-free ds_read_b128 per NT MFMAs, K1b's operand path)
+//                       instead of staying in registers;
+//   bit 1            : the 16 -> 1 max fold of every accumulator tile (8 v_max3 per 8 MFMAs) runs next to the MFMAs.
+// There is no HBM traffic, no barrier and no LDS-DMA.  MI355X clocks to its power budget (MI355X_MICROARCH.md, DVFS):
+// the 2.5 PFLOP/s dense bf16 figure is 1024 SIMDs x 1024 FLOP/clk x 2.4 GHz; what the chip sustains on random data is lower
+// and is the ceiling an MFMA-bound kernel can be held against -- bench.py reports it next to the spec peak.
+#pragma once
+#include "maxsim_common.hpp"
+#include "maxsim_stream.hip"
+namespace msim {
+template <int NT, bool LDSA, bool FOLD>
+__global__ __launch_bounds__(512, 2) void probe_mfma_kernel(const uint16_t *__restrict__ X, int iters, float *__restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t base = ((size_t)blockIdx.x * 8 + wave) * (NT + 1) * kTokTile;     // rows of X used by this wave
+    bf16x8 qf[NT][kKSteps];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks)
+            qf[t][ks] = *reinterpret_cast<const bf16x8 *>(X + (base + t * kTokTile + (lane & 31)) * kDim + (lane >> 5) * 8 + ks * 16);
+    bf16x8 areg[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks)
+        areg[ks] = *reinterpret_cast<const bf16x8 *>(X + (base + NT * kTokTile + (lane & 31)) * kDim + (lane >> 5) * 8 + ks * 16);
+    char *slab = smem + wave * kSlabBytes;                                           // wave-private slab, K1s/K1b's swizzled image
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) {
+        rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+        if constexpr (LDSA) *reinterpret_cast<bf16x8 *>(slab + rd_off[ks]) = areg[ks];
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+    float m[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        m[t] = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            bf16x8 af;
+            if constexpr (LDSA) {
+                int o = rd_off[ks];
+                asm volatile("" : "+v"(o));                                          // a fresh read every iteration
+                af = *reinterpret_cast<const bf16x8 *>(slab + o);
+            } else {
+                asm volatile("" : "+v"(areg[ks]));
+                af = areg[ks];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma32<false>(af, qf[t][ks], acc[t]);
+        }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                m[t] = fold_max16(m[t], acc[t]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s += m[t] == -INFINITY ? 0.f : m[t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    }
+    if (s == 123.456f) sink[0] = s;
+}
+}  // namespace msim
+template <bool LDSA, bool FOLD>
+int run_probe_mfma(const uint16_t *x, int iters, float *sink, hipStream_t st) {
+    auto kern = msim::probe_mfma_kernel<4, LDSA, FOLD>;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), 8 * msim::kSlabBytes, st, x, iters, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

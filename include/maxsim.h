@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 9
+#define MSIM_ABI_VERSION 10
 
 /* error codes */
 #define MSIM_OK 0
@@ -220,6 +220,17 @@ int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages
 #define MSIM_PROBE_PIECES128B 1
 #define MSIM_PROBE_PIECES512B 2
 int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, float *sink, void *stream);
+
+/*
+ * Measurement aid (no reference counterpart): the matrix-core ceiling of this machine under its own power budget for the
+ * MaxSim kernels' MFMA (v_mfma_f32_32x32x16_bf16, two waves per SIMD, four 32-token tiles per wave) on the operand values
+ * the scorer multiplies.  X = row-major [rows, 128] bf16 (unit-norm rows), rows >= 256 * 8 * 5 * 32 = 327 680; every wave
+ * keeps 5 tiles of X in registers / LDS and issues `iters` x 32 MFMAs; no HBM traffic, no barrier.  The caller times the
+ * launch: FLOP = 256 workgroups x 8 waves x iters x 32 x 32768.
+ *   variant bit 0: A operand re-read from LDS per k-step (msim_fwd's operand path) instead of held in registers
+ *   variant bit 1: the 16 -> 1 max fold of every accumulator tile runs next to the MFMAs
+ */
+int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *sink, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""msim_probe_mfma: the matrix-core ceiling of this MI355X under its power budget on random unit-row bf16 operands
+(and on zeros, where the chip clocks higher), next to the 2.5 PFLOP/s spec figure."""
+import os, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch
+import bench, colpali_amd as amd
+
+dev = torch.device("cuda:0")
+L = amd._lib.lib()
+rows = 256 * 8 * 5 * 32
+g = torch.Generator(device=dev).manual_seed(1)
+X = torch.nn.functional.normalize(torch.randn((rows, 128), generator=g, device=dev), dim=-1).to(torch.bfloat16)
+Z = torch.zeros_like(X)
+sink = torch.zeros(4, dtype=torch.float32, device=dev)
+st = torch.cuda.current_stream()
+for data, name in ((X, "random unit rows"), (Z, "zeros")):
+    for variant, what in ((0, "A in registers"), (1, "A from LDS"), (2, "A in registers + max folds"), (3, "A from LDS + max folds")):
+        for iters in (2000, 20000):
+            ms = []
+            for i in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(st)
+                rc = L.msim_probe_mfma(variant, data.data_ptr(), rows, iters, sink.data_ptr(), st.cuda_stream)
+                b.record(st)
+                torch.cuda.synchronize()
+                assert rc == 0, L.msim_last_error()
+                if i >= 1:
+                    ms.append(a.elapsed_time(b))
+            t = sorted(ms)[len(ms) // 2]
+            flop = 256 * 8 * iters * 32 * 32768
+            print(f"{name:18s} variant {variant} ({what:28s}) iters {iters:6d}: {t:8.3f} ms  {flop / t / 1e9:7.0f} TFLOP/s = {flop / t / 1e9 / 2500:.3f} of 2.5 PF", flush=True)
