@@ -23,11 +23,10 @@ constexpr int kTokTile = 32;              // MFMA N: query tokens per tile
 
 #define MSIM_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// v_max3_f32.  Written with the builtin, NOT as inline asm: the compiler's hazard recognizer does not look inside an asm
+// statement, so an asm v_max3 that reads an accumulator straight after the MFMA that writes it gets no wait states (an
+// 8-pass MFMA needs 12 before a VALU read; the hardware does not interlock) and reads a partial sum.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 // max over the 16 accumulator registers of one lane, folded into a running max
 __device__ __forceinline__ float fold_max16(float m, const f32x16 &c) {

@@ -10,6 +10,8 @@ import bench, colpali_amd as amd
 docs = int(os.environ.get("AB_DOCS", "65536"))
 dev = torch.device("cuda:0")
 corpus = bench.make_shard(docs, 1024, dev, 1234)
+if os.environ.get("AB_ZERO") == "1":      # DVFS check (MI355X_MICROARCH.md): same binary, same traffic, operands that toggle nothing
+    corpus.blob.zero_()
 sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "5,6,7,8").split(",")]
 tag = os.environ.get("AB_TAG", "default")
 ref_mode = os.environ.get("AB_REF", "")
