@@ -175,10 +175,10 @@ int launch_stream(const FwdCall &c) {
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
 
-template <int TPQ, bool F16, int NW, int RING = 3, bool ONEPASS = false>
+template <int TPQ, bool F16, int NW, int RING = 3>
 int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING, ONEPASS>;
-    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves) / 32 KiB (2 waves, ring of 4)
+    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING>;
+    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves) / 32 KiB (pair, ring of 4)
     constexpr int wg_per_cu = 8 / NW;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -197,73 +197,56 @@ int launch_batch(const FwdCall &c) {
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
     hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", TPQ, NW, hipGetErrorString(e));
     return MSIM_OK;
 }
 
-// up to kStreamMaxTiles token tiles are held by every wave of K1s (HBM-bound regime, one pass over the corpus, no
-// barriers); above that K1b's workgroup blocking wins.  MSIM_STREAM_MAX_TILES is a tuning knob for A/B
-// measurements, not part of the ABI.
-int stream_max_tiles() {
+// MSIM_BATCH_NW=2|4|8 forces the number of waves that share a document stream in K1b (tuning knob for A/B measurements, not
+// part of the ABI; 2 is only legal up to 8 token tiles).
+int batch_nw_override() {
     static const int v = [] {
-        const char *e = getenv("MSIM_STREAM_MAX_TILES");
-        const int x = e ? atoi(e) : 8;
-        return x < 4 ? 4 : (x > 8 ? 8 : x);
+        const char *e = getenv("MSIM_BATCH_NW");
+        const int x = e ? atoi(e) : 0;
+        return (x == 2 || x == 4 || x == 8) ? x : 0;
     }();
     return v;
 }
 
-// MSIM_BATCH_EXP="NW,RING,ONEPASS": forces one K1b variant for 32-token bf16 queries (A/B measurements only; not part of the ABI)
-int batch_exp(const FwdCall &c) {
-    static const char *e = getenv("MSIM_BATCH_EXP");
-    if (!e) return 1;
-    int nw = 0, ring = 0, one = 0;
-    if (sscanf(e, "%d,%d,%d", &nw, &ring, &one) != 3) return 1;
-    switch (nw * 100 + ring * 10 + one) {
-        case 241: return launch_batch<1, false, 2, 4, true>(c);
-        case 240: return launch_batch<1, false, 2, 4, false>(c);
-        case 231: return launch_batch<1, false, 2, 3, true>(c);
-        case 251: return launch_batch<1, false, 2, 5, true>(c);
-        case 431: return launch_batch<1, false, 4, 3, true>(c);
-        case 441: return launch_batch<1, false, 4, 4, true>(c);
-        case 831: return launch_batch<1, false, 8, 3, true>(c);
-        default: return 1;
-    }
+template <int TPQ, bool F16>
+int batch_dispatch(const FwdCall &c) {
+    // 5..8 token tiles: the pair form; 9..20: two 4-wave workgroups per CU cover each other's chunk barriers; above: one
+    // 8-wave workgroup per CU (profiles/r02_logs/ab_ridge.log: 16 queries 6.57 ms with 4 waves vs 7.01 with 8, 24 queries
+    // 9.97 vs 9.73)
+    const int tiles = c.n_q * TPQ;
+    int nw = tiles <= 8 ? 2 : (tiles <= 20 ? 4 : 8);
+    const int forced = batch_nw_override();
+    if (forced && (forced != 2 || tiles <= 8)) nw = forced;
+    if (nw == 2) return launch_batch<TPQ, F16, 2, 4>(c);
+    if (nw == 4) return launch_batch<TPQ, F16, 4, 3>(c);
+    return launch_batch<TPQ, F16, 8, 3>(c);
 }
 
 template <bool F16>
 int fwd_dispatch(const FwdCall &c) {
     const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int n_q = c.n_q;
-    if (n_q * tpq > stream_max_tiles()) {
-        if (!F16 && tpq == 1) {
-            const int rc = batch_exp(c);
-            if (rc <= 0) return rc;
-        }
-        // up to 24 token tiles: two 4-wave workgroups per CU cover each other's chunk barriers; above: one 8-wave workgroup
-        const bool small = n_q * tpq <= 24;
-        if (tpq == 1) return small ? launch_batch<1, F16, 4>(c) : launch_batch<1, F16, 8>(c);
-        if (tpq == 2) return small ? launch_batch<2, F16, 4>(c) : launch_batch<2, F16, 8>(c);
-        if (tpq == 3) return small ? launch_batch<3, F16, 4>(c) : launch_batch<3, F16, 8>(c);
-        return small ? launch_batch<4, F16, 4>(c) : launch_batch<4, F16, 8>(c);
+    // up to 4 token tiles in total every wave of K1s holds all of them (HBM-bound regime, one pass over the corpus, no
+    // barriers at all); above that the tiles are spread over the 2 / 4 / 8 waves that share a document stream in K1b
+    if (n_q * tpq > 4) {
+        if (tpq == 1) return batch_dispatch<1, F16>(c);
+        if (tpq == 2) return batch_dispatch<2, F16>(c);
+        if (tpq == 3) return batch_dispatch<3, F16>(c);
+        return batch_dispatch<4, F16>(c);
     }
     switch (n_q * 10 + tpq) {
         case 11: return launch_stream<1, 1, F16>(c);
         case 21: return launch_stream<2, 1, F16>(c);
         case 31: return launch_stream<3, 1, F16>(c);
         case 41: return launch_stream<4, 1, F16>(c);
-        case 51: return launch_stream<5, 1, F16>(c);
-        case 61: return launch_stream<6, 1, F16>(c);
-        case 71: return launch_stream<7, 1, F16>(c);
-        case 81: return launch_stream<8, 1, F16>(c);
         case 12: return launch_stream<2, 2, F16>(c);
         case 22: return launch_stream<4, 2, F16>(c);
-        case 32: return launch_stream<6, 2, F16>(c);
-        case 42: return launch_stream<8, 2, F16>(c);
         case 13: return launch_stream<3, 3, F16>(c);
-        case 23: return launch_stream<6, 3, F16>(c);
         case 14: return launch_stream<4, 4, F16>(c);
-        case 24: return launch_stream<8, 4, F16>(c);
         default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
     }
 }

@@ -1,25 +1,28 @@
-// K1b -- "batch" MaxSim kernel for gfx950 (MI355X), the MFMA-bound regime:
-// many queries (>= 5 token tiles) scored against a corpus.  Same arithmetic as K1s
-// (colpali_engine/utils/processing_utils.py:179 and
-//  colpali_engine/loss/late_interaction_losses.py:297-298), different blocking.
+// K1b -- "batch" MaxSim kernel for gfx950 (MI355X): more than 4 token tiles (of 32 query tokens) in total, i.e. the ridge
+// and the MFMA-bound regime.  Same arithmetic as K1s (colpali_engine/utils/processing_utils.py:179 and
+// colpali_engine/loss/late_interaction_losses.py:297-298), different blocking.
 //
 // Structure
-//   * workgroup = 8 waves (2 per SIMD); every wave keeps up to 4 query token tiles (32 tokens x 128
-//     each) in registers as MFMA B operands -> a workgroup scores a block of up to 32 token tiles
-//     (32 queries of <= 32 tokens) against its document range.  The queries are split EVENLY over the
-//     query blocks and dealt to the waves of a block round-robin (query j of the block -> wave j % 8), and
-//     a wave runs the loop body compiled for the number of tiles it actually holds: 12 queries cost
-//     3 tiles per SIMD, not 4, and 40 queries cost two blocks of 20 (5 per SIMD), not 32 + 8;
-//   * documents are streamed in chunks of 4 slabs (128 patches, 32 KiB) into a 3-deep LDS ring
-//     shared by the 8 waves: each wave issues 4 of the chunk's 32 LDS-DMA wave-instructions
-//     (buffer_load_dwordx4 ... lds, per-document bounds-checked descriptor, XOR-swizzled source);
-//     ONE raw s_barrier per chunk, LDS-DMA stays in flight across it (counted vmcnt, never 0);
-//   * every wave reads every slab (ds_read_b128, conflict free) and runs 8 MFMAs per (slab, tile);
-//     per-token running max in registers (v_max3), no cross-wave reduction at all;
-//   * arithmetic intensity vs HBM/L2: 32 token tiles per streamed byte -> 1024 FLOP/B.
-//   * grid: blockIdx -> (XCD, slot); the workgroups resident on one XCD stream the SAME document
-//     range for different query blocks, so a document is pulled from HBM once per XCD and served
-//     to the other CUs from that XCD's L2 (placement only affects speed, never results).
+//   * NW waves share ONE document stream through an LDS ring; every wave keeps up to 4 query token tiles (32 tokens x 128
+//     each = 32 VGPRs) in registers as MFMA B operands and scores them against every slab of the stream:
+//       NW = 2 ("pair", 5..8 tiles):  four pairs per CU -- two waves per SIMD at <= 256 registers where one wave holding all
+//               8 tiles needs 300+ and runs alone on its SIMD; one 32-row slab per barrier, and the barrier spans two waves only;
+//       NW = 4 (9..20 tiles):         two workgroups per CU, 64-row chunks: one computes while the other sits at its barrier;
+//       NW = 8 (more):                one workgroup per CU, 128-row chunks, up to 32 tiles per query block -- the fewest passes
+//               over the corpus;
+//     the queries are split EVENLY over the query blocks and dealt to the waves of a block round-robin (query j of the block ->
+//     wave j % NW), and a wave runs the loop body compiled for the number of tiles it actually holds;
+//   * a chunk = NW/2 slabs; each wave issues 4 of the chunk's LDS-DMA wave-instructions (buffer_load_dwordx4 ... lds,
+//     per-document bounds-checked descriptor, XOR-swizzled source); ONE raw s_barrier per chunk, LDS-DMA stays in flight across it
+//     (counted vmcnt, never 0);
+//   * per slab a wave reads the 8 operand fragments ONCE (ds_read_b128, conflict free), then runs 8 MFMAs per tile with the
+//     16 -> 1 max fold of one tile underneath the MFMAs of the next; per-token running max in registers, no cross-wave
+//     reduction at all.  (A first version processed the tiles in two passes and re-read the fragments for the second: the
+//     one-pass body is 1-5 % faster everywhere -- this regime is POWER-bound on real data, see DESIGN.md, and an LDS read
+//     costs energy.)
+//   * grid: blockIdx -> (XCD, slot); the workgroups resident on one XCD stream the SAME document range for different query
+//     blocks, so a document is pulled from HBM once per XCD and served to the other CUs from that XCD's L2 (placement only
+//     affects speed, never results).
 #pragma once
 #include <type_traits>
 
@@ -58,12 +61,8 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 // NW : waves per workgroup.  8 = one workgroup per CU, 128-row chunks (the MFMA-bound end: fewest query blocks per corpus pass);
 //      4 = two workgroups per CU with 64-row chunks and half the queries each: while one sits at its chunk barrier the other
 //      computes (+5 % at 9..16 queries, -2..-4 % from 64 queries up, where the doubled number of query blocks costs more).
-// RING: chunks in the shared LDS ring.  ONEPASS: the operand fragments of a slab are read from LDS once and kept in registers for
-//      all of the wave's tiles, each tile's 16 -> 1 fold running underneath the next tile's MFMAs (K1s' body; fits 256 registers
-//      for up to 4 tiles) instead of the two-pass body that re-reads them.
-// NW = 2 is the "pair" form for 5..8 token tiles: two waves share one document stream (one 32-row slab per barrier, the
-//      barrier spans two waves only), four such pairs per CU -- two waves per SIMD where K1s at 5..8 tiles has one.
-template <int TPQ, bool F16, int NW, int RING = 3, bool ONEPASS = false>
+// RING: chunks in the shared LDS ring (4 for the pair form: 32 KiB per workgroup, 3 otherwise: 48 / 96 KiB).
+template <int TPQ, bool F16, int NW, int RING = 3>
 __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
@@ -181,90 +180,22 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         float m[NTA];
 #pragma unroll
         for (int t = 0; t < NTA; ++t) m[t] = -INFINITY;
-        // Tiles are processed in two passes per slab (A = tiles 0..NA-1, B = the rest); the 16 -> 1 max fold of a
-        // pass is deferred so that its v_max3 run underneath the NEXT pass's MFMAs instead of stalling the matrix
-        // pipe: `pend` holds the accumulators of the last pass of the previous slab (all -inf = nothing pending).
-        constexpr int NA = NTA < 2 ? NTA : 2, NB = NTA - NA, NP = NB > 0 ? NB : NA;
-        f32x16 pend[NP];
-#pragma unroll
-        for (int t = 0; t < NP; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pend[t][r] = -INFINITY;
-
         auto slab = [&](int src_lds, auto tail, int rows_left) {   // src_lds: LDS byte address of the slab (wave-uniform)
             constexpr bool kTail = decltype(tail)::value;
-            if constexpr (ONEPASS) {
-                bf16x8 af[kKSteps];
+            bf16x8 af[kKSteps];
 #pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
+            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
 #pragma unroll
-                for (int t = 0; t < NTA; ++t) {
-                    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < NTA; ++t) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(af[ks], qf[t][ks], acc);
-                    if constexpr (kTail) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
-                    }
-                    m[t] = fold_max16(m[t], acc);
-                }
-                return;
-            }
-            // ---- region 1: pass A MFMAs, with the previous slab's pending fold underneath them
-            f32x16 accA[NA];
-#pragma unroll
-            for (int t = 0; t < NA; ++t) accA[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
-#pragma unroll
-                for (int t = 0; t < NA; ++t) accA[t] = mfma32<F16>(af, qf[t][ks], accA[t]);
-            }
-            if constexpr (NB > 0) {
-#pragma unroll
-                for (int t = 0; t < NB; ++t) m[NA + t] = fold_max16(m[NA + t], pend[t]);   // previous slab's pass B
-            } else {
-#pragma unroll
-                for (int t = 0; t < NA; ++t) m[t] = fold_max16(m[t], pend[t]);              // previous slab's pass A
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kTail) {
-#pragma unroll
-                for (int t = 0; t < NA; ++t)
+                for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(af[ks], qf[t][ks], acc);
+                if constexpr (kTail) {      // rows past the document end do not exist
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (acc_row(r, lane) >= rows_left) accA[t][r] = -INFINITY;
-            }
-            if constexpr (NB > 0) {
-                // ---- region 2: pass B MFMAs (operands re-read from LDS: cheaper than 32 live VGPRs), pass A's fold underneath
-                int src_b = src_lds;
-                asm volatile("" : "+s"(src_b));   // keep the compiler from merging the two passes back into one
-                f32x16 accB[NB];
-#pragma unroll
-                for (int t = 0; t < NB; ++t) accB[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(smem + src_b + rd_off[ks]);
-#pragma unroll
-                    for (int t = 0; t < NB; ++t)
-                        accB[t] = mfma32<F16>(af, qf[NA + t][ks], accB[t]);
+                        if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
                 }
-#pragma unroll
-                for (int t = 0; t < NA; ++t) m[t] = fold_max16(m[t], accA[t]);             // this slab's pass A
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (kTail) {
-#pragma unroll
-                    for (int t = 0; t < NB; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (acc_row(r, lane) >= rows_left) accB[t][r] = -INFINITY;
-                }
-#pragma unroll
-                for (int t = 0; t < NB; ++t) pend[t] = accB[t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < NA; ++t) pend[t] = accA[t];
+                m[t] = fold_max16(m[t], acc);
             }
         };
 
@@ -285,12 +216,6 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
                 if (n_full < kChunkSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem);
             }
         }
-        // fold what is still pending from the document's last slab
-        if constexpr (!ONEPASS) {
-#pragma unroll
-            for (int t = 0; t < NP; ++t) m[(NB > 0 ? NA : 0) + t] = fold_max16(m[(NB > 0 ? NA : 0) + t], pend[t]);
-        }
-
         // ---- document epilogue (per wave, its own queries)
         if constexpr (wave_has_queries) {
             bool clamp = false;

@@ -97,7 +97,12 @@ def _oracle(qs, ps, batch_size):
     (9, 33, 40, 130, 128),       # two token tiles per query
     (2, 100, 30, 90, 128),       # four token tiles per query
     (3, 128, 20, 64, 128),
-    (8, 32, 300, 500, 128),      # K1s with 8 token tiles
+    (8, 32, 300, 500, 128),      # K1b pair form (NW=2): 8 token tiles, 4 per wave
+    (5, 32, 257, 700, 128),      # pair form: 3 + 2 tiles
+    (7, 31, 64, 1030, 16),       # pair form: 4 + 3 tiles, clamp0
+    (3, 64, 90, 260, 128),       # pair form, two-tile queries: 2 + 1 queries per wave
+    (2, 96, 60, 200, 128),       # pair form, three-tile queries: one per wave
+    (2, 128, 40, 150, 128),      # pair form, four-tile queries
     (13, 32, 300, 500, 128),     # K1b<1>: waves with 2 and with 1 tile in one block
     (20, 32, 100, 400, 128),     # K1b<1>: 3 / 2 tiles per wave
     (33, 32, 500, 300, 128),     # K1b<1>: two balanced query blocks (17 + 16)
@@ -137,16 +142,20 @@ def test_batch_regime_fixed_length_corpus_and_literal_mode(amd):
 
 
 def test_stream_and_batch_kernels_agree_bitwise_on_shared_queries(amd):
-    # the same query scored alone (K1s) and inside a 40-query batch (K1b) must give the same fp32 value:
-    # both kernels run the identical MFMA chain per (token tile, slab) and the same reduction tree
+    # the same query scored alone (K1s) and inside batches of 6 (K1b pair form), 12 (4 waves) and 40 (8 waves) must give the same
+    # fp32 value: all kernels run the identical MFMA chain per (token tile, slab) and the same reduction tree
     qs, ps = _random_case(9, 40, 32, 300, 700)
     dev = torch.device("cuda:0")
     corpus = amd.pack_passages(ps, dev)
-    big = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()
     lq = max(q.shape[0] for q in qs)
+    padded = [torch.cat([q, q.new_zeros(lq - q.shape[0], 128)]) for q in qs]
+    big = amd.maxsim_scores(amd.pack_queries(padded, dev), corpus).cpu()
     for i in (0, 7, 39):
-        one = amd.maxsim_scores(amd.pack_queries([torch.cat([qs[i], qs[i].new_zeros(lq - qs[i].shape[0], 128)])], dev), corpus).cpu()
+        one = amd.maxsim_scores(amd.pack_queries([padded[i]], dev), corpus).cpu()
         assert torch.equal(one[0], big[i])
+    for n in (6, 12):
+        part = amd.maxsim_scores(amd.pack_queries(padded[:n], dev), corpus).cpu()
+        assert torch.equal(part, big[:n])
 
 
 @pytest.mark.parametrize("n_q,lq_max,n_d,ld_max", [(2, 32, 200, 700), (7, 32, 150, 300), (40, 40, 120, 500)])
