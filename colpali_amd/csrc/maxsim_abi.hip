@@ -22,6 +22,7 @@
 #include "token_pooling.hip"
 #include "probe_stream.hip"
 #include "probe_mfma.hip"
+#include "loss_epilogue.hip"
 #include "topk_select.hip"
 
 namespace {
@@ -755,6 +756,49 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, con
         launch_pairs_bwd<false>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_bwd launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+// ---------------------------------------------------------------- loss epilogue
+size_t msim_loss_epilogue_workspace_bytes(int B) { return B > 0 ? 16 + (size_t)3 * B * sizeof(float) : 16; }
+
+int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C, const void *Q, int q_dtype, int Lq, int width,
+                       int offset, float temperature, int normalize, int filter, float filter_threshold, float filter_factor,
+                       float *G, int32_t *pairs, float *coef, int32_t *order, void *workspace, float *out, void *stream) {
+    if (B < 0 || C < 0 || Lq < 0 || width <= 0) return fail(MSIM_EINVAL, "negative size");
+    if (mode != MSIM_LOSS_PAIRWISE && mode != MSIM_LOSS_INFONCE) return fail(MSIM_EINVAL, "unknown loss mode %d", mode);
+    if (!scores || !Q || !workspace || !out) return fail(MSIM_EINVAL, "null pointer argument");
+    if (q_dtype != MSIM_DTYPE_BF16 && q_dtype != MSIM_DTYPE_F16 && q_dtype != MSIM_DTYPE_F32)
+        return fail(MSIM_EUNSUPPORTED, "dtype code %d", q_dtype);
+    if (B == 0) return fail(MSIM_EINVAL, "empty batch");
+    if (offset < 0 || (long long)offset + B > C) return fail(MSIM_EINVAL, "offset %d + batch %d exceeds the %d documents", offset, B, C);
+    if (ld < C) return fail(MSIM_EINVAL, "ld=%lld < C=%d", (long long)ld, C);
+    if (temperature == 0.0f) return fail(MSIM_EINVAL, "temperature must be non-zero");
+    if (mode == MSIM_LOSS_PAIRWISE) {
+        if (C < 2) return fail(MSIM_EINVAL, "the pairwise loss needs at least 2 documents (topk(2))");
+        if (!pairs || !coef || !order) return fail(MSIM_EINVAL, "null pair-list output");
+    }
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
+    msim::EpiArgs a;
+    a.ld = ld;
+    a.B = B;
+    a.C = C;
+    a.Lq = Lq;
+    a.q_elem_bytes = elem_bytes(q_dtype);
+    a.q_row_bytes = width * a.q_elem_bytes;
+    a.offset = offset;
+    a.mode = mode == MSIM_LOSS_PAIRWISE ? msim::kEpiPairwise : msim::kEpiInfoNCE;
+    a.normalize = normalize != 0;
+    a.filter = filter != 0;
+    a.inv_T = 1.0f / temperature;
+    a.filter_threshold = filter_threshold;
+    a.filter_factor = filter_factor;
+    char *ws = static_cast<char *>(workspace);
+    hipLaunchKernelGGL(msim::loss_epilogue_kernel, dim3(B), dim3(msim::kEpiThreads), 0, static_cast<hipStream_t>(stream), scores,
+                       static_cast<const char *>(Q), G, pairs, coef, order, reinterpret_cast<float *>(ws + 16),
+                       reinterpret_cast<unsigned int *>(ws), out, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "loss_epilogue_kernel launch: %s", hipGetErrorString(e));
     return MSIM_OK;
 }
 

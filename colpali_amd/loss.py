@@ -101,30 +101,33 @@ def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
 
 
 def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor, argmax_all=None):
-    """(dQ fp32 [B,Lq,width], dD fp32 [C,Ld,width]) for upstream dLoss/dscores [B, C].  `argmax_all`: the [B*C, Lq] routing
-    of every pair in row-major order when the forward kept it (used when the gradient is dense)."""
+    """(dQ fp32 [B,Lq,width], dD fp32 [C,Ld,width]) for upstream dLoss/dscores [B, C].  Every (query, doc) pair is a pair of
+    the list (zero gradients contribute zero): no data-dependent count, hence no host synchronisation.  `argmax_all`: the
+    [B*C, Lq] routing in row-major order when the forward kept it; otherwise it is recomputed here (one pass of the
+    arg-max pair kernel, about the cost of the forward).  The losses whose gradient is 2-sparse per query (pairwise) do not
+    come through here: their epilogue kernel hands the backward its 2B pairs directly (_FusedInBatchLoss)."""
+    B, C = qc.shape[0], dc.shape[0]
+    dev = qc.device
+    if B * C == 0:
+        return (torch.zeros(qc.shape, dtype=torch.float32, device=dev), torch.zeros(dc.shape, dtype=torch.float32, device=dev))
+    pairs = _all_pairs(B, C, dev)
+    if argmax_all is None:
+        _, argmax_all = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
+    gp = grad_scores.to(torch.float32).reshape(-1).contiguous()
+    return _pairs_backward(qc, dc, offsets, pairs, _all_pairs_order(B, C, dev), gp, argmax_all)
+
+
+def _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax):
+    """msim_pairs_bwd: (dQ, dD) fp32 for a pair list sorted by query with its by-document permutation and routing."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C, Ld, _ = dc.shape
     dev = qc.device
-    g = grad_scores.to(torch.float32)
-    pairs64 = torch.nonzero(g)                        # row-major order = sorted by query, then doc (one host sync)
-    n_pairs = pairs64.shape[0]
     dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
     dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
-    if n_pairs == 0:
-        return dq.zero_(), dd.zero_()
-    if argmax_all is not None and n_pairs == B * C:
-        gp, pairs, argmax = g.reshape(-1).contiguous(), _all_pairs(B, C, dev), argmax_all
-        order = _all_pairs_order(B, C, dev)
-    else:
-        gp = g[pairs64[:, 0], pairs64[:, 1]].contiguous()
-        pairs = pairs64.to(torch.int32).contiguous()
-        order = torch.sort(pairs64[:, 1], stable=True).indices.to(torch.int32).contiguous()
-        _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
     with torch.cuda.device(dev):
         rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
-                              _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), n_pairs,
+                              _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
                               _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
     _lib.check(rc, "msim_pairs_bwd")
     return dq, dd
@@ -144,20 +147,10 @@ class _MaxSimPairs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_scores: torch.Tensor):
         qc, dc, offsets, pairs = ctx.saved_tensors
-        L = _lib.lib()
-        B, Lq, dim = qc.shape
-        C, Ld, _ = dc.shape
-        dev = qc.device
         gp = grad_scores.to(torch.float32).contiguous()
         order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
         _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
-        dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
-        dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
-                                  _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
-                                  _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
-        _lib.check(rc, "msim_pairs_bwd")
+        dq, dd = _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax)
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
                 dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
 
@@ -232,8 +225,9 @@ def _all_pairs_order(B: int, C: int, device: torch.device) -> torch.Tensor:
     return t
 
 
-def _smooth_backward(qc, dc, offsets, pairs, gp, tau, lse=None):
-    """(dQ, dD) fp32 for the listed pairs (sorted by query) with upstream gradients gp; `lse` [n_pairs, Lq] if the forward kept it."""
+def _smooth_backward(qc, dc, offsets, pairs, gp, tau, lse=None, order=None):
+    """(dQ, dD) fp32 for the listed pairs (sorted by query) with upstream gradients gp; `lse` [n_pairs, Lq] if the forward kept
+    it; `order`: the stable by-document permutation of the list if the caller has it."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C, Ld, _ = dc.shape
@@ -243,7 +237,8 @@ def _smooth_backward(qc, dc, offsets, pairs, gp, tau, lse=None):
     n_pairs = pairs.shape[0]
     if n_pairs == 0:
         return dq.zero_(), dd.zero_()
-    order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
+    if order is None:
+        order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
     if lse is None:
         _, lse = smooth_pairs(qc, dc, offsets, pairs, tau, want_scores=False)
     with torch.cuda.device(dev):
@@ -286,13 +281,9 @@ class _MaxSimSmooth(torch.autograd.Function):
     def backward(ctx, grad_scores: torch.Tensor):
         qc, dc, offsets, lse = ctx.saved_tensors
         B, C = qc.shape[0], dc.shape[0]
-        g = grad_scores.to(torch.float32)
-        pairs64 = torch.nonzero(g)                      # row-major = sorted by query, then doc (one host sync)
-        if lse is not None and pairs64.shape[0] == B * C:
-            pairs, gp = _all_pairs(B, C, qc.device), g.reshape(-1).contiguous()     # dense gradient: the forward's list and LSE
-        else:
-            pairs, gp, lse = pairs64.to(torch.int32).contiguous(), g[pairs64[:, 0], pairs64[:, 1]].contiguous(), None
-        dq, dd = _smooth_backward(qc, dc, offsets, pairs, gp, ctx.tau, lse=lse)
+        # every pair is listed (zero gradients contribute zero): no data-dependent count, no host synchronisation
+        pairs, gp = _all_pairs(B, C, qc.device), grad_scores.to(torch.float32).reshape(-1).contiguous()
+        dq, dd = _smooth_backward(qc, dc, offsets, pairs, gp, ctx.tau, lse=lse, order=_all_pairs_order(B, C, qc.device))
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
                 dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
 
@@ -339,6 +330,101 @@ def maxsim_smooth_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.T
     if validate:
         _check_pairs(pairs, query_embeddings.shape[0], doc_embeddings.shape[0])
     return _MaxSimPairsSmooth.apply(_widen32(query_embeddings), _widen32(doc_embeddings), pairs, float(tau))
+
+
+_epi_ws = {}
+
+
+def _epilogue_workspace(B: int, device: torch.device) -> torch.Tensor:
+    """Zero-filled scratch of msim_loss_epilogue, one per (device, stream): the call leaves it ready for the next one."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    need = _lib.lib().msim_loss_epilogue_workspace_bytes(B)
+    ws = _epi_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if len(_epi_ws) > 32:
+            _epi_ws.clear()
+        ws = _epi_ws[key] = torch.zeros((max(need, 16 + 3 * 4 * 1024),), dtype=torch.uint8, device=device)
+    return ws
+
+
+MODE_PAIRWISE, MODE_INFONCE = 0, 1
+
+
+class _FusedInBatchLoss(torch.autograd.Function):
+    """loss = epilogue(MaxSim(Q, D)) for ColbertPairwiseCELoss / ColbertLoss, forward and backward without a host
+    synchronisation and without torch ops between the kernels (hipGraph-capturable as a whole):
+
+      forward   fused MaxSim (hard or smooth max; for InfoNCE the pair-list kernel over all pairs, which also leaves the routing /
+                logsumexp the dense gradient needs) -> msim_loss_epilogue (normalisation, filtering, loss value, dLoss/dscores)
+      backward  pairwise: the 2B (query, doc) pairs the epilogue emitted -> arg-max (or logsumexp) recompute for those pairs only
+                -> msim_pairs_bwd;   InfoNCE: dense G with the routing kept by the forward -> msim_pairs_bwd.
+    `stats` (returned for the caller's bound check) = [loss, min, max of the normalised scores]."""
+
+    @staticmethod
+    def forward(ctx, q, d, mode, offset, temperature, normalize, filtering, filter_threshold, filter_factor, smooth, tau):
+        L = _lib.lib()
+        qc, dc = q.contiguous(), d.contiguous()
+        corpus = _dense_corpus(dc)
+        B, Lq, width = qc.shape
+        C = dc.shape[0]
+        dev = qc.device
+        need_grad = any(ctx.needs_input_grad[:2])
+        aux = None                                  # InfoNCE + gradients: [B*C, Lq] routing (hard max) or logsumexp (smooth max)
+        if mode == MODE_INFONCE and need_grad:
+            scores = torch.empty((B, C), dtype=torch.float32, device=dev)
+            if smooth:
+                _, aux = smooth_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, dev), tau, scores_out=scores)
+            else:
+                _, aux = maxsim_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, dev), scores_out=scores)
+        elif smooth:
+            scores = torch.empty((B, C), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.msim_smooth_fwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(corpus.offsets), C, width,
+                                       tau, _lib.ptr(scores), max(C, 1), _lib.current_stream_handle(dev))
+            _lib.check(rc, "msim_smooth_fwd")
+        else:
+            scores = maxsim_scores(qc, corpus)
+        stats = torch.empty((3,), dtype=torch.float32, device=dev)
+        G = pairs = coef = order = None
+        if mode == MODE_PAIRWISE:
+            pairs = torch.empty((2 * B, 2), dtype=torch.int32, device=dev)
+            coef = torch.empty((2 * B,), dtype=torch.float32, device=dev)
+            order = torch.empty((2 * B,), dtype=torch.int32, device=dev)
+        elif need_grad:
+            G = torch.empty((B, C), dtype=torch.float32, device=dev)
+        ws = _epilogue_workspace(B, dev)
+        with torch.cuda.device(dev):
+            rc = L.msim_loss_epilogue(mode, _lib.ptr(scores), C, B, C, _lib.ptr(qc), _lib.dtype_code(qc.dtype), Lq, width, offset,
+                                      float(temperature), int(normalize), int(filtering), float(filter_threshold),
+                                      float(filter_factor), _lib.ptr(G), _lib.ptr(pairs), _lib.ptr(coef), _lib.ptr(order),
+                                      _lib.ptr(ws), _lib.ptr(stats), _lib.current_stream_handle(dev))
+        _lib.check(rc, "msim_loss_epilogue")
+        ctx.mode, ctx.smooth, ctx.tau = mode, smooth, tau
+        ctx.save_for_backward(qc, dc, corpus.offsets, G, pairs, coef, order, aux)
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats                 # the loss as a tensor of its own (not a view of the statistics buffer)
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):
+        qc, dc, offsets, G, pairs, coef, order, aux = ctx.saved_tensors
+        B, C = qc.shape[0], dc.shape[0]
+        up = grad_loss.to(torch.float32)
+        if ctx.mode == MODE_PAIRWISE:
+            gp = coef * up
+            if ctx.smooth:
+                dq, dd = _smooth_backward(qc, dc, offsets, pairs, gp, ctx.tau, order=order)
+            else:
+                _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
+                dq, dd = _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax)
+        else:
+            gp = (G * up).reshape(-1)
+            all_pairs, all_order = _all_pairs(B, C, qc.device), _all_pairs_order(B, C, qc.device)
+            if ctx.smooth:
+                dq, dd = _smooth_backward(qc, dc, offsets, all_pairs, gp, ctx.tau, lse=aux, order=all_order)
+            else:
+                dq, dd = _pairs_backward(qc, dc, offsets, all_pairs, all_order, gp, aux)
+        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None) + (None,) * 9
 
 
 def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
@@ -400,10 +486,43 @@ class ColbertModule(torch.nn.Module):
 
     def _apply_normalization(self, scores: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
         out = scores / (lengths.unsqueeze(1) if scores.ndim == 2 else lengths)
-        lo, hi = torch.aminmax(out)
-        if lo < -self.norm_tol or hi > 1 + self.norm_tol:   # the reference only prints here (:64-70)
-            print(f"Scores out of bounds after normalization: min={lo.item():.4f}, max={hi.item():.4f}, tol={self.norm_tol}")
+        self._report_bounds(torch.stack(torch.aminmax(out.detach())).to(torch.float32))
         return out
+
+    def _report_bounds(self, lo_hi: torch.Tensor) -> None:
+        """The reference prints when normalised scores leave [-tol, 1 + tol] (:62-70) -- and synchronises the host to find
+        out.  Here the two numbers travel to pinned memory asynchronously and the message of step k is printed when step
+        k + 1 (or a later one) finds them arrived: same diagnostic, no synchronisation in the training step.  Nothing is
+        recorded while a hipGraph is being captured."""
+        if lo_hi.device.type != "cuda":                       # CPU-sized helper use (the reference's own unit tests): check now
+            lo, hi = float(lo_hi[-2]), float(lo_hi[-1])
+            if lo < -self.norm_tol or hi > 1 + self.norm_tol:
+                print(f"Scores out of bounds after normalization: min={lo:.4f}, max={hi:.4f}, tol={self.norm_tol}")
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self._flush_bounds(wait=False)
+        if getattr(self, "_bounds_pending", None) is not None:
+            return                                           # the previous report is still in flight: keep that one
+        host = torch.empty((2,), dtype=torch.float32, pin_memory=True)
+        host.copy_(lo_hi[-2:], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(lo_hi.device))
+        self._bounds_pending = (host, ev)
+
+    def _flush_bounds(self, wait: bool = True) -> None:
+        pending = getattr(self, "_bounds_pending", None)
+        if pending is None:
+            return
+        host, ev = pending
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._bounds_pending = None
+        lo, hi = float(host[0]), float(host[1])
+        if lo < -self.norm_tol or hi > 1 + self.norm_tol:
+            print(f"Scores out of bounds after normalization: min={lo:.4f}, max={hi:.4f}, tol={self.norm_tol}")
 
     def _aggregate(self, scores_raw: torch.Tensor, use_smooth_max: bool, dim_max: int, dim_sum: int) -> torch.Tensor:
         reduced = self._smooth_max(scores_raw, dim=dim_max) if use_smooth_max else scores_raw.amax(dim=dim_max)
@@ -414,7 +533,27 @@ class ColbertModule(torch.nn.Module):
         limit = self.filter_threshold * scores[rows, pos_idx].unsqueeze(1)
         too_high = scores > limit
         too_high[rows, pos_idx] = False
-        scores[too_high] *= self.filter_factor
+        # in place like the reference (`scores[mask] *= factor`), written without boolean-mask indexing (its nonzero() is a
+        # host synchronisation): same values, same gradient
+        scores.mul_(torch.where(too_high, self.filter_factor, 1.0).to(scores.dtype))
+
+    def _fused_inbatch_loss(self, mode: int, query_embeddings, doc_embeddings, offset: int) -> torch.Tensor:
+        q, d = _autocast_inputs(query_embeddings, doc_embeddings)
+        _check_embeddings(q, d)
+        B, C = q.shape[0], d.shape[0]
+        _check_offset(B, C, offset)
+        if B > self.idx_buffer.numel():
+            raise RuntimeError(f"batch of {B} queries exceeds max_batch_size={self.idx_buffer.numel()} (idx_buffer, :27)")
+        if mode == MODE_PAIRWISE and C < 2:
+            raise RuntimeError("selected index k out of range")          # what scores.topk(2, dim=1) raises (:310)
+        widen = _widen32 if self.use_smooth_max else _widen
+        loss, stats = _FusedInBatchLoss.apply(widen(q), widen(d), mode, int(offset), float(self.temperature),
+                                              bool(self.normalize_scores), bool(self.pos_aware_negative_filtering),
+                                              float(self.filter_threshold), float(self.filter_factor),
+                                              bool(self.use_smooth_max), float(self.tau))
+        if self.normalize_scores:
+            self._report_bounds(stats)
+        return loss.to(_loss_dtype(query_embeddings))
 
     # -- shared front end of every in-batch loss: lengths, fused MaxSim, optional normalisation / filtering
     def _inbatch_scores(self, query_embeddings, doc_embeddings, offset, dense_grad=False):
@@ -445,12 +584,9 @@ class ColbertPairwiseCELoss(ColbertModule):
         self.pos_aware_negative_filtering = pos_aware_negative_filtering
 
     def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
-        scores, _, _ = self._inbatch_scores(query_embeddings, doc_embeddings, offset)
-        pos = scores.diagonal(offset=offset)                            # :309
-        best2 = scores.topk(2, dim=1).values                            # :310
-        neg = torch.where(best2[:, 0] == pos, best2[:, 1], best2[:, 0])  # :311 exact-equality selection
-        loss = F.softplus((neg - pos) / self.temperature).mean()        # :313
-        return loss.to(_loss_dtype(query_embeddings))
+        # :296-313 in two launches: fused MaxSim, then msim_loss_epilogue (lengths, normalisation, filtering, diagonal, top-2 with
+        # the exact-equality selection, softplus mean -- and the two gradient-carrying (query, doc) pairs per query)
+        return self._fused_inbatch_loss(MODE_PAIRWISE, query_embeddings, doc_embeddings, offset)
 
 
 class ColbertLoss(ColbertModule):
@@ -467,8 +603,9 @@ class ColbertLoss(ColbertModule):
         self.ce_loss = torch.nn.CrossEntropyLoss()
 
     def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
-        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset, dense_grad=True)
-        return self.ce_loss(scores / self.temperature, pos_idx).to(_loss_dtype(query_embeddings))   # :164
+        # :152-164 in two launches: the pair-list MaxSim over all pairs (keeps the routing for the dense gradient), then
+        # msim_loss_epilogue (lengths, normalisation, filtering, cross entropy and its gradient)
+        return self._fused_inbatch_loss(MODE_INFONCE, query_embeddings, doc_embeddings, offset)
 
 
 class ColbertSigmoidLoss(ColbertModule):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 10
+#define MSIM_ABI_VERSION 11
 
 /* error codes */
 #define MSIM_OK 0
@@ -152,6 +152,31 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
                           const int32_t *pairs, const int32_t *order_by_doc,
                           const float *g, const float *lse, int n_pairs, float tau,
                           float *dQ, float *dD, void *workspace, void *stream);
+
+/*
+ * The [B, C]-sized epilogue of the in-batch losses, value and gradient with respect to the MaxSim scores in one launch
+ * (no host synchronisation, hipGraph-capturable).  Replaces, for scores = the raw MaxSim matrix of msim_fwd / msim_pairs_argmax,
+ *   colpali_engine/loss/late_interaction_losses.py:296 (lengths), :300-301 (normalisation), :303-307 (pos-aware filtering) and
+ *   MSIM_LOSS_PAIRWISE  :309-313  softplus((hardest in-batch negative - positive) / T).mean()     (ColbertPairwiseCELoss)
+ *   MSIM_LOSS_INFONCE   :164      cross_entropy(scores / T, pos_idx)                                (ColbertLoss)
+ * together with what autograd derives for them:
+ *   PAIRWISE  pairs int32 [2B, 2] = the two (query, doc) entries per query that carry a gradient (positive, selected negative),
+ *             sorted by (query, doc); coef fp32 [2B] = dLoss/dscore of each for a unit upstream gradient; order int32 [2B] = the
+ *             stable by-document permutation msim_pairs_bwd wants.  Always exactly 2B pairs: nothing to read back.  C >= 2.
+ *   INFONCE   G fp32 [B, ld] = dLoss/dscores (dense).
+ * Q [B, Lq, width] are the query embeddings (q_dtype as in msim_fwd): lengths[b] = number of tokens whose first component is
+ * non-zero.  out fp32 [3] = loss, min and max of the normalised scores (the reference prints when they leave [-tol, 1+tol]).
+ * workspace: msim_loss_epilogue_workspace_bytes(B) bytes, 16-byte aligned, ZERO-FILLED once by the caller before its first use
+ * (the call leaves it ready for the next one); one workspace per stream.  offset + B <= C.
+ */
+#define MSIM_LOSS_PAIRWISE 0
+#define MSIM_LOSS_INFONCE 1
+size_t msim_loss_epilogue_workspace_bytes(int B);
+int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C,
+                       const void *Q, int q_dtype, int Lq, int width, int offset,
+                       float temperature, int normalize, int filter, float filter_threshold, float filter_factor,
+                       float *G, int32_t *pairs, float *coef, int32_t *order,
+                       void *workspace, float *out, void *stream);
 
 /*
  * Embedding head: the last three lines of every Col* model forward, producing the scorer's corpus format.

@@ -123,3 +123,174 @@ def test_probe_stream_runs_and_validates_arguments(amd):
     assert L.msim_probe_stream(2, x128.data_ptr(), 4096, 128, sink.data_ptr(), st) != 0      # row shorter than a piece
     assert L.msim_probe_stream(7, x128.data_ptr(), 4096, 128, sink.data_ptr(), st) != 0
     assert L.msim_probe_stream(0, None, 4096, 128, sink.data_ptr(), st) != 0
+
+
+@pytest.mark.parametrize("cls,kw", [("ColbertPairwiseCELoss", dict(normalize_scores=False)),
+                                    ("ColbertPairwiseCELoss", dict(pos_aware_negative_filtering=True)),
+                                    ("ColbertLoss", dict()),
+                                    ("ColbertLoss", dict(use_smooth_max=True)),
+                                    ("ColbertPairwiseCELoss", dict(use_smooth_max=True, normalize_scores=False))])
+def test_whole_loss_step_forward_and_backward_captures_in_one_hipgraph(amd, cls, kw):
+    """A training step of the loss -- MaxSim forward, the [B, C] epilogue, gradient routing and both backward kernels -- has no
+    host synchronisation and no data-dependent launch shape: it is captured ONCE and replayed on new embeddings, and the
+    replayed loss and gradients equal an eager run on the same numbers bit for bit."""
+    dev = torch.device("cuda:0")
+    B, C, Lq, Ld, offset = 8, 24, 32, 96, 8
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        Q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1)
+        D = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1)
+        Q[1, :5] = 0
+        for b in range(B):
+            D[offset + b, :Lq] = torch.nn.functional.normalize(Q[b] + 0.5 * torch.randn(Lq, 128, generator=g), dim=-1)
+        return Q.to(torch.bfloat16).to(dev), D.to(torch.bfloat16).to(dev)
+
+    loss_fn = getattr(amd, cls)(**kw)
+    sq, sd = (t.clone().requires_grad_(True) for t in batch(0))
+
+    def step():
+        sq.grad = sd.grad = None
+        loss = loss_fn(sq, sd, offset=offset)
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                                   # warm-up: caches, one-time attribute calls
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    sq.grad = sd.grad = None
+    with torch.cuda.graph(graph):
+        loss_static = loss_fn(sq, sd, offset=offset)
+        loss_static.backward()
+    gq_static, gd_static = sq.grad, sd.grad
+    for seed in (1, 2):
+        nq, nd = batch(seed)
+        with torch.no_grad():
+            sq.copy_(nq)
+            sd.copy_(nd)
+        graph.replay()
+        torch.cuda.synchronize()
+        eq, ed = nq.clone().requires_grad_(True), nd.clone().requires_grad_(True)
+        eager = loss_fn(eq, ed, offset=offset)
+        eager.backward()
+        assert torch.equal(loss_static, eager.detach())
+        assert torch.equal(gq_static, eq.grad) and torch.equal(gd_static, ed.grad)
+
+
+def test_loss_step_does_not_synchronise_the_host(amd):
+    """No call on the path of a training step may block the host: with a long-running kernel queued in front, building the whole
+    step (forward + backward) must return while that kernel is still running."""
+    import time
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    Q = torch.nn.functional.normalize(torch.randn(16, 32, 128, generator=g), dim=-1).to(torch.bfloat16).to(dev)
+    D = torch.nn.functional.normalize(torch.randn(64, 200, 128, generator=g), dim=-1).to(torch.bfloat16).to(dev)
+    big = torch.randn(8192, 8192, device=dev)
+    for cls, kw in (("ColbertPairwiseCELoss", {}), ("ColbertLoss", {}), ("ColbertLoss", dict(pos_aware_negative_filtering=True)),
+                    ("ColbertSigmoidLoss", {}), ("ColbertPairwiseCELoss", dict(use_smooth_max=True))):
+        fn = getattr(amd, cls)(**kw)
+        if cls == "ColbertSigmoidLoss":
+            d_in = D[:16].clone().requires_grad_(True)
+        else:
+            d_in = D.clone().requires_grad_(True)
+        q_in = Q.clone().requires_grad_(True)
+        fn(q_in, d_in).backward()                               # warm-up
+        torch.cuda.synchronize()
+        done = torch.cuda.Event()
+        for _ in range(30):                                      # ~100+ ms of queued GPU work
+            big = big @ big * 1e-4
+        done.record()
+        t0 = time.perf_counter()
+        loss = fn(q_in, d_in)
+        loss.backward()
+        host_s = time.perf_counter() - t0
+        still_running = not done.query()
+        torch.cuda.synchronize()
+        assert still_running, (cls, kw, f"the step took {host_s * 1e3:.1f} ms on the host and outlived the queued work")
+
+
+def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
+    """msim_loss_epilogue against the reference's own torch lines (late_interaction_losses.py:300-313, :164) evaluated with
+    autograd in fp32 on the same score matrix: ties between equal scores, a positive that is not the best document, filtering
+    that hits the selected negative, padded (zero-first-component) query tokens."""
+    import torch.nn.functional as F
+
+    L = amd._lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    B, C, Lq, offset = 7, 19, 12, 5
+    Q = torch.randn(B, Lq, 128, generator=g)
+    Q[2, :4, 0] = 0
+    Q[5, 3, 0] = -0.0
+    Q = Q.to(torch.bfloat16).to(dev)
+    base = (torch.rand(B, C, generator=g) * 8 + 1)
+    base[0, offset + 0] = 20.0                       # positive is the best
+    base[1, 3] = base[1, offset + 1] = 15.0          # exact tie between the positive and another document
+    base[2, 0] = 30.0                                # positive is not the best
+    base[3, offset + 3] = 9.0; base[3, 1] = 8.9      # the hardest negative is above the filter threshold
+    base[4, 2] = base[4, 7] = 25.0                   # two tied best negatives
+    for mode, T, norm, filt in ((0, 1.0, False, False), (0, 0.5, True, True), (0, 1.0, True, False), (1, 0.02, True, False),
+                                (1, 0.5, False, True), (0, 0.02, False, True)):
+        scores = base.clone().to(dev).requires_grad_(True)
+        lengths = (Q[:, :, 0] != 0).sum(dim=1)
+        s = scores / lengths.unsqueeze(1) if norm else scores * 1.0
+        idx = torch.arange(B, device=dev)
+        pos_idx = idx + offset
+        if filt:
+            lim = 0.95 * s[idx, pos_idx].unsqueeze(1)
+            m = s > lim
+            m[idx, pos_idx] = False
+            s = s * torch.where(m, 0.5, 1.0)
+        if mode == 0:
+            pos = s.diagonal(offset=offset)
+            top2 = s.topk(2, dim=1).values
+            neg = torch.where(top2[:, 0] == pos, top2[:, 1], top2[:, 0])
+            want = F.softplus((neg - pos) / T).mean()
+        else:
+            want = F.cross_entropy(s / T, pos_idx)
+        want.backward()
+        raw = base.clone().to(dev).contiguous()
+        G = torch.zeros((B, C), dtype=torch.float32, device=dev)
+        pairs = torch.empty((2 * B, 2), dtype=torch.int32, device=dev)
+        coef = torch.empty((2 * B,), dtype=torch.float32, device=dev)
+        order = torch.empty((2 * B,), dtype=torch.int32, device=dev)
+        ws = torch.zeros((L.msim_loss_epilogue_workspace_bytes(B),), dtype=torch.uint8, device=dev)
+        out = torch.empty((3,), dtype=torch.float32, device=dev)
+        for rep in range(2):                          # twice on the same workspace: the ticket counter resets itself
+            rc = L.msim_loss_epilogue(mode, raw.data_ptr(), C, B, C, Q.data_ptr(), 0, Lq, 128, offset, T, int(norm), int(filt), 0.95, 0.5,
+                                      G.data_ptr(), pairs.data_ptr(), coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, L.msim_last_error()
+        torch.cuda.synchronize()
+        assert abs(float(out[0]) - float(want)) <= 1e-5 * abs(float(want)) + 1e-6, (mode, T, norm, filt)
+        if mode == 0:
+            got = torch.zeros((B, C), dtype=torch.float32, device=dev)
+            got.index_put_((pairs[:, 0].long(), pairs[:, 1].long()), coef, accumulate=True)
+            assert pairs[:, 0].tolist() == [b for b in range(B) for _ in range(2)]
+            assert all(pairs[2 * b, 1] <= pairs[2 * b + 1, 1] for b in range(B))
+            docs = pairs[:, 1].long()
+            perm = order.long()
+            assert sorted(perm.tolist()) == list(range(2 * B))
+            assert torch.equal(docs[perm], docs[torch.sort(docs, stable=True).indices])
+            assert torch.equal(perm, torch.sort(docs, stable=True).indices)
+        else:
+            got = G
+        # tied scores: torch splits / picks differently, the sum over the tied entries is what is defined
+        ref = scores.grad
+        assert torch.allclose(got.sum(dim=1), ref.sum(dim=1), rtol=1e-4, atol=1e-6)
+        untied = torch.ones(B, dtype=torch.bool)
+        if mode == 0:
+            untied[1] = untied[4] = False
+        assert torch.allclose(got[untied], ref[untied], rtol=1e-4, atol=1e-7), (mode, T, norm, filt)
+        want_lo = (raw / lengths.unsqueeze(1)).min() if norm else raw.min()
+        assert abs(float(out[1]) - float(want_lo)) < 1e-5
+    # argument checks
+    assert L.msim_loss_epilogue(0, raw.data_ptr(), C, B, C, Q.data_ptr(), 0, Lq, 128, C - B + 1, 1.0, 0, 0, 0.95, 0.5, None, pairs.data_ptr(),
+                                coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(), None) == -1
+    assert L.msim_loss_epilogue(0, raw.data_ptr(), 1, 1, 1, Q.data_ptr(), 0, Lq, 128, 0, 1.0, 0, 0, 0.95, 0.5, None, pairs.data_ptr(),
+                                coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(), None) == -1
