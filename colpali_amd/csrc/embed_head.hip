@@ -53,6 +53,13 @@ constexpr int kHeadRingW = 2;                        // weight chunks
 constexpr int kHeadWBase = kHeadRingA * kHeadABytes; // 128 KiB
 constexpr int kHeadLds = kHeadWBase + kHeadRingW * kHeadWBytes;   // 160 KiB: the whole LDS of a CU
 constexpr int kHeadThreads = (kHeadWaves + 1) * 64;  // 8 compute waves + the weight loader
+// flag-synchronised variant: hidden-state ring 3 deep (96 KiB, 64 KiB in flight), weight ring 3 deep (48 KiB, the loader runs up
+// to two chunks ahead), one 64-byte line of counters behind them
+constexpr int kHeadFRingA = 3;
+constexpr int kHeadFRingW = 3;
+constexpr int kHeadFWBase = kHeadFRingA * kHeadABytes;                   // 96 KiB
+constexpr int kHeadFFlags = kHeadFWBase + kHeadFRingW * kHeadWBytes;      // 144 KiB
+constexpr int kHeadFLds = kHeadFFlags + 64;
 
 struct HeadArgs {
     long long M;          // token rows
@@ -62,13 +69,25 @@ struct HeadArgs {
 
 // row_map[m] (int32, ceil(M / 256) * 256 entries):  v >= 0: write the normalised row to out row v;
 //   v == -1: drop the row;  v <= -2: write a row of zeros to out row (-2 - v)   (a masked position kept in place).
-template <bool F16>
+// FLAGS = false: the weight ring is handed over with one raw s_barrier per K chunk (all nine waves in lock step).
+// FLAGS = true : no workgroup barrier at all.  The loader wave publishes "weight chunks landed" in an LDS counter and reads eight
+//                "chunks consumed" counters before it overwrites a slot; a compute wave polls the first (only when its cached copy
+//                runs out) and bumps its own counter right behind its last operand read of the chunk.  LDS operations of one wave
+//                execute in order and an LDS-DMA load has landed once vmcnt says so, so counter writes need no fence.  The eight
+//                private hidden-state streams are no longer coupled: a wave whose rows arrive late delays nobody, and the waves
+//                drift out of phase, so one wave's operand reads overlap another's MFMAs.
+template <bool F16, bool FLAGS = false>
 __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
                                                                      const int32_t *__restrict__ row_map,
                                                                      uint16_t *__restrict__ out, HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kRingA = FLAGS ? kHeadFRingA : kHeadRingA;
+    constexpr int kRingW = FLAGS ? kHeadFRingW : kHeadRingW;
+    constexpr int kWBase = FLAGS ? kHeadFWBase : kHeadWBase;
+    volatile int *const f_ready = reinterpret_cast<volatile int *>(smem + kHeadFFlags);          // weight chunks landed
+    volatile int *const f_done = reinterpret_cast<volatile int *>(smem + kHeadFFlags) + 1;       // [8] chunks consumed per compute wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -89,6 +108,11 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
     const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int total = my_tiles * n_chunks;                                   // chunks this workgroup walks (= its barriers)
 
+    if constexpr (FLAGS) {
+        if (threadIdx.x < 16) f_ready[threadIdx.x] = 0;      // the only workgroup barrier of the kernel: counters zeroed
+        __syncthreads();
+    }
+
     if (wave == kHeadWaves) {
         // ================= weight loader: W chunk c -> ring slot c & 1, one chunk ahead of the consumers
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, kHeadN * row_bytes, 0x00020000);
@@ -99,12 +123,36 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             w_src[i] = n * row_bytes + ((((lane & 7) ^ ((n >> 1) & 7))) << 4);
         }
         auto load_w = [&](int c) {
-            char *dst = smem + kHeadWBase + (c & 1) * kHeadWBytes;
+            char *dst = smem + kWBase + (c % kRingW) * kHeadWBytes;
             const int soff = (c % n_chunks) * (kHeadBK * 2);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, MSIM_LDS(dst + i * 1024), 16, w_src[i], soff, 0, 0);
         };
+        if constexpr (FLAGS) {
+            for (int c = 0; c < total; ++c) {
+                // slot c % 3 was last read for chunk c - 3: every compute wave must have consumed c - 2 chunks
+                if (c >= kRingW) {
+                    for (;;) {
+                        int v = f_done[lane & 7];
+                        v = min(v, __shfl_xor(v, 1));
+                        v = min(v, __shfl_xor(v, 2));
+                        v = min(v, __shfl_xor(v, 4));
+                        if (__builtin_amdgcn_readfirstlane(v) >= c - (kRingW - 1)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                load_w(c);
+                if (c >= 1) {
+                    wait_vmcnt<16>();            // chunk c - 1 has landed (chunk c stays in flight)
+                    if (lane == 0) *f_ready = c;
+                }
+            }
+            wait_vmcnt<0>();
+            if (lane == 0) *f_ready = total;
+            return;
+        }
         if (total > 0) load_w(0);
         for (int c = 0; c < total; ++c) {
             wait_vmcnt<0>();                 // W chunk c has landed
@@ -131,7 +179,7 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             a_rd[ks] = arow * 128 + ((((2 * ks + half) << 4)) ^ ax);
-            b_rd[ks] = kHeadWBase + l31 * 128 + ((((2 * ks + half) << 4)) ^ bx);
+            b_rd[ks] = kWBase + l31 * 128 + ((((2 * ks + half) << 4)) ^ bx);
         }
     }
 
@@ -153,7 +201,7 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
 #pragma unroll
         for (int i = 0; i < 4; ++i)   // hidden states: streamed once -> nt
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, MSIM_LDS(dst + i * 1024), 16, a_src[i], soff, 0, 2);
-        p_slot = (p_slot + 1 == kHeadRingA) ? 0 : p_slot + 1;
+        p_slot = (p_slot + 1 == kRingA) ? 0 : p_slot + 1;
         if (++p_chunk == n_chunks) {
             p_chunk = 0;
             p_tile += gridDim.x;
@@ -162,9 +210,9 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
         return true;
     };
 #pragma unroll
-    for (int i = 0; i < kHeadRingA - 1; ++i) produce();
+    for (int i = 0; i < kRingA - 1; ++i) produce();
 
-    int c_slot = 0, c_count = 0;
+    int c_slot = 0, c_count = 0, w_slot = 0, seen_ready = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         f32x16 acc[4];
 #pragma unroll
@@ -173,11 +221,20 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
         for (int ch = 0; ch < n_chunks; ++ch, ++c_count) {
             // the slot consumed in the previous iteration is private to this wave and free again: refill it, then wait for
             // this chunk's 4 loads (the rows are this wave's own -- no barrier is involved in the A stream at all)
-            if (produce()) wait_vmcnt<4 * (kHeadRingA - 1)>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();   // W chunk landed (loader wave); everyone finished reading the previous W chunk
+            if (produce()) wait_vmcnt<4 * (kRingA - 1)>(); else wait_vmcnt<0>();
+            if constexpr (FLAGS) {
+                while (seen_ready <= c_count) {                    // weight chunk c_count not known to have landed: poll
+                    seen_ready = *f_ready;
+                    if (seen_ready <= c_count) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");                      // no operand read may move above the poll
+            } else {
+                __builtin_amdgcn_s_barrier();   // W chunk landed (loader wave); everyone finished reading the previous W chunk
+            }
             const char *sa = smem + c_slot * kHeadABytes;
-            const char *sw = smem + (c_count & 1) * kHeadWBytes;
-            c_slot = (c_slot + 1 == kHeadRingA) ? 0 : c_slot + 1;
+            const char *sw = smem + w_slot * kHeadWBytes;
+            w_slot = (w_slot + 1 == kRingW) ? 0 : w_slot + 1;
+            c_slot = (c_slot + 1 == kRingA) ? 0 : c_slot + 1;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + a_rd[ks]);
@@ -187,6 +244,11 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
                     // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
                     acc[j] = mfma32<F16>(af, bf, acc[j]);
                 }
+            }
+            if constexpr (FLAGS) {
+                // every operand read of this chunk has been ISSUED (LDS executes a wave's operations in order): release the slot
+                asm volatile("" ::: "memory");
+                if (lane == 0) f_done[wave] = c_count + 1;
             }
         }
 

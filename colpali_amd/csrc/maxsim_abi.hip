@@ -946,13 +946,21 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X), *w = static_cast<const uint16_t *>(W), *b = static_cast<const uint16_t *>(bias);
     uint16_t *o = static_cast<uint16_t *>(out);
-    auto go = [&](auto kern, std::atomic<int> *configured) -> int {
-        if (int rc = allow_lds(kern, msim::kHeadLds, configured)) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(msim::kHeadThreads), msim::kHeadLds, st, x, w, b, row_map, o, a);
+    auto go = [&](auto kern, std::atomic<int> *configured, int lds) -> int {
+        if (int rc = allow_lds(kern, lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(msim::kHeadThreads), lds, st, x, w, b, row_map, o, a);
         return MSIM_OK;
     };
-    static std::atomic<int> configured[2][kMaxDevices];
-    const int rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true>, configured[0]) : go(msim::embed_head_kernel<false>, configured[1]);
+    static std::atomic<int> configured[4][kMaxDevices];
+    // MSIM_HEAD_BARRIER=1 selects the first version (one s_barrier per K chunk) for A/B measurements (not part of the ABI)
+    static const bool barrier_variant = getenv("MSIM_HEAD_BARRIER") && atoi(getenv("MSIM_HEAD_BARRIER")) != 0;
+    int rc;
+    if (barrier_variant)
+        rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true, false>, configured[0], msim::kHeadLds)
+                                     : go(msim::embed_head_kernel<false, false>, configured[1], msim::kHeadLds);
+    else
+        rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true, true>, configured[2], msim::kHeadFLds)
+                                     : go(msim::embed_head_kernel<false, true>, configured[3], msim::kHeadFLds);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));

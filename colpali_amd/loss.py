@@ -478,7 +478,12 @@ class ColbertModule(torch.nn.Module):
         self.filter_factor = filter_factor
 
     def _get_idx(self, batch_size: int, offset: int, device: torch.device):
-        rows = self.idx_buffer[:batch_size].to(device)
+        if self.idx_buffer.device == torch.device(device):
+            rows = self.idx_buffer[:batch_size]
+        else:
+            # the reference copies its (CPU) buffer to the device on every call -- a blocking pageable H2D copy, i.e. a host
+            # synchronisation per step unless the module itself was moved to the GPU; same values from a device-side arange
+            rows = torch.arange(min(batch_size, self.idx_buffer.numel()), device=device, dtype=self.idx_buffer.dtype)
         return rows, rows + offset
 
     def _smooth_max(self, scores: torch.Tensor, dim: int) -> torch.Tensor:
@@ -529,7 +534,7 @@ class ColbertModule(torch.nn.Module):
         return reduced.sum(dim=dim_sum)
 
     def _filter_high_negatives(self, scores: torch.Tensor, pos_idx: torch.Tensor) -> None:
-        rows = self.idx_buffer[: scores.size(0)].to(scores.device)
+        rows, _ = self._get_idx(scores.size(0), 0, scores.device)
         limit = self.filter_threshold * scores[rows, pos_idx].unsqueeze(1)
         too_high = scores > limit
         too_high[rows, pos_idx] = False
