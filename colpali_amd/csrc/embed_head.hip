@@ -76,7 +76,8 @@ struct HeadArgs {
 //                execute in order and an LDS-DMA load has landed once vmcnt says so, so counter writes need no fence.  The eight
 //                private hidden-state streams are no longer coupled: a wave whose rows arrive late delays nobody, and the waves
 //                drift out of phase, so one wave's operand reads overlap another's MFMAs.
-template <bool F16, bool FLAGS = false>
+// PIPE: the operand fetch of a chunk is software-pipelined by hand two k-steps ahead of the MFMAs (see the loop).
+template <bool F16, bool FLAGS = false, bool PIPE = false>
 __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
@@ -235,14 +236,40 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             const char *sw = smem + w_slot * kHeadWBytes;
             w_slot = (w_slot + 1 == kRingW) ? 0 : w_slot + 1;
             c_slot = (c_slot + 1 == kRingA) ? 0 : c_slot + 1;
+            if constexpr (PIPE) {
+                // Operand fetch software-pipelined by hand, two k-steps ahead of the MFMAs (three fragment buffers of 1 + 4 operands =
+                // 60 VGPRs; nine waves per CU leave 168 per wave).  Left to itself hipcc keeps three fragment registers and issues
+                // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma sixteen times per chunk: every MFMA then waits out a full LDS round trip
+                // (the loop was LDS-LATENCY bound: ~2400 cycles per chunk and wave for 512 cycles of MFMA).  The scheduling barriers
+                // keep the compiler from folding the stages back together; the waitcnt pass still derives the counted lgkmcnt waits.
+                bf16x8 fa[3], fw[3][4];
+                auto fetch = [&](int ks, int buf) {
+                    fa[buf] = *reinterpret_cast<const bf16x8 *>(sa + a_rd[ks]);
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) fw[buf][j] = *reinterpret_cast<const bf16x8 *>(sw + b_rd[ks] + j * 4096);
+                };
+                fetch(0, 0);
+                fetch(1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 2 < 4) fetch(ks + 2, (ks + 2) % 3);
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)   // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
+                        acc[j] = mfma32<F16>(fa[ks % 3], fw[ks % 3][j], acc[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + a_rd[ks]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + a_rd[ks]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(sw + b_rd[ks] + j * 4096);
-                    // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
-                    acc[j] = mfma32<F16>(af, bf, acc[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(sw + b_rd[ks] + j * 4096);
+                        // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
+                        acc[j] = mfma32<F16>(af, bf, acc[j]);
+                    }
                 }
             }
             if constexpr (FLAGS) {

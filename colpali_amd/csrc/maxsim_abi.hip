@@ -951,16 +951,22 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         hipLaunchKernelGGL(kern, dim3(grid), dim3(msim::kHeadThreads), lds, st, x, w, b, row_map, o, a);
         return MSIM_OK;
     };
-    static std::atomic<int> configured[4][kMaxDevices];
-    // MSIM_HEAD_BARRIER=1 selects the first version (one s_barrier per K chunk) for A/B measurements (not part of the ABI)
-    static const bool barrier_variant = getenv("MSIM_HEAD_BARRIER") && atoi(getenv("MSIM_HEAD_BARRIER")) != 0;
+    static std::atomic<int> configured[8][kMaxDevices];
+    // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
+    // fetch (tuning knob for A/B measurements, not part of the ABI; the default is the measured winner)
+    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 3 : 0;
     int rc;
-    if (barrier_variant)
-        rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true, false>, configured[0], msim::kHeadLds)
-                                     : go(msim::embed_head_kernel<false, false>, configured[1], msim::kHeadLds);
-    else
-        rc = dtype == MSIM_DTYPE_F16 ? go(msim::embed_head_kernel<true, true>, configured[2], msim::kHeadFLds)
-                                     : go(msim::embed_head_kernel<false, true>, configured[3], msim::kHeadFLds);
+    const bool f16 = dtype == MSIM_DTYPE_F16;
+    switch (variant) {
+        case 1: rc = f16 ? go(msim::embed_head_kernel<true, true, false>, configured[0], msim::kHeadFLds)
+                         : go(msim::embed_head_kernel<false, true, false>, configured[1], msim::kHeadFLds); break;
+        case 2: rc = f16 ? go(msim::embed_head_kernel<true, false, true>, configured[2], msim::kHeadLds)
+                         : go(msim::embed_head_kernel<false, false, true>, configured[3], msim::kHeadLds); break;
+        case 3: rc = f16 ? go(msim::embed_head_kernel<true, true, true>, configured[4], msim::kHeadFLds)
+                         : go(msim::embed_head_kernel<false, true, true>, configured[5], msim::kHeadFLds); break;
+        default: rc = f16 ? go(msim::embed_head_kernel<true, false, false>, configured[6], msim::kHeadLds)
+                          : go(msim::embed_head_kernel<false, false, false>, configured[7], msim::kHeadLds); break;
+    }
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));

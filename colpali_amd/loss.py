@@ -630,7 +630,8 @@ class ColbertSigmoidLoss(ColbertModule):
         scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset, dense_grad=True)
         n = scores.size(0)
         sign = -torch.ones(n * n, device=scores.device)                 # :457-459: +1 on the positives of the flattened square
-        sign[pos_idx * (n + 1)] = 1.0
+        flat_pos = pos_idx * (n + 1)
+        sign.scatter_(0, flat_pos, torch.ones_like(flat_pos, dtype=sign.dtype))   # `sign[flat_pos] = 1.0` synchronises the host
         flat = scores.view(-1) / self.temperature                       # :462 (requires C == B, like the reference)
         return F.softplus(-flat * sign).mean().to(_loss_dtype(query_embeddings))
 
