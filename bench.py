@@ -51,7 +51,7 @@ def parse_args():
                          "BASELINE config 4 over 8 GPUs")
     ap.add_argument("--doc-len", type=int, default=1024)
     ap.add_argument("--nq", type=int, default=4, help="queries per step (32 tokens each); 4 = BASELINE config 1's query batch")
-    ap.add_argument("--regimes", type=str, default="1,32,1000",
+    ap.add_argument("--regimes", type=str, default="1,8,16,32,1000",
                     help="other query-batch sizes measured after the headline and reported under 'regimes' ('' = none)")
     ap.add_argument("--q-len", type=int, default=32)
     ap.add_argument("--topk", type=int, default=10)
@@ -356,6 +356,39 @@ def topk_parity(amd, q, corpus, scores, top_s, top_i, k, n_queries=2, n_random=1
                     "accumulate); ids_equal tolerates swaps only between docs closer than 2 x max_rel_err"}
 
 
+def mfma_ceiling(amd, corpus):
+    """The machine's own matrix-core ceiling under its power budget (msim_probe_mfma, include/maxsim.h): back-to-back
+    v_mfma_f32_32x32x16_bf16 on rows of the resident shard (the operand values the scorer multiplies), two waves per SIMD, no HBM
+    traffic.  `kernel_mix` = with K1b's operand path (A fragments re-read from LDS) and its max folds; `registers_only` = nothing
+    but MFMAs.  MI355X clocks to its power budget: on real operand values the chip does not reach the 2.5 PFLOP/s of
+    1024 SIMDs x 1024 FLOP/clk x 2.4 GHz (on zeros it nearly does), so this is what an MFMA-bound kernel can be held against."""
+    L = amd._lib.lib()
+    rows = int(corpus.blob.shape[0])
+    if rows < 256 * 8 * 5 * 32:
+        return None
+    sink = torch.zeros(4, dtype=torch.float32, device=corpus.blob.device)
+    st = torch.cuda.current_stream()
+    iters = 4000
+    flop = 256 * 8 * iters * 32 * 32768
+    out = {}
+    for name, variant in (("kernel_mix", 3), ("registers_only", 0)):
+        ms = []
+        for i in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            rc = L.msim_probe_mfma(variant, corpus.blob.data_ptr(), rows, iters, sink.data_ptr(), st.cuda_stream)
+            b.record(st)
+            torch.cuda.synchronize()
+            if rc != 0:
+                raise RuntimeError(f"msim_probe_mfma failed: {L.msim_last_error().decode()}")
+            if i >= 2:
+                ms.append(a.elapsed_time(b))
+        out[name + "_tflops"] = flop / sorted(ms)[len(ms) // 2] / 1e9
+    out["what"] = ("msim_probe_mfma on rows of the resident shard: 32x32x16 bf16 MFMAs back to back, 2 waves per SIMD, no memory traffic; "
+                   "kernel_mix = A fragments from LDS + max folds (K1b's instruction mix), registers_only = MFMAs alone")
+    return out
+
+
 def _free_port():
     import socket
 
@@ -469,6 +502,11 @@ def main():
         out["roofline"]["stream_ceiling_what"] = ceil_["what"]
         if out["roofline"]["bound"] == "hbm":
             out["roofline"]["frac_of_stream_ceiling"] = out["roofline"]["achieved"] / ceil_["gbs"]
+    ceil_m = mfma_ceiling(amd, corpus) if corpus.blob.shape[1] == 128 else None
+    if ceil_m:
+        out["mfma_ceiling"] = ceil_m
+        if out["roofline"]["bound"] == "mfma":
+            out["roofline"]["frac_of_mfma_ceiling"] = out["roofline"]["achieved"] / ceil_m["kernel_mix_tflops"]
     if not args.no_parity:
         # every rank checks its own shard (the CPU oracle as the checker); the verdicts are combined below
         local_top = amd.topk(scores, args.topk, corpus.id_base)
@@ -518,6 +556,8 @@ def main():
         regimes.append({"n_queries": nq, "steps": steps, "pairs_per_s": nq * args.docs * world * steps / d,
                         "ms_per_step": d / steps * 1e3, "kernel_ms": r["kernel_ms"], "bound": r["bound"],
                         "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"]})
+        if ceil_m and r["bound"] == "mfma":
+            regimes[-1]["frac_of_mfma_ceiling"] = r["mfma_tflops"] / ceil_m["kernel_mix_tflops"]
         del qq
     out["regimes"] = regimes
 

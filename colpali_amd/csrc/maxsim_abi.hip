@@ -116,7 +116,10 @@ struct FwdCall {
     unsigned flags;
     const DeviceInfo *di;
     hipStream_t st;
+    void *workspace = nullptr;   // msim_fwd_workspace_bytes() bytes or null
 };
+
+constexpr size_t kFwdWorkspaceBytes = 4096;   // K1b's convoy counters: n_ranges * n_qblocks <= 8 * 64 ints
 
 constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup (launch_stream picks 2 for 3-4 tiles)
 
@@ -196,6 +199,15 @@ int launch_batch(const FwdCall &c) {
     const int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
     a.n_ranges = 8 * sub;
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
+    // convoy (maxsim_batch.hip): only when several query blocks share a range AND all of them are resident at once
+    a.convoy = nullptr;
+    static const bool convoy_off = getenv("MSIM_BATCH_CONVOY") && atoi(getenv("MSIM_BATCH_CONVOY")) == 0;   // A/B knob
+    if (c.workspace && !convoy_off && a.n_qblocks > 1 && a.n_qblocks <= cus_per_xcd && a.n_qblocks <= 64 &&
+        (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
+        a.convoy = static_cast<int *>(c.workspace);
+        if (hipMemsetAsync(a.convoy, 0, (size_t)a.n_ranges * a.n_qblocks * sizeof(int), c.st) != hipSuccess)
+            return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
+    }
     hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", TPQ, NW, hipGetErrorString(e));
@@ -636,10 +648,16 @@ int msim_abi_version(void) { return MSIM_ABI_VERSION; }
 
 const char *msim_last_error(void) { return g_err; }
 
-size_t msim_fwd_workspace_bytes(int, int, int, int, int) { return 0; }
+size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim) {
+    // the only scratch msim_fwd uses: the progress counters of K1b's convoy, needed once more than one query block streams a
+    // document range (more than 32 token tiles of bf16 / fp16, width 128).  Passing NULL instead only switches the convoy off.
+    if (n_q <= 0 || n_d <= 0 || Lq <= 0 || !is_tuned(dtype, dim, Lq)) return 0;
+    const long long tiles = (long long)n_q * ((Lq + msim::kTokTile - 1) / msim::kTokTile);
+    return tiles > 32 ? kFwdWorkspaceBytes : 0;
+}
 
 int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
-             int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags, void *, void *stream) {
+             int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags, void *workspace, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0) return fail(MSIM_EINVAL, "negative size (n_q=%d n_d=%d Lq=%d)", n_q, n_d, Lq);
     if (n_q == 0 || n_d == 0) return MSIM_OK;
     if (!scores) return fail(MSIM_EINVAL, "null pointer argument");
@@ -695,6 +713,7 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
     c.n_d = n_d;
     c.flags = flags;
     c.st = static_cast<hipStream_t>(stream);
+    c.workspace = workspace;
     return dtype == MSIM_DTYPE_F16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c);
 }
 

@@ -44,6 +44,22 @@ def _require_gpu(device: Union[str, torch.device]) -> torch.device:
     return dev
 
 
+_fwd_ws = {}
+
+
+def _fwd_workspace(nbytes: int, device: torch.device) -> Optional[torch.Tensor]:
+    """msim_fwd's scratch (include/maxsim.h: one per stream; the call initialises what it uses), cached per (device, stream)."""
+    if nbytes == 0:
+        return None
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _fwd_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(_fwd_ws) > 64:
+            _fwd_ws.clear()
+        ws = _fwd_ws[key] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    return ws
+
+
 def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: bool = False,
                   out: Optional[torch.Tensor] = None, ref_bf16: Optional[bool] = None) -> torch.Tensor:
     """Device-level entry: [n_q, Lq, width] device tensor x packed corpus -> fp32 [n_q, n] on the device.
@@ -70,10 +86,11 @@ def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: 
         out = torch.empty((n_q, n), dtype=torch.float32, device=queries.device)
     elif out.shape != (n_q, n) or out.dtype != torch.float32 or out.stride(1) != 1:
         raise ValueError("out must be fp32 [n_q, n] with unit inner stride")
+    ws = _fwd_workspace(L.msim_fwd_workspace_bytes(dt, n_q, Lq, n, dim), queries.device)
     with torch.cuda.device(queries.device):
         rc = L.msim_fwd(dt, _lib.ptr(queries), n_q, Lq, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
                         _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out), out.stride(0) if n_q > 1 else max(n, 1),
-                        _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0, None,
+                        _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0, _lib.ptr(ws),
                         _lib.current_stream_handle(queries.device))
     _lib.check(rc, "msim_fwd")
     return out

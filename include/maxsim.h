@@ -64,8 +64,11 @@ extern "C" {
 int msim_abi_version(void);
 const char *msim_last_error(void);
 
-/* Number of bytes of scratch msim_fwd needs for this problem (0 today for
- * every supported shape; kept in the ABI so callers size a workspace once). */
+/* Number of bytes of scratch msim_fwd can use for this problem (16-byte aligned device memory, contents irrelevant: the
+ * call initialises what it uses on the stream).  Non-zero only when several query blocks stream the same document range
+ * (more than 32 token tiles): the workgroups of an XCD then keep in step through progress counters so that the range is
+ * fetched from HBM once and served to the others from that XCD's L2.  Passing NULL is legal and only switches that off.
+ * One workspace per stream. */
 size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim);
 
 /*
