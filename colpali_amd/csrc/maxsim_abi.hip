@@ -134,9 +134,9 @@ int stream_nt() {
     return v;
 }
 
-template <int QT, int TPQ, bool F16, int AUX, bool IL, int RING = kStreamRing>
+template <int QT, int TPQ, bool F16, int AUX, bool IL, int RING = kStreamRing, bool TILEMAJOR = false>
 int launch_stream_aux(const FwdCall &c) {
-    auto kern = msim::maxsim_stream_kernel<QT, TPQ, RING, F16, AUX, IL>;
+    auto kern = msim::maxsim_stream_kernel<QT, TPQ, RING, F16, AUX, IL, TILEMAJOR>;
     constexpr int lds = 4 * RING * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -174,6 +174,10 @@ int launch_stream(const FwdCall &c) {
     // MSIM_STREAM_RING=2|4 forces one of them (tuning knob, not part of the ABI).
     static const int ring_env = getenv("MSIM_STREAM_RING") ? atoi(getenv("MSIM_STREAM_RING")) : 0;
     const int ring = ring_env ? ring_env : ((QT == 3 || QT == 4) ? 2 : kStreamRing);
+    static const bool tile_major = getenv("MSIM_STREAM_TILEMAJOR") && atoi(getenv("MSIM_STREAM_TILEMAJOR")) != 0;   // A/B knob
+    if constexpr (QT == 4 && TPQ == 1 && !F16) {
+        if (ring == 2 && tile_major) return launch_stream_aux<QT, TPQ, F16, 2, true, 2, true>(c);
+    }
     if (ring == 2) return launch_stream_aux<QT, TPQ, F16, 2, true, 2>(c);
     if (stream_il() && stream_nt()) return launch_stream_aux<QT, TPQ, F16, 2, true>(c);
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);

@@ -31,7 +31,7 @@ struct PairsArgs {
 // One wave per pair (4 pairs per workgroup, wave-private LDS ring as in K1s).
 // TPQ = ceil(Lq / 32) token tiles of the pair's query live in registers.
 template <int TPQ, bool F16>
-__global__ __launch_bounds__(256) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
+__global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
                                                                   const uint16_t *__restrict__ D,
                                                                   const int32_t *__restrict__ d_off,
                                                                   const uint8_t *__restrict__ clamp0,

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void maxsim_smooth_pairs_kernel(const char *__
 // LDS-DMA, operands through ds_read): fragment-shaped global loads of the kernel above run at ~4 TB/s out of L2 / MALL,
 // whole-row LDS-DMA at ~11 (measured on the arg-max twin of this kernel, maxsim_pairs_argmax_kernel).
 template <int TPQ, bool F16>
-__global__ __launch_bounds__(256) void maxsim_smooth_pairs_stream_kernel(const uint16_t *__restrict__ Q,
+__global__ __launch_bounds__(256, 2) void maxsim_smooth_pairs_stream_kernel(const uint16_t *__restrict__ Q,
                                                                          const uint16_t *__restrict__ D,
                                                                          const int32_t *__restrict__ d_off,
                                                                          const int32_t *__restrict__ pairs,

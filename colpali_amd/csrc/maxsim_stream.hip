@@ -22,6 +22,8 @@
 //     tile in registers; one lane<->lane+32 exchange and a 5-step butterfly
 //     sum per document finish the score.
 #pragma once
+#include <type_traits>
+
 #include "maxsim_common.hpp"
 
 namespace msim {
@@ -46,8 +48,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // AUX : cache-policy bits of the LDS-DMA loads (0 = default, 2 = nt: streamed once, do not keep in L2 / MALL)
 // IL  : issue the 8 LDS-DMA pieces of the next slab BETWEEN the MFMAs of the current one instead of in a block in
 //       front of them (the matrix pipe idles while a block of DMA instructions issues; one piece per QT MFMAs hides)
-template <int QT, int TPQ, int RING, bool F16, int AUX = 0, bool IL = false>
-__global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
+// At most 4 token tiles: launch bounds ask for two waves per SIMD (<= 256 registers), which the 2-slab ring needs to put two
+// workgroups on a CU; without the bound hipcc gives every tile an accumulator of its own and lands at 290 registers.
+// TILEMAJOR: scheduling barriers between the token tiles keep the instruction stream tile by tile (8 MFMAs of one tile, the fold of
+// the previous one among them) instead of letting hipcc run all tiles' MFMAs k-step by k-step and fold everything at the end.
+template <int QT, int TPQ, int RING, bool F16, int AUX = 0, bool IL = false, bool TILEMAJOR = false>
+__global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
                                                             const uint16_t *__restrict__ D,       // [rows, 128] bf16
                                                             const int32_t *__restrict__ d_off,    // [n_d + 1]
                                                             const uint8_t *__restrict__ clamp0,   // [n_d] or null
@@ -166,12 +172,17 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
     int c_slot = 0;
     for (int c_idx = gw; c_idx < a.n_d; c_idx += GW) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
-        const int nslab = (len + kSlabRows - 1) / kSlabRows;
         float m[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) m[t] = -INFINITY;
 
-        for (int s = 0; s < nslab; ++s) {
+        // one slab: request the next one (IL: its 8 pieces go out between the MFMAs), fetch the 8 operand fragments once, then per
+        // token tile 8 MFMAs with the 16 -> 1 max fold of the PREVIOUS tile underneath them.  The fold is written one tile late on
+        // purpose: a VALU read of an accumulator needs 12 wait states after the MFMA that writes it (the compiler inserts them), and
+        // straight-line code lets it spend them on the next tile's MFMAs instead of on s_nop.  kTail (rows past the document end
+        // masked to -inf) is a compile-time variant so that the full-slab body has no branch in it.
+        auto slab = [&](auto tail_c, int s, int rows_left) {
+            constexpr bool kTail = decltype(tail_c)::value;
             // next slab to request (its slot is the one consumed in the previous iteration: free again)
             bool nx_live = false;
             char *nx_dst = ring;
@@ -198,7 +209,15 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
             for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
             c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
 
-            const int rows_left = len - s * kSlabRows;  // >= 1
+            auto masked = [&](f32x16 acc) {
+                if constexpr (kTail) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
+                }
+                return acc;
+            };
+            f32x16 prev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -213,15 +232,17 @@ __global__ __launch_bounds__(256) void maxsim_stream_kernel(const uint16_t *__re
                     }
                     acc = mfma32<F16>(af[ks], qf[t][ks], acc);
                 }
-                if (rows_left < kSlabRows) {  // tail slab: rows past the document end do not exist
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
-                }
-                m[t] = fold_max16(m[t], acc);
+                if (t > 0) m[t - 1] = fold_max16(m[t - 1], masked(prev));
+                prev = acc;
+                if constexpr (TILEMAJOR) __builtin_amdgcn_sched_barrier(0);
             }
+            m[QT - 1] = fold_max16(m[QT - 1], masked(prev));
             if constexpr (IL) advance(nx_live);                                  // the 8 pieces are out: advance the cursor
-        }
+            (void)s;
+        };
+        const int n_full = len / kSlabRows, rem = len - n_full * kSlabRows;
+        for (int s = 0; s < n_full; ++s) slab(std::false_type{}, s, kSlabRows);
+        if (rem > 0) slab(std::true_type{}, n_full, rem);
 
         // ---- document epilogue: combine the two lane halves, clamp, sum over tokens, store
         // clamp0 is a byte array; fetch the aligned dword around the byte with an explicit scalar load

@@ -282,11 +282,12 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
             got = G
         # tied scores: torch splits / picks differently, the sum over the tied entries is what is defined
         ref = scores.grad
-        assert torch.allclose(got.sum(dim=1), ref.sum(dim=1), rtol=1e-4, atol=1e-6)
+        scale = float(ref.abs().max())
         untied = torch.ones(B, dtype=torch.bool)
         if mode == 0:
             untied[1] = untied[4] = False
-        assert torch.allclose(got[untied], ref[untied], rtol=1e-4, atol=1e-7), (mode, T, norm, filt)
+            assert torch.allclose(got.sum(dim=1), ref.sum(dim=1), rtol=1e-4, atol=1e-6 * scale), (mode, T, norm, filt)
+        assert torch.allclose(got[untied], ref[untied], rtol=1e-4, atol=1e-6 * scale), (mode, T, norm, filt)
         want_lo = (raw / lengths.unsqueeze(1)).min() if norm else raw.min()
         assert abs(float(out[1]) - float(want_lo)) < 1e-5
     # argument checks
