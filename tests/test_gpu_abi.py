@@ -267,7 +267,7 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
                                       torch.cuda.current_stream().cuda_stream)
             assert rc == 0, L.msim_last_error()
         torch.cuda.synchronize()
-        assert abs(float(out[0]) - float(want)) <= 1e-5 * abs(float(want)) + 1e-6, (mode, T, norm, filt)
+        assert abs(float(out[0]) - float(want.detach())) <= 1e-5 * abs(float(want.detach())) + 1e-6, (mode, T, norm, filt)
         if mode == 0:
             got = torch.zeros((B, C), dtype=torch.float32, device=dev)
             got.index_put_((pairs[:, 0].long(), pairs[:, 1].long()), coef, accumulate=True)
@@ -287,7 +287,10 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
         if mode == 0:
             untied[1] = untied[4] = False
             assert torch.allclose(got.sum(dim=1), ref.sum(dim=1), rtol=1e-4, atol=1e-6 * scale), (mode, T, norm, filt)
-        assert torch.allclose(got[untied], ref[untied], rtol=1e-4, atol=1e-6 * scale), (mode, T, norm, filt)
+        # InfoNCE at T = 0.02: logits reach ~80, so `logit - lse` carries an absolute error of a few ulp(80) = 1e-5 in any fp32
+        # evaluation (torch's log_softmax as much as the kernel's): probabilities agree to that, not to 1e-7
+        atol = (3e-5 if mode == 1 else 1e-6) * scale
+        assert torch.allclose(got[untied], ref[untied], rtol=1e-4, atol=atol), (mode, T, norm, filt)
         want_lo = (raw / lengths.unsqueeze(1)).min() if norm else raw.min()
         assert abs(float(out[1]) - float(want_lo)) < 1e-5
     # argument checks
