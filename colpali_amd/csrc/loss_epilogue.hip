@@ -148,25 +148,28 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
         }
     } else {
         // cross entropy of row b with target pos_idx: lse(v / T) - pos / T
-        // the logit is ONE rounded product everywhere (__fmul_rn: no contraction into the subtractions below).  With an FMA the
-        // dominant entry would see fma(v, 1/T, -max) = the rounding error of its own product instead of exactly 0, and
-        // exp(that) - 1 ~ 4e-6 would leak into every gradient of the row.
+        // Softmax without cancellation: d_c = logit_c - max (<= 0, the logit ONE rounded product everywhere: __fmul_rn keeps the
+        // compiler from contracting it into the subtraction), p_c = exp(d_c) / sum.  The positive's gradient p_pos - 1 is formed as
+        // -(sum over the OTHER documents) / sum: when the positive dominates (p_pos = 1 - 1e-10) that is still exact to fp32
+        // relative precision, where exp(logit - lse) - 1 would return the rounding error of lse (~4e-6 at logits of 100).
         auto logit = [&](int c) { return __fmul_rn(value(c), a.inv_T); };
         float m = -INFINITY;
         for (int c = tid; c < a.C; c += kEpiThreads) m = fmaxf(m, logit(c));
         m = epi_block_reduce<float>(m, [](float x, float y) { return fmaxf(x, y); }, sh_f);
-        float se = 0.f;
-        for (int c = tid; c < a.C; c += kEpiThreads) se += expf(logit(c) - m);
-        se = epi_block_reduce<float>(se, [](float x, float y) { return x + y; }, sh_f);
-        const float lse = m + logf(se);
-        row_loss = lse - __fmul_rn(pos, a.inv_T);
+        float se_others = 0.f;
+        for (int c = tid; c < a.C; c += kEpiThreads)
+            if (c != pos_idx) se_others += expf(logit(c) - m);
+        se_others = epi_block_reduce<float>(se_others, [](float x, float y) { return x + y; }, sh_f);
+        const float d_pos = logit(pos_idx) - m;
+        const float se = se_others + expf(d_pos);
+        row_loss = logf(se) - d_pos;
         if (G != nullptr) {
             float *grow = G + (size_t)b * a.ld;
+            const float scale = a.inv_T * inv_B / se;
             for (int c = tid; c < a.C; c += kEpiThreads) {
                 const float s = norm(srow[c]);
                 const bool f = filtered(c, s);
-                const float v = f ? s * a.filter_factor : s;
-                float g = (expf(__fmul_rn(v, a.inv_T) - lse) - (c == pos_idx ? 1.0f : 0.0f)) * a.inv_T * inv_B;
+                float g = (c == pos_idx ? -se_others : expf(logit(c) - m)) * scale;
                 if (f) g *= a.filter_factor;
                 if (a.normalize) g /= len_f;
                 grow[c] = g;
