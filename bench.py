@@ -358,7 +358,7 @@ def topk_parity(amd, q, corpus, scores, top_s, top_i, k, n_queries=2, n_random=1
 
 def mfma_ceiling(amd, corpus):
     """The machine's own matrix-core ceiling under its power budget (msim_probe_mfma, include/maxsim.h): back-to-back
-    v_mfma_f32_32x32x16_bf16 on rows of the resident shard (the operand values the scorer multiplies), two waves per SIMD, no HBM
+    v_mfma_f32_16x16x32_bf16 on rows of the resident shard (the operand values the scorer multiplies), two waves per SIMD, no HBM
     traffic.  `kernel_mix` = with K1b's operand path (A fragments re-read from LDS) and its max folds; `registers_only` = nothing
     but MFMAs.  MI355X clocks to its power budget: on real operand values the chip does not reach the 2.5 PFLOP/s of
     1024 SIMDs x 1024 FLOP/clk x 2.4 GHz (on zeros it nearly does), so this is what an MFMA-bound kernel can be held against."""
@@ -371,7 +371,7 @@ def mfma_ceiling(amd, corpus):
     iters = 4000
     flop = 256 * 8 * iters * 32 * 32768
     out = {}
-    for name, variant in (("kernel_mix", 3), ("registers_only", 0)):
+    for name, variant in (("kernel_mix", 7), ("registers_only", 4), ("kernel_mix_32x32x16_tiles", 3)):
         ms = []
         for i in range(6):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,8 +384,9 @@ def mfma_ceiling(amd, corpus):
             if i >= 2:
                 ms.append(a.elapsed_time(b))
         out[name + "_tflops"] = flop / sorted(ms)[len(ms) // 2] / 1e9
-    out["what"] = ("msim_probe_mfma on rows of the resident shard: 32x32x16 bf16 MFMAs back to back, 2 waves per SIMD, no memory traffic; "
-                   "kernel_mix = A fragments from LDS + max folds (K1b's instruction mix), registers_only = MFMAs alone")
+    out["what"] = ("msim_probe_mfma on rows of the resident shard: v_mfma_f32_16x16x32_bf16 (the scorers' tile shape) back to back, 2 waves "
+                   "per SIMD, no memory traffic; kernel_mix = A fragments from LDS + max folds (K1s / K1b's instruction mix), "
+                   "registers_only = MFMAs alone; kernel_mix_32x32x16_tiles = the same mix on the 32x32x16 tile the kernels used before")
     return out
 
 

@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime (libamdhip64.so) we bind to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
+# COLPALI_AMD_LIB: load another build of the same ABI instead (A/B measurements of two builds inside one process run; tools/ only)
+LIB_PATH = os.environ.get("COLPALI_AMD_LIB") or os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
 MSIM_FLAG_REF_ROUNDING = 0x1
 ABI_VERSION = 11

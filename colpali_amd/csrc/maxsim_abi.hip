@@ -1104,7 +1104,7 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
     if (!X || !sink) return fail(MSIM_EINVAL, "null pointer argument");
     if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
     if (rows < 256LL * 8 * 5 * 32) return fail(MSIM_EINVAL, "the MFMA probe needs at least %d rows of operands", 256 * 8 * 5 * 32);
-    if (iters <= 0 || variant < 0 || variant > 3) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
+    if (iters <= 0 || variant < 0 || variant > 7) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X);
     int rc;
@@ -1112,6 +1112,10 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
         case 0: rc = run_probe_mfma<false, false>(x, iters, sink, st); break;
         case 1: rc = run_probe_mfma<true, false>(x, iters, sink, st); break;
         case 2: rc = run_probe_mfma<false, true>(x, iters, sink, st); break;
+        case 4: rc = run_probe_mfma16<false, false>(x, iters, sink, st); break;   // 16x16x32 tiles, registers only
+        case 5: rc = run_probe_mfma16<true, false>(x, iters, sink, st); break;    // + A fragments from LDS
+        case 6: rc = run_probe_mfma16<false, true>(x, iters, sink, st); break;    // + max folds
+        case 7: rc = run_probe_mfma16<true, true>(x, iters, sink, st); break;     // K1s / K1b's instruction mix
         default: rc = run_probe_mfma<true, true>(x, iters, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_mfma_kernel launch failed (variant %d)", variant);

@@ -116,33 +116,28 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     const int qb0 = qblock * q_base + (qblock < q_extra ? qblock : q_extra);   // first query of this block
     const int qb_n = q_base + (qblock < q_extra ? 1 : 0);                       // queries in this block (<= 8 * QPW)
     const int my_q = wave < qb_n ? (qb_n - 1 - wave) / kB1Waves + 1 : 0;     // queries of this wave (wave-uniform)
-    bf16x8 qf[NTMAX][kKSteps];
+    QueryTile qt[NTMAX];
 #pragma unroll
     for (int t = 0; t < NTMAX; ++t) {
+        const bool live = t / TPQ < my_q;
         const int q = qb0 + wave + kB1Waves * (t / TPQ);
-        const int row = (t % TPQ) * kTokTile + (lane & 31);
-        const bool valid = t / TPQ < my_q && row < a.Lq;
-        const uint16_t *p = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
-#pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) {
-            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 16);
-            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        load_query_tile(qt[t], Q + (size_t)(live ? q : 0) * a.Lq * kDim, (t % TPQ) * kTokTile, a.Lq, lane, live);
     }
     wait_vmcnt<0>();
 #pragma unroll
     for (int t = 0; t < NTMAX; ++t)
 #pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qt[t].f[h][ks]));
 
     // ---- per-lane address constants (same slab image as K1s)
     const int l16 = lane & 15, l4 = lane >> 4;
     int src_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
-    int rd_off[kKSteps];
-#pragma unroll
-    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
     // this wave fills rows 16*(wave&1) .. +15 of slab (wave>>1) of every chunk: 4 wave-instructions of 4 rows
     const int my_lds_off = (wave >> 1) * kSlabBytes + (wave & 1) * 4096;
     const int my_row_off = (wave >> 1) * kSlabRows + (wave & 1) * 16;
@@ -195,25 +190,30 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nchunk = (len + kChunkRows - 1) / kChunkRows;
-        float m[NTA];
+        float m[NTA][2];
 #pragma unroll
-        for (int t = 0; t < NTA; ++t) m[t] = -INFINITY;
+        for (int t = 0; t < NTA; ++t) m[t][0] = m[t][1] = -INFINITY;
         auto slab = [&](int src_lds, auto tail, int rows_left) {   // src_lds: LDS byte address of the slab (wave-uniform)
             constexpr bool kTail = decltype(tail)::value;
-            bf16x8 af[kKSteps];
+            bf16x8 af[2][kKSteps16];
 #pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[ks]);
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int ks = 0; ks < kKSteps16; ++ks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[g][ks]);
 #pragma unroll
             for (int t = 0; t < NTA; ++t) {
-                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                TileAcc acc;
 #pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(af[ks], qf[t][ks], acc);
-                if constexpr (kTail) {      // rows past the document end do not exist
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
-                }
-                m[t] = fold_max16(m[t], acc);
+                    for (int g = 0; g < 2; ++g) acc.a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps16; ++ks)
+#pragma unroll
+                    for (int hg = 0; hg < 4; ++hg)              // four independent accumulator chains per tile, round-robin
+                        acc.a[hg >> 1][hg & 1] = mfma16<F16>(af[hg & 1][ks], qt[t].f[hg >> 1][ks], acc.a[hg >> 1][hg & 1]);
+                if constexpr (kTail) tile_mask_tail(acc, rows_left, lane);   // rows past the document end do not exist
+                tile_fold(m[t], acc);
             }
         };
 
@@ -256,12 +256,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             }
             float tile_sum[NTA];
 #pragma unroll
-            for (int t = 0; t < NTA; ++t) {
-                float v = fmaxf(m[t], __shfl_xor(m[t], 32));
-                if (clamp) v = fmaxf(v, 0.0f);
-                if (ref_bf16) v = round_to_input<F16>(v);
-                tile_sum[t] = half_wave_sum(v);
-            }
+            for (int t = 0; t < NTA; ++t) tile_sum[t] = tile_finish<F16>(m[t], clamp, ref_bf16);
             if (lane == 0) {
 #pragma unroll
                 for (int qq = 0; qq < NTA / TPQ; ++qq) {

@@ -98,4 +98,100 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // Byte offset inside the slab of logical chunk `c` of row `r`:
 __device__ __forceinline__ int slab_swizzled_off(int r, int c) { return r * kRowBytes + ((c ^ (r & 15)) << 4); }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 16x16x32 tiling of the scorers K1s / K1b.  A 32-token query tile x a 32-row document slab x 128 is computed as
+// 2 (token halves) x 2 (row groups) x 4 (k-steps) v_mfma_f32_16x16x32 instead of 8 v_mfma_f32_32x32x16: the same FLOP, the same
+// operand bytes from LDS and from the query registers, the same number of max folds -- but half the accumulator registers read and
+// written per FLOP.  MI355X clocks to its power budget, and on real operand values the matrix pipe sustains 2.07 PFLOP/s with this
+// shape against 1.81 with 32x32x16 (msim_probe_mfma, registers only; 1.99 vs 1.71 with the max folds; both reach 2.45 on zeros):
+// in the power-bound regimes (everything from 4 queries up) the tile shape is worth more than any scheduling detail.
+//   A (M = 16 document rows): lane l supplies row l & 15, k-slice 8 * (l >> 4) .. +7 of the 32-wide k-step   (16 bytes)
+//   B (N = 16 query tokens) : lane l supplies token l & 15, the same k-slice                                  (16 bytes)
+//   D: lane l holds token l & 15 and document rows 4 * (l >> 4) + {0, 1, 2, 3}                                 (4 registers)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8 &a, const bf16x8 &b, const f32x4 &c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr int kKSteps16 = kDim / 32;      // 4 k-steps of 32
+
+struct QueryTile {                         // B operands of one 32-token tile: [token half][k-step], 32 VGPRs
+    bf16x8 f[2][kKSteps16];
+};
+struct TileAcc {                           // D of one (tile, slab): [token half][row group], 16 VGPRs
+    f32x4 a[2][2];
+};
+
+// byte offsets of this lane's A fragments inside the swizzled slab image: fragment (g, ks) = rows 16g .. 16g+15, k = 32ks .. 32ks+31.
+// Conflict-free for ds_read_b128: within each 16-lane access group the physical 16-byte chunk (4ks + (l >> 4)) ^ (row & 15) is distinct.
+__device__ __forceinline__ void slab_rd_offsets16(int lane, int (&rd)[2][kKSteps16]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) rd[g][ks] = slab_swizzled_off(16 * g + (lane & 15), 4 * ks + (lane >> 4));
+}
+
+// B fragments of tokens tok0 .. tok0+31 of one query (Qq -> its [Lq][128] rows); tokens >= Lq (and a dead tile) are zero rows
+__device__ __forceinline__ void load_query_tile(QueryTile &q, const uint16_t *__restrict__ Qq, int tok0, int Lq, int lane, bool live) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = tok0 + 16 * h + (lane & 15);
+        const bool valid = live && row < Lq;
+        const uint16_t *p = Qq + (size_t)(valid ? row : 0) * kDim + (lane >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+            q.f[h][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+}
+
+// rows of the slab at or beyond rows_left do not exist: -inf (after the MFMA; zero padding is a different thing, see clamp0)
+__device__ __forceinline__ void tile_mask_tail(TileAcc &acc, int rows_left, int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * g + 4 * (lane >> 4) + r >= rows_left) acc.a[h][g][r] = -INFINITY;
+}
+
+// running per-token max over document rows: m[h] covers token 16h + (lane & 15), this lane's rows only (8 v_max3 per tile and slab)
+__device__ __forceinline__ void tile_fold(float (&m)[2], const TileAcc &acc) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            m[h] = max3(m[h], acc.a[h][g][0], acc.a[h][g][1]);
+            m[h] = max3(m[h], acc.a[h][g][2], acc.a[h][g][3]);
+        }
+}
+
+// end of a document: combine the four lane groups (rows), clamp / round as asked, sum over the tile's 32 tokens.
+// Add order = the 5-step butterfly over tokens (t ^ 16 first): token t + token t+16, then xor 8, 4, 2, 1 inside 16 lanes.
+template <bool F16>
+__device__ __forceinline__ float tile_finish(const float (&m)[2], bool clamp, bool ref_round) {
+    float v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float x = fmaxf(m[h], __shfl_xor(m[h], 16));
+        x = fmaxf(x, __shfl_xor(x, 32));
+        if (clamp) x = fmaxf(x, 0.0f);
+        if (ref_round) x = round_to_input<F16>(x);
+        v[h] = x;
+    }
+    float s = v[0] + v[1];
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    return s;
+}
+
 }  // namespace msim

@@ -17,10 +17,11 @@
 //   * the slab image is XOR-swizzled on the SOURCE address so the ds_read_b128
 //     operand fetches are bank-conflict free (cdna_hip_programming.md T2 /
 //     rule 21: linear destination, swizzled source, same swizzle on the read);
-//   * swapped product mfma_f32_32x32x16_bf16(D_slab, Q^T): C layout puts one
-//     query token per lane column, so the max over patches is 8 v_max3 per
-//     tile in registers; one lane<->lane+32 exchange and a 5-step butterfly
-//     sum per document finish the score.
+//   * swapped product mfma_f32_16x16x32_bf16(D_slab rows, Q^T) (maxsim_common.hpp: the
+//     16x16x32 tiling -- half the accumulator traffic of 32x32x16, which is what counts
+//     on a chip that clocks to its power budget): the C layout puts one query token per
+//     lane column, so the max over patches is 8 v_max3 per 32-token tile and slab in
+//     registers; two lane-group exchanges and a butterfly sum per document finish the score.
 #pragma once
 #include <type_traits>
 
@@ -66,20 +67,10 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
     const int gw = blockIdx.x * 4 + wave;  // global wave id: this wave owns documents gw, gw+GW, ...
     const int GW = gridDim.x * 4;
 
-    // ---- query fragments: B operand, lane supplies token (lane&31), k-slice (lane>>5) of each k-step
-    bf16x8 qf[QT][kKSteps];
+    // ---- query fragments: B operands, resident for the whole kernel (32 VGPRs per 32-token tile)
+    QueryTile qt[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int q = t / TPQ;
-        const int row = (t % TPQ) * kTokTile + (lane & 31);
-        const bool valid = row < a.Lq;
-        const uint16_t *p = Q + ((size_t)q * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
-#pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) {
-            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 16);
-            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
+    for (int t = 0; t < QT; ++t) load_query_tile(qt[t], Q + (size_t)(t / TPQ) * a.Lq * kDim, (t % TPQ) * kTokTile, a.Lq, lane, true);
 
     // the query loads are ordinary VMEM loads: retire them before the LDS-DMA stream starts so that the
     // compiler's own vmcnt waits for them never drain the ring later on
@@ -87,7 +78,9 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qt[t].f[h][ks]));
 
     // ---- per-lane address constants
     // LDS-DMA source: wave-instruction i of a slab fills LDS rows 4i..4i+3 linearly; lane (l4 = lane>>4,
@@ -97,10 +90,9 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
     int src_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
-    // operand fetch: lane reads row (lane&31), logical chunk 2*ks + (lane>>5)
-    int rd_off[kKSteps];
-#pragma unroll
-    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+    // operand fetch: fragment (g, ks) = rows 16g + (lane & 15), logical chunk 4 * ks + (lane >> 4)
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
 
     // ---- producer cursor (wave-uniform): next slab to request
     int p_idx = gw, p_row = 0, p_len = 0;
@@ -172,9 +164,9 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
     int c_slot = 0;
     for (int c_idx = gw; c_idx < a.n_d; c_idx += GW) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
-        float m[QT];
+        float m[QT][2];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) m[t] = -INFINITY;
+        for (int t = 0; t < QT; ++t) m[t][0] = m[t][1] = -INFINITY;
 
         // one slab: request the next one (IL: its 8 pieces go out between the MFMAs), fetch the 8 operand fragments once, then per
         // token tile 8 MFMAs with the 16 -> 1 max fold of the PREVIOUS tile underneath them.  The fold is written one tile late on
@@ -204,39 +196,42 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
             }
 
             const char *src = ring + c_slot * kSlabBytes;
-            bf16x8 af[kKSteps];
+            bf16x8 af[2][kKSteps16];
 #pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int ks = 0; ks < kKSteps16; ++ks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[g][ks]);
             c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
 
-            auto masked = [&](f32x16 acc) {
-                if constexpr (kTail) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (acc_row(r, lane) >= rows_left) acc[r] = -INFINITY;
-                }
-                return acc;
-            };
-            f32x16 prev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            TileAcc prev;
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                TileAcc acc;
 #pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks) {
-                    if constexpr (IL) {
-                        if ((t * kKSteps + ks) % QT == 0) {                      // one DMA piece per QT MFMAs: 8 per slab
-                            const int i = (t * kKSteps + ks) / QT;
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(nx_rsrc, MSIM_LDS(nx_dst + i * 1024), 16, src_off[i & 3],
-                                                                     nx_soff + i * 1024, 0, AUX);
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc.a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps16; ++ks)
+#pragma unroll
+                    for (int hg = 0; hg < 4; ++hg) {           // four independent accumulator chains per tile, round-robin
+                        if constexpr (IL) {
+                            constexpr int kPer = 2 * QT;        // one DMA piece per 2 * QT MFMAs: 8 per slab
+                            const int mf = (t * kKSteps16 + ks) * 4 + hg;
+                            if (mf % kPer == 0) {
+                                const int i = mf / kPer;
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(nx_rsrc, MSIM_LDS(nx_dst + i * 1024), 16, src_off[i & 3],
+                                                                         nx_soff + i * 1024, 0, AUX);
+                            }
                         }
+                        acc.a[hg >> 1][hg & 1] = mfma16<F16>(af[hg & 1][ks], qt[t].f[hg >> 1][ks], acc.a[hg >> 1][hg & 1]);
                     }
-                    acc = mfma32<F16>(af[ks], qf[t][ks], acc);
-                }
-                if (t > 0) m[t - 1] = fold_max16(m[t - 1], masked(prev));
+                if constexpr (kTail) tile_mask_tail(acc, rows_left, lane);
+                if (t > 0) tile_fold(m[t - 1], prev);
                 prev = acc;
                 if constexpr (TILEMAJOR) __builtin_amdgcn_sched_barrier(0);
             }
-            m[QT - 1] = fold_max16(m[QT - 1], masked(prev));
+            tile_fold(m[QT - 1], prev);
             if constexpr (IL) advance(nx_live);                                  // the 8 pieces are out: advance the cursor
             (void)s;
         };
@@ -254,12 +249,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
         }
         float tile_sum[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float v = fmaxf(m[t], __shfl_xor(m[t], 32));
-            if (clamp) v = fmaxf(v, 0.0f);
-            if (ref_bf16) v = round_to_input<F16>(v);
-            tile_sum[t] = half_wave_sum(v);
-        }
+        for (int t = 0; t < QT; ++t) tile_sum[t] = tile_finish<F16>(m[t], clamp, ref_bf16);
         if (lane == 0) {
 #pragma unroll
             for (int q = 0; q < QT / TPQ; ++q) {

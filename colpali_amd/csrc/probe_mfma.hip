@@ -77,7 +77,89 @@ __global__ __launch_bounds__(512, 2) void probe_mfma_kernel(const uint16_t *__re
     }
     if (s == 123.456f) sink[0] = s;
 }
+// The same experiment on v_mfma_f32_16x16x32_bf16 (half the accumulator registers per FLOP): 2 x NT x 8 MFMAs of 16384 FLOP per
+// iteration = the FLOP of the kernel above.  This is the tile shape K1s / K1b use (maxsim_common.hpp); with LDSA + FOLD it is their
+// instruction mix: one ds_read_b128 per 8 MFMAs, 8 v_max3 per 16.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int NT, bool LDSA, bool FOLD>
+__global__ __launch_bounds__(512, 2) void probe_mfma16_kernel(const uint16_t *__restrict__ X, int iters, float *__restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t base = ((size_t)blockIdx.x * 8 + wave) * (NT + 1) * kTokTile;
+    bf16x8 qf[NT][kKSteps];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks)
+            qf[t][ks] = *reinterpret_cast<const bf16x8 *>(X + (base + t * kTokTile + (lane & 31)) * kDim + (lane >> 5) * 8 + ks * 16);
+    bf16x8 areg[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks)
+        areg[ks] = *reinterpret_cast<const bf16x8 *>(X + (base + NT * kTokTile + (lane & 31)) * kDim + (lane >> 5) * 8 + ks * 16);
+    char *slab = smem + wave * kSlabBytes;
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) {
+        rd_off[ks] = slab_swizzled_off(16 * (ks >> 2) + (lane & 15), 4 * (ks & 3) + (lane >> 4));   // K1s/K1b's fragment (g, ks)
+        if constexpr (LDSA) *reinterpret_cast<bf16x8 *>(slab + rd_off[ks]) = areg[ks];
+    }
+    __syncthreads();
+    f32x4 acc[NT][2];
+    float m[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        m[t] = -INFINITY;
+        acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            bf16x8 af;
+            if constexpr (LDSA) {
+                int o = rd_off[ks];
+                asm volatile("" : "+v"(o));
+                af = *reinterpret_cast<const bf16x8 *>(slab + o);
+            } else {
+                asm volatile("" : "+v"(areg[ks]));
+                af = areg[ks];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, qf[t][ks], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, qf[t][(ks + 1) & 7], acc[t][1], 0, 0, 0);
+            }
+        }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    m[t] = max3(m[t], acc[t][h][0], acc[t][h][1]);
+                    m[t] = max3(m[t], acc[t][h][2], acc[t][h][3]);
+                    acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s += m[t] == -INFINITY ? 0.f : m[t];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[t][h][r];
+    }
+    if (s == 123.456f) sink[0] = s;
+}
 }  // namespace msim
+template <bool LDSA, bool FOLD>
+int run_probe_mfma16(const uint16_t *x, int iters, float *sink, hipStream_t st) {
+    auto kern = msim::probe_mfma16_kernel<4, LDSA, FOLD>;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), 8 * msim::kSlabBytes, st, x, iters, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 template <bool LDSA, bool FOLD>
 int run_probe_mfma(const uint16_t *x, int iters, float *sink, hipStream_t st) {
     auto kern = msim::probe_mfma_kernel<4, LDSA, FOLD>;

@@ -257,6 +257,8 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
  * launch: FLOP = 256 workgroups x 8 waves x iters x 32 x 32768.
  *   variant bit 0: A operand re-read from LDS per k-step (msim_fwd's operand path) instead of held in registers
  *   variant bit 1: the 16 -> 1 max fold of every accumulator tile runs next to the MFMAs
+ *   variants 4..7: the same four mixes on v_mfma_f32_16x16x32_bf16, the tile shape msim_fwd's kernels use (variant - 4 = the bits
+ *   above): 7 = their instruction mix (A fragments from LDS + max folds), 4 = MFMAs alone
  */
 int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *sink, void *stream);
 

@@ -263,16 +263,17 @@ def test_generic_many_documents_and_literal_rounding(amd):
     assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
 
 
-def test_generic_and_tuned_kernels_agree_bitwise(amd):
-    # same 32x32x16 MFMA chain in the same k order, same reduction tree: a 128-wide bf16 query scored by the tuned
-    # kernels (Lq <= 128) and, zero-padded to 160 tokens, by the generic kernel must give identical fp32 values
+def test_generic_and_tuned_kernels_agree(amd):
+    # a 128-wide bf16 query scored by the tuned kernels (Lq <= 128: 16x16x32 MFMA tiles, 32 k per step) and, zero-padded to 160
+    # tokens, by the generic kernel (32x32x16 tiles, 16 k per step): the same exact products summed in a different order inside
+    # the matrix unit -- equal to fp32 summation-order noise, not bit for bit
     qs, ps = _random_case(21, 3, 32, 200, 500)
     dev = torch.device("cuda:0")
     corpus = amd.pack_passages(ps, dev)
     tuned = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()
     long_q = [torch.cat([q, q.new_zeros(160 - q.shape[0], 128)]) for q in qs]
     generic = amd.maxsim_scores(amd.pack_queries(long_q, dev), corpus).cpu()
-    assert torch.equal(tuned, generic)
+    assert float(((tuned - generic).abs() / generic.abs().clamp_min(1.0)).max()) < 2e-6
 
 
 def test_transpose_detecting_asymmetric_inputs_fp32(amd):

@@ -15,7 +15,9 @@ Z = torch.zeros_like(X)
 sink = torch.zeros(4, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream()
 for data, name in ((X, "random unit rows"), (Z, "zeros")):
-    for variant, what in ((0, "A in registers"), (1, "A from LDS"), (2, "A in registers + max folds"), (3, "A from LDS + max folds")):
+    for variant, what in ((0, "A in registers"), (1, "A from LDS"), (2, "A in registers + max folds"), (3, "A from LDS + max folds"),
+                          (4, "16x16x32 tiles, registers"), (5, "16x16x32, A from LDS"), (6, "16x16x32, registers + folds"),
+                          (7, "16x16x32, A from LDS + folds")):
         for iters in (2000, 20000):
             ms = []
             for i in range(5):
