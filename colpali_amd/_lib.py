@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLPALI_AMD_LIB") or os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def dtype_code(dtype) -> int:
@@ -94,6 +94,8 @@ def lib() -> ctypes.CDLL:
     L.msim_loss_epilogue_workspace_bytes.restype = sz
     L.msim_loss_epilogue.argtypes = [i32, vp, i64, i32, i32, vp, i32, i32, i32, i32, f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]
     L.msim_loss_epilogue.restype = i32
+    L.msim_host_gather.argtypes = [vp, vp, vp, vp, i64, i32]
+    L.msim_host_gather.restype = i32
     L.msim_probe_mfma.argtypes = [i32, vp, i64, i32, vp, vp]
     L.msim_probe_mfma.restype = i32
     L.msim_topk_workspace_bytes.argtypes = [i32, i64, i32]

@@ -20,6 +20,7 @@ from typing import List, Optional, Sequence, Union
 
 import torch
 
+from . import _lib as _lib_mod
 from ._lib import kernel_width
 
 EMBED_DIM = 128   # the width the tuned kernels are built for (ColPali / ColQwen2 projection dim)
@@ -81,18 +82,6 @@ def _widen(x: torch.Tensor) -> torch.Tensor:
 
 
 _COPY_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))
-_pool = None
-
-
-def _copy_pool():
-    global _pool
-    if _pool is None:
-        from concurrent.futures import ThreadPoolExecutor
-
-        _pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="msim-stage")
-    return _pool
-
-
 # pinned host memory per staging buffer = two halves that alternate: while one half is on its way to the GPU the passages of the
 # next chunk are memcpy'd into the other, so a call costs max(host memcpy, PCIe upload) instead of their sum -- 32 MiB per half
 # is large enough for both to run at full speed and small enough for a 264 MB corpus (1000 ColPali pages) to overlap almost fully
@@ -136,23 +125,34 @@ class _Staging:
         with self.lock:
             half = self._halves(nbytes)
             base = self.buf.data_ptr()
-            # (destination offset in the image, source pointer, bytes, keep-alive) per passage, split at chunk borders so that
-            # every chunk fits one half of the staging buffer
-            pieces = []
+            # (destination offset in the image, source pointer, bytes) per passage, split at chunk borders so that every chunk
+            # fits one half of the staging buffer; the copies themselves run in msim_host_gather (native threads, one call per
+            # chunk: a thousand small memmoves from python threads fight over the interpreter lock)
+            import numpy as np
+
+            L = _lib_mod.lib()
+            keep, offs, srcs, sizes = [], [], [], []
             o = 0
             for p in ps:
                 n = int(p.shape[0]) * dim * es
                 if n:
                     src = p if p.is_contiguous() else p.contiguous()
+                    keep.append(src)
                     sp, done = src.data_ptr(), 0
                     while done < n:
                         room = half - ((o + done) % half)
                         take = min(room, n - done)
-                        pieces.append((o + done, sp + done, take, src))
+                        offs.append(o + done)
+                        srcs.append(sp + done)
+                        sizes.append(take)
                         done += take
                 o += n if slot_rows is None else slot_rows * dim * es
+            offs_a = np.asarray(offs, dtype=np.int64)
+            srcs_a = np.asarray(srcs, dtype=np.uint64)
+            sizes_a = np.asarray(sizes, dtype=np.int64)
             stream = torch.cuda.current_stream(device)
             k = 0
+            n_pieces = len(offs)
             for c0 in range(0, nbytes, half):
                 c1 = min(nbytes, c0 + half)
                 h = (c0 // half) & 1
@@ -161,28 +161,20 @@ class _Staging:
                     self.events[h].synchronize()          # the previous upload has left this half
                 if slot_rows is not None:
                     ctypes.memset(hb, 0, c1 - c0)
-                jobs = []
-                while k < len(pieces) and pieces[k][0] < c1:
-                    dst_off, sp, n, keep = pieces[k]
-                    jobs.append((hb + (dst_off - c0), sp, n, keep))
-                    k += 1
-                # plain memcpy per passage (no tensor-op dispatch); ctypes releases the GIL inside memmove, so a few threads
-                # copy disjoint runs of passages in parallel -- one thread moves ~6 GB/s, the upload that follows 50+
-                n_thr = min(_COPY_THREADS, max(1, (c1 - c0) >> 22))       # below ~4 MiB per thread it is not worth a hand-off
-                if n_thr <= 1 or len(jobs) < 2 * n_thr:
-                    for dst, sp, n, _ in jobs:
-                        ctypes.memmove(dst, sp, n)
-                else:
-                    def run(chunk):
-                        for dst, sp, n, _ in chunk:
-                            ctypes.memmove(dst, sp, n)
-                    per = (len(jobs) + n_thr - 1) // n_thr
-                    futures = [_copy_pool().submit(run, jobs[j : j + per]) for j in range(0, len(jobs), per)]
-                    for f in futures:
-                        f.result()
+                k1 = k
+                while k1 < n_pieces and offs[k1] < c1:
+                    k1 += 1
+                if k1 > k:
+                    rel = offs_a[k:k1] - c0                # offsets inside this half
+                    rc = L.msim_host_gather(hb, srcs_a[k:k1].ctypes.data, rel.ctypes.data, sizes_a[k:k1].ctypes.data,
+                                            k1 - k, _COPY_THREADS)
+                    if rc != 0:
+                        raise RuntimeError(f"msim_host_gather failed: {L.msim_last_error().decode()}")
+                k = k1
                 dev_bytes[c0:c1].copy_(self.buf[h * half : h * half + (c1 - c0)], non_blocking=True)
                 self.events[h] = torch.cuda.Event()
                 self.events[h].record(stream)
+            del keep
         return dev
 
 

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
@@ -1070,6 +1072,42 @@ int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages
     }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(MSIM_ELAUNCH, "pool_reduce_kernel launch: %s", hipGetErrorString(err));
+    return MSIM_OK;
+}
+
+int msim_host_gather(void *dst, const void *const *src, const int64_t *dst_off, const int64_t *nbytes, int64_t n, int n_threads) {
+    if (n < 0) return fail(MSIM_EINVAL, "negative count");
+    if (n == 0) return MSIM_OK;
+    if (!dst || !src || !dst_off || !nbytes) return fail(MSIM_EINVAL, "null pointer argument");
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (nbytes[i] < 0 || dst_off[i] < 0 || (nbytes[i] > 0 && !src[i])) return fail(MSIM_EINVAL, "bad buffer %lld", (long long)i);
+        total += nbytes[i];
+    }
+    char *d = static_cast<char *>(dst);
+    auto run = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i)
+            if (nbytes[i]) memcpy(d + dst_off[i], src[i], (size_t)nbytes[i]);
+    };
+    int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    if (total < (int64_t)(4 << 20) * nt) nt = (int)(total >> 22) < 1 ? 1 : (int)(total >> 22);   // below ~4 MiB per thread: fewer
+    if (nt <= 1 || n < 2) {
+        run(0, n);
+        return MSIM_OK;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nt);
+    const int64_t per = (total + nt - 1) / nt;
+    int64_t lo = 0, acc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        acc += nbytes[i];
+        if (acc >= per || i + 1 == n) {
+            pool.emplace_back(run, lo, i + 1);
+            lo = i + 1;
+            acc = 0;
+        }
+    }
+    for (auto &t : pool) t.join();
     return MSIM_OK;
 }
 

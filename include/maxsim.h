@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 11
+#define MSIM_ABI_VERSION 12
 
 /* error codes */
 #define MSIM_OK 0
@@ -231,6 +231,16 @@ int msim_pool_cluster(int dtype, const void *E, const int32_t *d_off, int n_page
                       int32_t *labels, int32_t *n_clusters, void *stream);
 int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages, int dim, int ld_in,
                      const int32_t *labels, const int32_t *out_off, void *out, int ld_out, void *stream);
+
+/*
+ * Host-side helper of the drop-in's upload path (no device work): copies n separate host buffers into one destination image,
+ *     memcpy(dst + dst_off[i], src[i], nbytes[i])   for i < n,
+ * with up to n_threads threads (contiguous runs of buffers of about equal bytes per thread).  The reference hands the scorer a
+ * python list of per-page tensors (README.md:121-126) and re-pads it per block with pad_sequence (processing_utils.py:172-178);
+ * here the pages are gathered once into a pinned staging buffer and uploaded.  Native because a thousand small memcpy calls
+ * issued from python threads fight over the interpreter lock (70 ms stalls in a 10 ms call were measured).
+ */
+int msim_host_gather(void *dst, const void *const *src, const int64_t *dst_off, const int64_t *nbytes, int64_t n, int n_threads);
 
 /*
  * Measurement aid (no reference counterpart): the streaming ceiling of this machine for the access patterns
