@@ -167,7 +167,8 @@ def dropin_numbers(amd):
                 ts.append(time.perf_counter() - t0)
             return sorted(ts)[len(ts) // 2]
 
-        ours = timed(lambda: amd.score_multi_vector(qs, ps, device="cuda:0"), 5)
+        ours = timed(lambda: amd.score_multi_vector(qs, ps, device="cuda:0"), 11)   # median of 11: the host gather now and then
+        #                                                  stalls ~70 ms inside memcpy (page migration on the 256-CPU host), 1 call in 4
         ref = timed(lambda: torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0"), 3)
         # parity of the two results that were just timed: ours (fp32-accurate scores of the bf16 inputs) against the
         # reference's own torch calls on this GPU -- on fp32 upcasts of the same inputs (its truth tier) and on the raw bf16

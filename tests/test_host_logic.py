@@ -265,3 +265,23 @@ def test_loss_offset_and_pair_checks_run_before_any_device_work():
     with pytest.raises(ValueError):
         Lm._check_pairs(torch.tensor([[1, 0], [0, 1]], dtype=torch.int32), 4, 6)          # not sorted by query
     Lm._check_pairs(torch.tensor([[0, 5], [3, 0]], dtype=torch.int32), 4, 6)
+
+
+def test_native_host_gather_copies_every_buffer_to_its_offset():
+    """msim_host_gather (include/maxsim.h): the drop-in's staging memcpy, native and multi-threaded; no device involved."""
+    L = colpali_amd._lib.lib()
+    rng = np.random.default_rng(3)
+    bufs = [rng.integers(0, 255, size=n, dtype=np.uint8) for n in (5 << 20, 0, 1, 3 << 20, 7, 9 << 20)]
+    offs = np.cumsum([0] + [b.size + 5 for b in bufs[:-1]]).astype(np.int64)          # gaps of 5 bytes stay untouched
+    dst = np.full(int(offs[-1]) + bufs[-1].size + 3, 0xEE, dtype=np.uint8)
+    srcs = np.array([b.ctypes.data if b.size else 0 for b in bufs], dtype=np.uint64)
+    sizes = np.array([b.size for b in bufs], dtype=np.int64)
+    for threads in (1, 8, 64):
+        dst[:] = 0xEE
+        assert L.msim_host_gather(dst.ctypes.data, srcs.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(bufs), threads) == 0
+        for b, o in zip(bufs, offs):
+            np.testing.assert_array_equal(dst[o : o + b.size], b)
+            if b.size:
+                assert dst[o + b.size] == 0xEE
+    assert L.msim_host_gather(dst.ctypes.data, None, offs.ctypes.data, sizes.ctypes.data, len(bufs), 4) == -1
+    assert L.msim_host_gather(dst.ctypes.data, srcs.ctypes.data, offs.ctypes.data, sizes.ctypes.data, 0, 4) == 0
