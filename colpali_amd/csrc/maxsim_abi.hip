@@ -185,9 +185,9 @@ int launch_stream(const FwdCall &c) {
     return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
 }
 
-template <int TPQ, bool F16, int NW, int RING = 3>
+template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0>
 int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING>;
+    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING, AUX>;
     constexpr int lds = RING * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves) / 32 KiB (pair, ring of 4)
     constexpr int wg_per_cu = 8 / NW;
     static std::atomic<int> configured[kMaxDevices];
@@ -240,9 +240,14 @@ int batch_dispatch(const FwdCall &c) {
     int nw = tiles <= 8 ? 2 : (tiles <= 20 ? 4 : 8);
     const int forced = batch_nw_override();
     if (forced && (forced != 2 || tiles <= 8)) nw = forced;
-    if (nw == 2) return launch_batch<TPQ, F16, 2, 4>(c);
-    if (nw == 4) return launch_batch<TPQ, F16, 4, 3>(c);
-    return launch_batch<TPQ, F16, 8, 3>(c);
+    // one query block = every corpus byte is read once by one workgroup: stream it past L2 / MALL (nt), like K1s does.
+    // MSIM_BATCH_NT=0 switches that off for A/B measurements (tuning knob, not part of the ABI).
+    static const bool nt_off = getenv("MSIM_BATCH_NT") && atoi(getenv("MSIM_BATCH_NT")) == 0;
+    const int q_per_block = nw * (4 / TPQ);
+    const bool single_block = c.n_q <= q_per_block && !nt_off;
+    if (nw == 2) return single_block ? launch_batch<TPQ, F16, 2, 4, 2>(c) : launch_batch<TPQ, F16, 2, 4, 0>(c);
+    if (nw == 4) return single_block ? launch_batch<TPQ, F16, 4, 3, 2>(c) : launch_batch<TPQ, F16, 4, 3, 0>(c);
+    return single_block ? launch_batch<TPQ, F16, 8, 3, 2>(c) : launch_batch<TPQ, F16, 8, 3, 0>(c);
 }
 
 template <bool F16>

@@ -73,7 +73,9 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 //      4 = two workgroups per CU with 64-row chunks and half the queries each: while one sits at its chunk barrier the other
 //      computes (+5 % at 9..16 queries, -2..-4 % from 64 queries up, where the doubled number of query blocks costs more).
 // RING: chunks in the shared LDS ring (4 for the pair form: 32 KiB per workgroup, 3 otherwise: 48 / 96 KiB).
-template <int TPQ, bool F16, int NW, int RING = 3>
+// AUX : cache policy of the LDS-DMA loads: 2 = nt (no L2 / MALL allocation) when ONE query block streams the corpus, i.e. every byte
+//       is read exactly once, as in K1s; 0 = default when several query blocks share a range through the XCD's L2.
+template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0>
 __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         const int soff = (p_row + my_row_off) * kRowBytes;   // rows past the document end read as zeros (bounds check)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, AUX);
         p_slot = (p_slot + 1 == kBatchRing) ? 0 : p_slot + 1;
         p_row += kChunkRows;
         if (p_row >= p_len) {
