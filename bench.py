@@ -186,6 +186,25 @@ def dropin_numbers(amd):
                      "reference_on_this_gpu_ms": ref * 1e3, "speedup_vs_reference_on_this_gpu": ref / ours,
                      "max_rel_err_vs_reference_fp32_on_this_gpu": e32, "max_rel_err_vs_reference_bf16_on_this_gpu": e16,
                      "frac_queries_with_identical_top10_vs_reference_fp32": same_top}
+    # BASELINE config 1 literally: 4 queries x 16 docs, random bf16 [32,128] x [1024,128] -- a latency case.  The reference runs it on
+    # the CPU (that is its "on CPU" baseline, timed here on this host); ours runs on cuda:0 and returns the same CPU fp32 tensor.
+    qs, ps = [unit(32) for _ in range(4)], [unit(1024) for _ in range(16)]
+    amd.score_multi_vector(qs, ps, device="cuda:0")
+    ts = []
+    for _ in range(21):
+        t0 = time.perf_counter()
+        got = amd.score_multi_vector(qs, ps, device="cuda:0")
+        ts.append(time.perf_counter() - t0)
+    ours1 = sorted(ts)[len(ts) // 2]
+    torch_port.score_multi_vector_cpu(qs, ps)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref_cpu = torch_port.score_multi_vector_cpu([t.float() for t in qs], [t.float() for t in ps])
+        ts.append(time.perf_counter() - t0)
+    out["config1_4x16"] = {"pairs": 64, "ms": ours1 * 1e3, "reference_on_this_host_cpu_ms": sorted(ts)[len(ts) // 2] * 1e3,
+                           "max_rel_err_vs_reference_fp32_on_cpu": float(((got - ref_cpu).abs() / ref_cpu.abs().clamp_min(1.0)).max()),
+                           "what": "end-to-end latency of one score_multi_vector call from host lists (pack, upload, kernel, D2H)"}
     out["device_note"] = ("BASELINE config 1 reads 'on CPU'; colpali_amd has no CPU path by design, so configs 1-3 are run with "
                           "device='cuda:0' and return the reference's CPU fp32 tensor")
     return out
