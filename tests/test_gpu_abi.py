@@ -298,3 +298,50 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
                                 coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(), None) == -1
     assert L.msim_loss_epilogue(0, raw.data_ptr(), 1, 1, 1, Q.data_ptr(), 0, Lq, 128, 0, 1.0, 0, 0, 0.95, 0.5, None, pairs.data_ptr(),
                                 coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(), None) == -1
+
+
+def test_probe_mfma_runs_and_validates_arguments(amd):
+    """msim_probe_mfma (measurement aid): every variant launches and leaves the sink untouched; bad arguments are refused."""
+    L = amd._lib.lib()
+    dev = torch.device("cuda:0")
+    rows = 256 * 8 * 5 * 32
+    x = torch.nn.functional.normalize(torch.randn((rows, 128), device=dev), dim=-1).to(torch.bfloat16)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for variant in range(8):
+        assert L.msim_probe_mfma(variant, x.data_ptr(), rows, 50, sink.data_ptr(), st) == 0, L.msim_last_error()
+    torch.cuda.synchronize()
+    assert float(sink.abs().sum()) == 0.0
+    assert L.msim_probe_mfma(8, x.data_ptr(), rows, 50, sink.data_ptr(), st) != 0
+    assert L.msim_probe_mfma(0, x.data_ptr(), rows - 1, 50, sink.data_ptr(), st) != 0
+    assert L.msim_probe_mfma(0, x.data_ptr(), rows, 0, sink.data_ptr(), st) != 0
+    assert L.msim_probe_mfma(0, None, rows, 50, sink.data_ptr(), st) != 0
+
+
+def test_forward_workspace_is_optional_and_changes_no_score(amd):
+    """msim_fwd's workspace only carries the convoy's progress counters (several query blocks streaming one document range):
+    with it, without it (NULL), and with a dirty one the scores are bit-identical; the workspace size query is consistent."""
+    L = amd._lib.lib()
+    dev = torch.device("cuda:0")
+    q, docs = _case(70, 600, ld=257, seed=4)            # 70 queries: three query blocks of 8-wave workgroups
+    q = q.to(dev)
+    corpus = amd.pack_passages(docs, dev, batch_size=None)
+    n_q, Lq, dim = q.shape
+    n = len(corpus)
+    need = L.msim_fwd_workspace_bytes(0, n_q, Lq, n, dim)
+    assert need > 0 and L.msim_fwd_workspace_bytes(0, 4, Lq, n, dim) == 0 and L.msim_fwd_workspace_bytes(2, n_q, Lq, n, dim) == 0
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(ws):
+        out = torch.empty((n_q, n), dtype=torch.float32, device=dev)
+        rc = L.msim_fwd(0, q.data_ptr(), n_q, Lq, corpus.blob.data_ptr(), corpus.offsets.data_ptr(), None, n, dim, out.data_ptr(), n, 0,
+                        None if ws is None else ws.data_ptr(), st)
+        assert rc == 0, L.msim_last_error()
+        torch.cuda.synchronize()
+        return out
+
+    base = run(None)
+    clean = torch.zeros(need, dtype=torch.uint8, device=dev)
+    dirty = torch.full((need,), 0x7f, dtype=torch.uint8, device=dev)     # the call initialises what it uses
+    assert torch.equal(run(clean), base) and torch.equal(run(dirty), base) and torch.equal(run(dirty), base)
+    assert torch.equal(amd.maxsim_scores(q, corpus), base)
