@@ -531,8 +531,9 @@ def main():
     if not args.no_parity:
         # every rank checks its own shard (the CPU oracle as the checker); the verdicts are combined below
         local_top = amd.topk(scores, args.topk, corpus.id_base)
-        par = topk_parity(amd, q, corpus, scores, local_top[0], local_top[1], args.topk)
-        par100 = topk_parity(amd, q, corpus, scores, *amd.topk(scores, 100, corpus.id_base), 100, n_queries=1)
+        n_rand = 1000 if world == 1 else 300       # N > 1: every rank runs the oracle on the cores torchrun leaves it (often one)
+        par = topk_parity(amd, q, corpus, scores, local_top[0], local_top[1], args.topk, n_random=n_rand)
+        par100 = topk_parity(amd, q, corpus, scores, *amd.topk(scores, 100, corpus.id_base), 100, n_queries=1, n_random=n_rand)
         par["k100"] = {k_: par100[k_] for k_ in ("checked_queries", "ids_equal", "ids_exact_equal", "max_rel_err")}
         if world > 1:
             flags = torch.tensor([int(par["ids_equal"]), int(par["ids_exact_equal"]), int(par100["ids_equal"]),
