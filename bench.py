@@ -242,6 +242,59 @@ def embed_head_numbers(amd, dev):
     return out
 
 
+def embed_and_score_numbers(amd, dev):
+    """BASELINE configs 2 / 3 without the VLM: the last hidden states of 1000 ColPali pages (1030 tokens x 2048, padded positions
+    masked) -> embeddings -> scores of 100 queries, end to end on one GPU.
+      ours:       CorpusWriter (fused head writing the scorer's packed corpus, 250 pages per append) -> maxsim_scores -> CPU fp32
+      reference:  its three torch lines (modeling_colpali.py:67-72) -> list(torch.unbind(emb.cpu())) (README.md:121-126) -> its
+                  blocked scorer on cuda:0 (processing_utils.py:170-186, via oracle/torch_port.py)
+    Both produce the [100, 1000] fp32 score matrix on the CPU; they are compared (the reference path rounds every similarity to
+    bf16, so agreement is ~5e-3)."""
+    from oracle import torch_port
+
+    B, S, H, nq = 1000, 1030, 2048, 100
+    g = torch.Generator(device=dev).manual_seed(5)
+    hidden = torch.randn((B, S, H), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    weight = (torch.randn((128, H), generator=g, device=dev) / H**0.5).to(torch.bfloat16)
+    bias = (torch.randn((128,), generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    mask = torch.ones((B, S), dtype=torch.long, device=dev)
+    mask[:, S - 6:] = 0
+    q = make_queries(nq, 32, dev, seed=8)
+    qs_host = list(torch.unbind(q.cpu()))
+
+    def ours():
+        writer = amd.CorpusWriter(capacity_rows=B * S, device=dev)
+        for b0 in range(0, B, 250):
+            writer.append(hidden[b0:b0 + 250], weight, bias, mask[b0:b0 + 250])
+        return amd.maxsim_scores(q, writer.finish()).cpu()
+
+    def ref():
+        proj = torch.nn.functional.linear(hidden, weight, bias)
+        proj = proj / proj.norm(dim=-1, keepdim=True)
+        emb = proj * mask.unsqueeze(-1)
+        ps = list(torch.unbind(emb.to("cpu")))
+        return torch_port.score_multi_vector_cpu(qs_host, ps, device="cuda:0")
+
+    def timed(fn, reps):
+        out = fn()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], out
+
+    t_ours, s_ours = timed(ours, 5)
+    t_ref, s_ref = timed(ref, 2)
+    err = float(((s_ours - s_ref).abs() / s_ref.abs().clamp_min(1.0)).max())
+    del hidden
+    return {"workload": f"{B} pages x {S} tokens x hidden {H} bf16 -> embeddings -> scores of {nq} queries (BASELINE configs 2/3 minus the VLM)",
+            "ms": t_ours * 1e3, "pages_per_s": B / t_ours, "reference_path_on_this_gpu_ms": t_ref * 1e3,
+            "speedup_vs_reference_path": t_ref / t_ours, "max_rel_err_vs_reference_path_bf16": err}
+
+
 def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
     """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list, the last
     step's score matrix, the last step's (top scores, top ids))."""
@@ -567,6 +620,7 @@ def main():
         out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)
         out["embed_head"] = embed_head_numbers(amd, dev)
         out["dropin_from_host_lists"] = dropin_numbers(amd)
+        out["embed_and_score_1k_pages"] = embed_and_score_numbers(amd, dev)
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
