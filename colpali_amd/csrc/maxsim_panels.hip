@@ -1,13 +1,13 @@
 // K1sP / K1bP -- the tuned MaxSim kernels for embeddings WIDER than 128 (ColQwen3: dim = 320,
 // colpali_engine/models/qwen3/colqwen3/modeling_colqwen3.py:48), 16-bit.  Same arithmetic as K1s / K1b
 // (colpali_engine/utils/processing_utils.py:179); same building blocks: LDS-DMA with a per-document buffer
-// descriptor, the 32 x 256 B slab image XOR-swizzled on the source address, swapped 32x32x16 MFMA with the
-// running max in registers.
+// descriptor, the 32 x 256 B slab image XOR-swizzled on the source address, the swapped 16x16x32 MFMA tiling of
+// maxsim_common.hpp with the running max in registers.
 //
 // A row of dim * 2 bytes is streamed as PANELS column panels of 256 bytes (128 elements): panel p of a 32-row slab is
 // one 8 KiB "panel-slab" with exactly the LDS image of a dim-128 slab, so the swizzle, the operand fetches and the
 // conflict-freeness carry over unchanged; the MFMA chain of a (slab, token tile) simply runs across the panels
-// (8 k-steps per full panel, KS_LAST in the last one) before the max is folded.  dim = ((PANELS-1)*8 + KS_LAST) * 16 is a
+// (4 k-steps of 32 per full panel, KS_LAST / 2 in the last one) before the max is folded.  dim = ((PANELS-1)*8 + KS_LAST) * 16 is a
 // compile-time constant of each instantiation.  In the last panel the lanes whose 16-byte chunk lies beyond the row
 // re-read chunk 0 of their row instead (their LDS slots are never consumed): no byte outside the row is fetched.
 //
@@ -51,25 +51,32 @@ __global__ __launch_bounds__(256) void maxsim_stream_panels_kernel(const uint16_
     const int gw = blockIdx.x * 4 + wave;
     const int GW = gridDim.x * 4;
 
-    // ---- query fragments (B operand): lane supplies token (lane & 31), k-slice (lane >> 5) of each k-step
-    bf16x8 qf[QT][KT];
+    // ---- query fragments (B operands of the 16x16x32 tiling, maxsim_common.hpp): [tile][token half][k-step of 32]
+    static_assert(KS_LAST % 2 == 0, "the last panel must hold whole k-steps of 32");
+    constexpr int KT32 = KT / 2;
+    bf16x8 qf[QT][2][KT32];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = t / TPQ;
-        const int row = (t % TPQ) * kTokTile + (lane & 31);
-        const bool valid = row < a.Lq;
-        const uint16_t *p = Q + ((size_t)q * a.Lq + (valid ? row : 0)) * DIM + (lane >> 5) * 8;
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 16);
-            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int h = 0; h < 2; ++h) {
+            const int row = (t % TPQ) * kTokTile + 16 * h + (lane & 15);
+            const bool valid = row < a.Lq;
+            const uint16_t *p = Q + ((size_t)q * a.Lq + (valid ? row : 0)) * DIM + (lane >> 4) * 8;
+#pragma unroll
+            for (int ks = 0; ks < KT32; ++ks) {
+                bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+                qf[t][h][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     }
     wait_vmcnt<0>();
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KT32; ++ks) asm volatile("" : "+v"(qf[t][h][ks]));
 
     int src_full[4], src_last[4];
 #pragma unroll
@@ -77,9 +84,8 @@ __global__ __launch_bounds__(256) void maxsim_stream_panels_kernel(const uint16_
         src_full[j] = panel_src_off(lane, j, ROW_BYTES, 16);
         src_last[j] = panel_src_off(lane, j, ROW_BYTES, 2 * KS_LAST);
     }
-    int rd_off[kKSteps];
-#pragma unroll
-    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
 
     // ---- producer cursor (wave-uniform): next panel-slab to request = (document, first row of the slab, panel)
     int p_idx = gw, p_row = 0, p_len = 0, p_pan = 0;
@@ -128,40 +134,46 @@ __global__ __launch_bounds__(256) void maxsim_stream_panels_kernel(const uint16_
     for (int c_idx = gw; c_idx < a.n_d; c_idx += GW) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nslab = (len + kSlabRows - 1) / kSlabRows;
-        float m[QT];
+        float m[QT][2];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) m[t] = -INFINITY;
+        for (int t = 0; t < QT; ++t) m[t][0] = m[t][1] = -INFINITY;
 
         for (int s = 0; s < nslab; ++s) {
-            f32x16 acc[QT];
+            TileAcc acc[QT];
 #pragma unroll
-            for (int t = 0; t < QT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[t].a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < PANELS; ++p) {
-                constexpr int kFull = kKSteps;
-                const int nks = p == PANELS - 1 ? KS_LAST : kFull;
+                const int nks = p == PANELS - 1 ? KS_LAST / 2 : kKSteps16;     // k-steps of 32 in this panel
                 if (produce()) wait_vmcnt<8 * (kPanelRing - 1)>(); else wait_vmcnt<0>();
                 const char *src = ring + c_slot * kSlabBytes;
                 c_slot = (c_slot + 1 == kPanelRing) ? 0 : c_slot + 1;
-                bf16x8 af[kKSteps];
+                bf16x8 af[2][kKSteps16];
 #pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks)
-                    if (ks < nks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int ks = 0; ks < kKSteps16; ++ks)
+                        if (ks < nks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[g][ks]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
 #pragma unroll
-                    for (int ks = 0; ks < kKSteps; ++ks)
-                        if (ks < nks) acc[t] = mfma32<F16>(af[ks], qf[t][p * 8 + ks], acc[t]);
+                    for (int ks = 0; ks < kKSteps16; ++ks)
+                        if (ks < nks) {
+#pragma unroll
+                            for (int hg = 0; hg < 4; ++hg)
+                                acc[t].a[hg >> 1][hg & 1] =
+                                    mfma16<F16>(af[hg & 1][ks], qf[t][hg >> 1][p * kKSteps16 + ks], acc[t].a[hg >> 1][hg & 1]);
+                        }
             }
             const int rows_left = len - s * kSlabRows;
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                if (rows_left < kSlabRows) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (acc_row(r, lane) >= rows_left) acc[t][r] = -INFINITY;
-                }
-                m[t] = fold_max16(m[t], acc[t]);
+                if (rows_left < kSlabRows) tile_mask_tail(acc[t], rows_left, lane);
+                tile_fold(m[t], acc[t]);
             }
         }
 
@@ -172,12 +184,7 @@ __global__ __launch_bounds__(256) void maxsim_stream_panels_kernel(const uint16_
         }
         float tile_sum[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float v = fmaxf(m[t], __shfl_xor(m[t], 32));
-            if (clamp) v = fmaxf(v, 0.0f);
-            if (ref_bf16) v = round_to_input<F16>(v);
-            tile_sum[t] = half_wave_sum(v);
-        }
+        for (int t = 0; t < QT; ++t) tile_sum[t] = tile_finish<F16>(m[t], clamp, ref_bf16);
         if (lane == 0) {
 #pragma unroll
             for (int q = 0; q < QT / TPQ; ++q) {
@@ -221,24 +228,31 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
     static_assert(NT >= 1 && NT <= 2 && NT % TPQ == 0, "a wave holds whole queries");
     constexpr int q_per_wave = NT / TPQ;
     const int q_first = (qblock * kBatchWaves + wave) * q_per_wave;
-    bf16x8 qf[NT][KT];
+    static_assert(KS_LAST % 2 == 0, "the last panel must hold whole k-steps of 32");
+    constexpr int KT32 = KT / 2;
+    bf16x8 qf[NT][2][KT32];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int q = q_first + t / TPQ;
-        const int row = (t % TPQ) * kTokTile + (lane & 31);
-        const bool valid = q < a.n_q && row < a.Lq;
-        const uint16_t *p = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * DIM + (lane >> 5) * 8;
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 16);
-            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int h = 0; h < 2; ++h) {
+            const int row = (t % TPQ) * kTokTile + 16 * h + (lane & 15);
+            const bool valid = q < a.n_q && row < a.Lq;
+            const uint16_t *p = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * DIM + (lane >> 4) * 8;
+#pragma unroll
+            for (int ks = 0; ks < KT32; ++ks) {
+                bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+                qf[t][h][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     }
     wait_vmcnt<0>();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KT32; ++ks) asm volatile("" : "+v"(qf[t][h][ks]));
     const bool wave_has_queries = q_first < a.n_q;
 
     // ---- this wave's share of a stage's 8 * PANELS LDS-DMA wave-instructions: instruction `wave` (rows 4*wave .. 4*wave+3)
@@ -246,9 +260,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
     const int my_src_full = panel_src_off(lane, wave & 3, ROW_BYTES, 16) + wave * 4 * ROW_BYTES;
     const int my_src_last = panel_src_off(lane, wave & 3, ROW_BYTES, 2 * KS_LAST) + wave * 4 * ROW_BYTES;
     const int my_lds = wave * 1024;
-    int rd_off[kKSteps];
-#pragma unroll
-    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
 
     // ---- producer cursor over the flattened (document, slab) sequence of [d_lo, d_hi)
     int p_idx = d_lo, p_row = 0, p_len = 0;
@@ -292,9 +305,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
     for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nslab = (len + kSlabRows - 1) / kSlabRows;
-        float m[NT];
+        float m[NT][2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) m[t] = -INFINITY;
+        for (int t = 0; t < NT; ++t) m[t][0] = m[t][1] = -INFINITY;
 
         for (int s = 0; s < nslab; ++s) {
             // my share of this stage has landed once at most (stages - 2) later stages of mine are still in flight
@@ -304,27 +317,33 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
             const char *st = smem + c_slot * kStage;
             c_slot = (c_slot + 1 == kPanelStages) ? 0 : c_slot + 1;
             if (wave_has_queries) {
-                f32x16 acc[NT];
+                TileAcc acc[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc[t].a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int p = 0; p < PANELS; ++p)
 #pragma unroll
-                    for (int ks = 0; ks < kKSteps; ++ks)
-                        if (ks < (p == PANELS - 1 ? KS_LAST : kKSteps)) {
-                            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(st + p * kSlabBytes + rd_off[ks]);
+                    for (int ks = 0; ks < kKSteps16; ++ks)
+                        if (ks < (p == PANELS - 1 ? KS_LAST / 2 : kKSteps16)) {
+                            bf16x8 af[2];
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[t] = mfma32<F16>(af, qf[t][p * 8 + ks], acc[t]);
+                            for (int g = 0; g < 2; ++g) af[g] = *reinterpret_cast<const bf16x8 *>(st + p * kSlabBytes + rd_off[g][ks]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int hg = 0; hg < 4; ++hg)
+                                    acc[t].a[hg >> 1][hg & 1] =
+                                        mfma16<F16>(af[hg & 1], qf[t][hg >> 1][p * kKSteps16 + ks], acc[t].a[hg >> 1][hg & 1]);
                         }
                 const int rows_left = len - s * kSlabRows;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (rows_left < kSlabRows) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (acc_row(r, lane) >= rows_left) acc[t][r] = -INFINITY;
-                    }
-                    m[t] = fold_max16(m[t], acc[t]);
+                    if (rows_left < kSlabRows) tile_mask_tail(acc[t], rows_left, lane);
+                    tile_fold(m[t], acc[t]);
                 }
             }
         }
@@ -337,12 +356,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
             }
             float tile_sum[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float v = fmaxf(m[t], __shfl_xor(m[t], 32));
-                if (clamp) v = fmaxf(v, 0.0f);
-                if (ref_bf16) v = round_to_input<F16>(v);
-                tile_sum[t] = half_wave_sum(v);
-            }
+            for (int t = 0; t < NT; ++t) tile_sum[t] = tile_finish<F16>(m[t], clamp, ref_bf16);
             if (lane == 0) {
 #pragma unroll
                 for (int qq = 0; qq < q_per_wave; ++qq) {

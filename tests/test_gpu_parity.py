@@ -317,9 +317,10 @@ def test_dim320_panel_kernels_against_oracle(amd, dtype, n_q, lq_max, n_d, ld_ma
     assert close(got, _oracle(qs, ps, bs))
 
 
-def test_dim320_panel_kernels_agree_bitwise_with_each_other_and_the_generic_kernel(amd):
-    # the same MFMA chain in the same k order and the same reduction tree in K1sP (query alone), K1bP (inside a batch)
-    # and K1g (same query zero-padded to 160 tokens: five tiles, which only the generic kernel takes)
+def test_dim320_panel_kernels_agree_bitwise_with_each_other_and_closely_with_the_generic_kernel(amd):
+    # the same 16x16x32 MFMA chain in the same k order and the same reduction tree in K1sP (query alone) and K1bP (inside a
+    # batch): bit-identical; K1g (same query zero-padded to 160 tokens: five tiles, which only the generic kernel takes) runs
+    # 32x32x16 tiles: equal up to the summation order inside the matrix unit
     qs, ps = _random_generic(11, 20, 32, 200, 500, 320, torch.bfloat16)
     dev = torch.device("cuda:0")
     corpus = amd.pack_passages(ps, dev)
@@ -331,7 +332,7 @@ def test_dim320_panel_kernels_agree_bitwise_with_each_other_and_the_generic_kern
         assert torch.equal(one[0], big[i])
         long_q = torch.cat([qs[i], qs[i].new_zeros(160 - qs[i].shape[0], 320)])
         gen = amd.maxsim_scores(amd.pack_queries([long_q], dev), corpus).cpu()            # K1g
-        assert torch.equal(gen[0], big[i])
+        assert float(((gen[0] - big[i]).abs() / big[i].abs().clamp_min(1.0)).max()) < 2e-6
 
 
 def test_dim320_many_documents_and_literal_rounding(amd):
