@@ -65,6 +65,7 @@ struct HeadArgs {
     long long M;          // token rows
     int H;                // hidden size (multiple of 64)
     long long ld_out;     // elements between consecutive output rows (>= 128)
+    unsigned long long *trace;   // debug (MSIM_HEAD_TRACE_PTR): per wave of workgroup 0, cycles spent per phase; null in production
 };
 
 // row_map[m] (int32, ceil(M / 256) * 256 entries):  v >= 0: write the normalised row to out row v;
@@ -77,16 +78,24 @@ struct HeadArgs {
 //                private hidden-state streams are no longer coupled: a wave whose rows arrive late delays nobody, and the waves
 //                drift out of phase, so one wave's operand reads overlap another's MFMAs.
 // PIPE: the operand fetch of a chunk is software-pipelined by hand two k-steps ahead of the MFMAs (see the loop).
-template <bool F16, bool FLAGS = false, bool PIPE = false>
+// EPI2: MFMA operand roles swapped (A = weight rows = output columns, B = hidden rows), so that a lane ends a tile holding 64 of
+//       the 128 output columns of ONE hidden row instead of one column of 16 rows.  The s_memtime trace of the first form
+//       (tools/trace_head.py) showed the per-tile epilogue taking a quarter of the kernel: 16 five-step butterflies for the row
+//       norms, 32 dependent scalar row-map loads and 64 two-byte stores per lane.  Here the row norm is an in-lane sum plus one
+//       lane exchange, the row map is read once per lane, and a lane stores 16 x 8 bytes.
+// DEEPW: hidden-state ring 3 deep, weight ring 3 deep with the loader TWO chunks ahead (still one s_barrier per chunk): the s_memtime
+//       trace showed the loader on the critical path -- it issued chunk c+1 at barrier c and had to see it land (an L2 round trip of
+//       16 KiB, ~1000-1500 ticks) before barrier c+1 -- while the compute waves never waited for their hidden states (vmcnt ~80 ticks).
+template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false>
 __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
                                                                      const int32_t *__restrict__ row_map,
                                                                      uint16_t *__restrict__ out, HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kRingA = FLAGS ? kHeadFRingA : kHeadRingA;
-    constexpr int kRingW = FLAGS ? kHeadFRingW : kHeadRingW;
-    constexpr int kWBase = FLAGS ? kHeadFWBase : kHeadWBase;
+    constexpr int kRingA = (FLAGS || DEEPW) ? kHeadFRingA : kHeadRingA;
+    constexpr int kRingW = (FLAGS || DEEPW) ? kHeadFRingW : kHeadRingW;
+    constexpr int kWBase = (FLAGS || DEEPW) ? kHeadFWBase : kHeadWBase;
     volatile int *const f_ready = reinterpret_cast<volatile int *>(smem + kHeadFFlags);          // weight chunks landed
     volatile int *const f_done = reinterpret_cast<volatile int *>(smem + kHeadFFlags) + 1;       // [8] chunks consumed per compute wave
     const int lane = threadIdx.x & 63;
@@ -99,10 +108,11 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
     // ---- bias: one column per lane and column tile
     float bias_f[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias_f[j] = bias != nullptr ? elem_to_float<F16>(bias[j * 32 + l31]) : 0.0f;
+    for (int j = 0; j < 4; ++j) bias_f[j] = (!EPI2 && bias != nullptr) ? elem_to_float<F16>(bias[j * 32 + l31]) : 0.0f;
     wait_vmcnt<0>();
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bias_f[j]));
+    const uint32_t *bias32 = reinterpret_cast<const uint32_t *>(bias);     // EPI2: pairs of adjacent columns, read through the scalar cache
 
     // ---- LDS image of a chunk: 128-byte rows, logical 16-byte chunk c of row r stored at physical chunk c ^ ((r >> 1) & 7).
     // One LDS-DMA wave-instruction fills 1 KiB = 8 rows x 128 B linearly: lane -> (row = lane >> 3, physical chunk lane & 7).
@@ -154,11 +164,34 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             if (lane == 0) *f_ready = total;
             return;
         }
+        if constexpr (DEEPW) {
+            if (total > 0) load_w(0);
+            if (total > 1) load_w(1);
+            for (int c = 0; c < total; ++c) {
+                if (c + 1 < total) wait_vmcnt<16>(); else wait_vmcnt<0>();   // W chunk c has landed (chunk c + 1 may still be in flight)
+                __builtin_amdgcn_s_barrier();    // consumers may read chunk c; they are done with chunk c - 1, whose slot is free again
+                if (c + 2 < total) load_w(c + 2);
+            }
+            return;
+        }
         if (total > 0) load_w(0);
+        unsigned long long tr_vm = 0, tr_bar = 0, tr_issue = 0;
+        const bool tracing = a.trace != nullptr && blockIdx.x == 0;
         for (int c = 0; c < total; ++c) {
+            const unsigned long long t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             wait_vmcnt<0>();                 // W chunk c has landed
+            const unsigned long long t1 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             __builtin_amdgcn_s_barrier();    // consumers may read it; they are done with chunk c - 1, whose slot is free again
+            const unsigned long long t2 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             if (c + 1 < total) load_w(c + 1);
+            if (tracing) {
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                tr_vm += t1 - t0; tr_bar += t2 - t1; tr_issue += t3 - t2;
+            }
+        }
+        if (tracing && lane == 0) {
+            a.trace[wave * 8 + 0] = tr_issue; a.trace[wave * 8 + 1] = tr_vm; a.trace[wave * 8 + 2] = tr_bar; a.trace[wave * 8 + 3] = 0;
+            a.trace[wave * 8 + 4] = (unsigned long long)total;
         }
         return;
     }
@@ -214,6 +247,8 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
     for (int i = 0; i < kRingA - 1; ++i) produce();
 
     int c_slot = 0, c_count = 0, w_slot = 0, seen_ready = 0;
+    unsigned long long tr_issue = 0, tr_vm = 0, tr_bar = 0, tr_comp = 0, tr_epi = 0;
+    const bool tracing = !FLAGS && a.trace != nullptr && blockIdx.x == 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         f32x16 acc[4];
 #pragma unroll
@@ -222,7 +257,11 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
         for (int ch = 0; ch < n_chunks; ++ch, ++c_count) {
             // the slot consumed in the previous iteration is private to this wave and free again: refill it, then wait for
             // this chunk's 4 loads (the rows are this wave's own -- no barrier is involved in the A stream at all)
-            if (produce()) wait_vmcnt<4 * (kRingA - 1)>(); else wait_vmcnt<0>();
+            const unsigned long long t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
+            const bool issued = produce();
+            const unsigned long long t1 = tracing ? __builtin_amdgcn_s_memtime() : 0;
+            if (issued) wait_vmcnt<4 * (kRingA - 1)>(); else wait_vmcnt<0>();
+            const unsigned long long t2 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             if constexpr (FLAGS) {
                 while (seen_ready <= c_count) {                    // weight chunk c_count not known to have landed: poll
                     seen_ready = *f_ready;
@@ -232,6 +271,7 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             } else {
                 __builtin_amdgcn_s_barrier();   // W chunk landed (loader wave); everyone finished reading the previous W chunk
             }
+            const unsigned long long t3 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             const char *sa = smem + c_slot * kHeadABytes;
             const char *sw = smem + w_slot * kHeadWBytes;
             w_slot = (w_slot + 1 == kRingW) ? 0 : w_slot + 1;
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
                     __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
                     for (int j = 0; j < 4; ++j)   // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
-                        acc[j] = mfma32<F16>(fa[ks % 3], fw[ks % 3][j], acc[j]);
+                        acc[j] = EPI2 ? mfma32<F16>(fw[ks % 3][j], fa[ks % 3], acc[j]) : mfma32<F16>(fa[ks % 3], fw[ks % 3][j], acc[j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -268,9 +308,16 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
                     for (int j = 0; j < 4; ++j) {
                         const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(sw + b_rd[ks] + j * 4096);
                         // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
-                        acc[j] = mfma32<F16>(af, bf, acc[j]);
+                        acc[j] = EPI2 ? mfma32<F16>(bf, af, acc[j]) : mfma32<F16>(af, bf, acc[j]);
                     }
                 }
+            }
+            if (tracing) {
+                // the MFMAs have been issued, not retired: make the accumulators' values needed before stamping
+                float sink = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+                asm volatile("" ::"v"(sink));
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                tr_issue += t1 - t0; tr_vm += t2 - t1; tr_bar += t3 - t2; tr_comp += t4 - t3;
             }
             if constexpr (FLAGS) {
                 // every operand read of this chunk has been ISSUED (LDS executes a wave's operations in order): release the slot
@@ -279,9 +326,69 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
             }
         }
 
+        const unsigned long long te0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
         // ---- epilogue: acc[j][r] of lane (l31, half) = (row 32*wave + row(r, half), column 32*j + l31)
         const long long row0 = (long long)tile * kHeadBM + wave * 32;
         const int32_t *rm = row_map + row0;          // wave-uniform address: read through the scalar cache
+        if constexpr (EPI2) {
+            // acc[j][r] of lane (l31, half) = (hidden row 32*wave + l31, output column 32*j + acc_row(r, lane))
+            int v = -1;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int sv = rm[i];                      // wave-uniform address: scalar loads (merged by the compiler)
+                v = l31 == i ? sv : v;
+            }
+            float ssq = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // the lane's column is 32j + acc_row(r, 0) + 4 * half: both candidates come from wave-uniform (scalar) loads
+                    float bv = 0.0f;
+                    if (bias != nullptr) {
+                        const uint32_t lo = bias32[(j * 32 + acc_row(r & ~1, 0)) >> 1], hi = bias32[(j * 32 + acc_row(r & ~1, 0) + 4) >> 1];
+                        const uint32_t pk = half ? hi : lo;
+                        bv = elem_to_float<F16>((uint16_t)((r & 1) ? (pk >> 16) : (pk & 0xffffu)));
+                    }
+                    const float y = round_to_input<F16>(acc[j][r] + bv);
+                    acc[j][r] = y;
+                    ssq += y * y;
+                }
+            ssq += __shfl_xor(ssq, 32);                    // the other 64 columns of the same row
+            const float nrm = round_to_input<F16>(sqrtf(ssq));
+            // 64 quotients by one divisor: reciprocal, product, one Newton correction (2 FMAs) = the correctly rounded quotient in
+            // all but ~1e-7 of the cases, which the rounding to 16 bits that follows absorbs; a subnormal norm takes the real division
+            const float rcp = 1.0f / nrm;
+            const bool tiny = nrm < 1e-30f;
+            auto quot = [&](float y) {
+                float qv = y * rcp;
+                qv = fmaf(fmaf(-qv, nrm, y), rcp, qv);
+                return tiny ? y / nrm : qv;
+            };
+            if (v != -1) {
+                const bool zero = v < 0;
+                uint16_t *dst = out + (size_t)(zero ? -2 - v : v) * a.ld_out + 4 * half;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {       // registers 4rg .. 4rg+3 = four consecutive columns: one 8-byte store
+                        uint16_t b4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float o = round_to_input<F16>(quot(acc[j][4 * rg + e]));
+                            if (zero) o *= 0.0f;           // `proj * attention_mask`: +-0 (sign kept), NaN stays NaN
+                            if constexpr (F16) b4[e] = __builtin_bit_cast(uint16_t, (_Float16)o);
+                            else b4[e] = (uint16_t)(__float_as_uint(o) >> 16);
+                        }
+                        uint2 w2;
+                        w2.x = (uint32_t)b4[0] | ((uint32_t)b4[1] << 16);
+                        w2.y = (uint32_t)b4[2] | ((uint32_t)b4[3] << 16);
+                        *reinterpret_cast<uint2 *>(dst + j * 32 + 8 * rg) = w2;
+                    }
+            }
+            if (tracing) tr_epi += __builtin_amdgcn_s_memtime() - te0;
+            continue;
+        }
         float ss[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -309,6 +416,11 @@ __global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t
                 dst[j * 32] = bits;
             }
         }
+        if (tracing) tr_epi += __builtin_amdgcn_s_memtime() - te0;
+    }
+    if (tracing && lane == 0) {
+        a.trace[wave * 8 + 0] = tr_issue; a.trace[wave * 8 + 1] = tr_vm; a.trace[wave * 8 + 2] = tr_bar; a.trace[wave * 8 + 3] = tr_comp;
+        a.trace[wave * 8 + 4] = (unsigned long long)c_count; a.trace[wave * 8 + 5] = tr_epi;
     }
 }
 

@@ -971,6 +971,9 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     a.M = M;
     a.H = H;
     a.ld_out = ld_out;
+    a.trace = nullptr;
+    if (const char *tp = getenv("MSIM_HEAD_TRACE_PTR"))      // debug knob: device address of 9 x 8 uint64 (tools/trace_head.py)
+        a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
     const long long tiles = (M + msim::kHeadBM - 1) / msim::kHeadBM;
     const int grid = tiles < di->cus ? (int)tiles : di->cus;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -981,19 +984,33 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         hipLaunchKernelGGL(kern, dim3(grid), dim3(msim::kHeadThreads), lds, st, x, w, b, row_map, o, a);
         return MSIM_OK;
     };
-    static std::atomic<int> configured[8][kMaxDevices];
+    static std::atomic<int> configured[12][kMaxDevices];
     // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
-    // fetch (tuning knob for A/B measurements, not part of the ABI; the default is the measured winner)
-    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 3 : 0;
+    // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (the default): loader two weight chunks ahead, rings 3 + 3
+    // (tuning knob for A/B measurements, not part of the ABI; profiles/r02_logs/ab_head_variants.log)
+    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 15 : 8;
     int rc;
     const bool f16 = dtype == MSIM_DTYPE_F16;
-    switch (variant) {
+    const bool epi2 = (variant & 4) && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
+                      (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0);   // 8-byte stores, 4-byte bias loads
+    // bit 3: loader two weight chunks ahead (rings 3 + 3)
+    if ((variant & 8) && (variant & 4) && epi2) {
+        static std::atomic<int> configured2[2][kMaxDevices];
+        rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true>, configured2[0], msim::kHeadFLds)
+                 : go(msim::embed_head_kernel<false, false, false, true, true>, configured2[1], msim::kHeadFLds);
+    } else if (variant & 8) {
+        rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true>, configured[10], msim::kHeadFLds)
+                 : go(msim::embed_head_kernel<false, false, false, false, true>, configured[11], msim::kHeadFLds);
+    } else
+    switch (epi2 ? 4 : (variant & 3)) {
         case 1: rc = f16 ? go(msim::embed_head_kernel<true, true, false>, configured[0], msim::kHeadFLds)
                          : go(msim::embed_head_kernel<false, true, false>, configured[1], msim::kHeadFLds); break;
         case 2: rc = f16 ? go(msim::embed_head_kernel<true, false, true>, configured[2], msim::kHeadLds)
                          : go(msim::embed_head_kernel<false, false, true>, configured[3], msim::kHeadLds); break;
         case 3: rc = f16 ? go(msim::embed_head_kernel<true, true, true>, configured[4], msim::kHeadFLds)
                          : go(msim::embed_head_kernel<false, true, true>, configured[5], msim::kHeadFLds); break;
+        case 4: rc = f16 ? go(msim::embed_head_kernel<true, false, false, true>, configured[8], msim::kHeadLds)
+                         : go(msim::embed_head_kernel<false, false, false, true>, configured[9], msim::kHeadLds); break;
         default: rc = f16 ? go(msim::embed_head_kernel<true, false, false>, configured[6], msim::kHeadLds)
                           : go(msim::embed_head_kernel<false, false, false>, configured[7], msim::kHeadLds); break;
     }

@@ -41,12 +41,11 @@ __device__ __forceinline__ float fold_max16(float m, const f32x16 &c) {
     return m;
 }
 
-// round-to-nearest-even to bf16, result kept as fp32 (torch's float->bfloat16->float)
+// round-to-nearest-even to bf16, result kept as fp32 (torch's float->bfloat16->float): gfx950 converts in hardware
+// (v_cvt_pk_bf16_f32: round to nearest even, NaN stays a quiet NaN)
 __device__ __forceinline__ float bf16_round(float x) {
-    uint32_t u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return __uint_as_float((u | 0x00400000u) & 0xffff0000u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return __uint_as_float(u & 0xffff0000u);
+    const __bf16 b = (__bf16)x;
+    return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
 }
 
 // D = A * B + C on one 32x32x16 tile; operands travel as 8 x 16-bit lanes whatever the element type
