@@ -86,16 +86,22 @@ struct HeadArgs {
 // DEEPW: hidden-state ring 3 deep, weight ring 3 deep with the loader TWO chunks ahead (still one s_barrier per chunk): the s_memtime
 //       trace showed the loader on the critical path -- it issued chunk c+1 at barrier c and had to see it land (an L2 round trip of
 //       16 KiB, ~1000-1500 ticks) before barrier c+1 -- while the compute waves never waited for their hidden states (vmcnt ~80 ticks).
-template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false>
-__global__ __launch_bounds__(kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
+// HALF: two workgroups per CU, each with 4 compute waves (128-row tiles) + its own loader and half the LDS (hidden-state ring 3, weight
+//       ring 2): the lock-step phases of one workgroup overlap the other's, at the price of every weight chunk being fetched twice per CU.
+template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false, bool HALF = false>
+__global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
                                                                      const int32_t *__restrict__ row_map,
                                                                      uint16_t *__restrict__ out, HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kRingA = (FLAGS || DEEPW) ? kHeadFRingA : kHeadRingA;
+    static_assert(!HALF || (!FLAGS && !DEEPW), "HALF has its own ring plan");
+    constexpr int kHeadWaves = HALF ? 4 : 8;                 // compute waves (shadows the namespace constants below)
+    constexpr int kHeadBM = kHeadWaves * 32;
+    constexpr int kHeadABytes = kHeadBM * kHeadBK * 2;
+    constexpr int kRingA = (FLAGS || DEEPW || HALF) ? kHeadFRingA : kHeadRingA;
     constexpr int kRingW = (FLAGS || DEEPW) ? kHeadFRingW : kHeadRingW;
-    constexpr int kWBase = (FLAGS || DEEPW) ? kHeadFWBase : kHeadWBase;
+    constexpr int kWBase = kRingA * kHeadABytes;
     volatile int *const f_ready = reinterpret_cast<volatile int *>(smem + kHeadFFlags);          // weight chunks landed
     volatile int *const f_done = reinterpret_cast<volatile int *>(smem + kHeadFFlags) + 1;       // [8] chunks consumed per compute wave
     const int lane = threadIdx.x & 63;

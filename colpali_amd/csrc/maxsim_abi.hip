@@ -976,6 +976,8 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
     const long long tiles = (M + msim::kHeadBM - 1) / msim::kHeadBM;
     const int grid = tiles < di->cus ? (int)tiles : di->cus;
+    const long long tiles_h = (M + 127) / 128;                               // HALF variant: 128-row tiles, two workgroups per CU
+    const int grid_h = tiles_h < 2 * di->cus ? (int)tiles_h : 2 * di->cus;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X), *w = static_cast<const uint16_t *>(W), *b = static_cast<const uint16_t *>(bias);
     uint16_t *o = static_cast<uint16_t *>(out);
@@ -984,17 +986,27 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         hipLaunchKernelGGL(kern, dim3(grid), dim3(msim::kHeadThreads), lds, st, x, w, b, row_map, o, a);
         return MSIM_OK;
     };
+    auto go_half = [&](auto kern, std::atomic<int> *configured) -> int {
+        constexpr int lds = 3 * 128 * 128 + 2 * msim::kHeadWBytes;             // 48 + 32 KiB
+        if (int rc = allow_lds(kern, lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid_h), dim3(320), lds, st, x, w, b, row_map, o, a);
+        return MSIM_OK;
+    };
     static std::atomic<int> configured[12][kMaxDevices];
     // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
     // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (the default): loader two weight chunks ahead, rings 3 + 3
     // (tuning knob for A/B measurements, not part of the ABI; profiles/r02_logs/ab_head_variants.log)
-    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 15 : 8;
+    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 31 : 8;
     int rc;
     const bool f16 = dtype == MSIM_DTYPE_F16;
     const bool epi2 = (variant & 4) && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                       (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0);   // 8-byte stores, 4-byte bias loads
     // bit 3: loader two weight chunks ahead (rings 3 + 3)
-    if ((variant & 8) && (variant & 4) && epi2) {
+    if (variant & 16) {           // bit 4: two half-size workgroups per CU
+        static std::atomic<int> configured3[2][kMaxDevices];
+        rc = f16 ? go_half(msim::embed_head_kernel<true, false, false, false, false, true>, configured3[0])
+                 : go_half(msim::embed_head_kernel<false, false, false, false, false, true>, configured3[1]);
+    } else if ((variant & 8) && (variant & 4) && epi2) {
         static std::atomic<int> configured2[2][kMaxDevices];
         rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true>, configured2[0], msim::kHeadFLds)
                  : go(msim::embed_head_kernel<false, false, false, true, true>, configured2[1], msim::kHeadFLds);
