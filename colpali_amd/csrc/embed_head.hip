@@ -88,7 +88,10 @@ struct HeadArgs {
 //       16 KiB, ~1000-1500 ticks) before barrier c+1 -- while the compute waves never waited for their hidden states (vmcnt ~80 ticks).
 // HALF: two workgroups per CU, each with 4 compute waves (128-row tiles) + its own loader and half the LDS (hidden-state ring 3, weight
 //       ring 2): the lock-step phases of one workgroup overlap the other's, at the price of every weight chunk being fetched twice per CU.
-template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false, bool HALF = false>
+// IL:   a compute wave no longer issues the four LDS-DMA pieces of its next hidden-state chunk in front of the barrier (where all
+//       eight waves queue on the CU's one vector-memory issue path at the same moment, ~140 ticks per piece, with the matrix pipe
+//       idle) but one piece behind every k-step's MFMAs of the chunk it is multiplying.
+template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false, bool HALF = false, bool IL = false>
 __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
                                                                      uint16_t *__restrict__ out, HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!HALF || (!FLAGS && !DEEPW), "HALF has its own ring plan");
+    static_assert(!IL || (!FLAGS && !PIPE && !HALF), "IL is built on the barrier form with the compiler's operand schedule");
     constexpr int kHeadWaves = HALF ? 4 : 8;                 // compute waves (shadows the namespace constants below)
     constexpr int kHeadBM = kHeadWaves * 32;
     constexpr int kHeadABytes = kHeadBM * kHeadBK * 2;
@@ -234,6 +238,16 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
         }
     };
     p_open();
+    int p_issued = 0;                                                        // chunks this wave has issued so far
+    auto produce_advance = [&]() {
+        ++p_issued;
+        p_slot = (p_slot + 1 == kRingA) ? 0 : p_slot + 1;
+        if (++p_chunk == n_chunks) {
+            p_chunk = 0;
+            p_tile += gridDim.x;
+            p_open();
+        }
+    };
     auto produce = [&]() -> bool {
         if (p_tile >= n_tiles) return false;
         char *dst = smem + p_slot * kHeadABytes + a_dst;
@@ -241,12 +255,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
 #pragma unroll
         for (int i = 0; i < 4; ++i)   // hidden states: streamed once -> nt
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, MSIM_LDS(dst + i * 1024), 16, a_src[i], soff, 0, 2);
-        p_slot = (p_slot + 1 == kRingA) ? 0 : p_slot + 1;
-        if (++p_chunk == n_chunks) {
-            p_chunk = 0;
-            p_tile += gridDim.x;
-            p_open();
-        }
+        produce_advance();
         return true;
     };
 #pragma unroll
@@ -259,14 +268,28 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
         f32x16 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (IL) {
+            if (tile != (int)blockIdx.x) produce();      // the chunk the previous tile's last iteration left out (see `feed`)
+        }
 
         for (int ch = 0; ch < n_chunks; ++ch, ++c_count) {
             // the slot consumed in the previous iteration is private to this wave and free again: refill it, then wait for
             // this chunk's 4 loads (the rows are this wave's own -- no barrier is involved in the A stream at all)
             const unsigned long long t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            const bool issued = produce();
+            bool issued = false;
+            if constexpr (IL) {
+                // chunks c_count + 1 .. c_count + kRingA - 2 may stay in flight (fewer at the very end of this wave's sequence)
+                const int ahead = p_issued - c_count - 1;
+                if (ahead >= kRingA - 2) wait_vmcnt<4 * (kRingA - 2)>();
+                else if (kRingA > 3 && ahead == 1) wait_vmcnt<4>();
+                else wait_vmcnt<0>();
+            } else {
+                issued = produce();
+            }
             const unsigned long long t1 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            if (issued) wait_vmcnt<4 * (kRingA - 1)>(); else wait_vmcnt<0>();
+            if constexpr (!IL) {
+                if (issued) wait_vmcnt<4 * (kRingA - 1)>(); else wait_vmcnt<0>();
+            }
             const unsigned long long t2 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             if constexpr (FLAGS) {
                 while (seen_ready <= c_count) {                    // weight chunk c_count not known to have landed: poll
@@ -307,6 +330,12 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
+                // wave-uniform: this wave still has chunks to fetch.  Not behind the last chunk of a tile: vmcnt counts the epilogue's
+                // stores too and retires in order, so loads issued in front of them could only be waited for together with them --
+                // that chunk is issued in one piece behind the epilogue instead (top of the tile loop)
+                const bool feed = IL && p_tile < n_tiles && ch != n_chunks - 1;
+                char *const pdst = smem + p_slot * kHeadABytes + a_dst;   // the slot read in the previous iteration
+                const int psoff = p_chunk * (kHeadBK * 2);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + a_rd[ks]);
@@ -316,6 +345,12 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
                         // A = hidden rows (-> accumulator rows), B = weight rows = output columns (-> lane column)
                         acc[j] = EPI2 ? mfma32<F16>(bf, af, acc[j]) : mfma32<F16>(af, bf, acc[j]);
                     }
+                    if constexpr (IL) {
+                        if (feed) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, MSIM_LDS(pdst + ks * 1024), 16, a_src[ks], psoff, 0, 2);
+                    }
+                }
+                if constexpr (IL) {
+                    if (feed) produce_advance();
                 }
             }
             if (tracing) {
