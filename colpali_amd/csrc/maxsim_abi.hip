@@ -192,7 +192,7 @@ int launch_batch(const FwdCall &c) {
     constexpr int wg_per_cu = 8 / NW;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
-    msim::BatchArgs a;
+    msim::BatchArgs a{};
     a.ld = c.ld;
     a.n_q = c.n_q;
     a.Lq = c.Lq;
@@ -202,7 +202,20 @@ int launch_batch(const FwdCall &c) {
     a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
     const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
-    const int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
+    int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
+    // Two workgroups share a CU in the 4-wave form, and the matrix pipe serves the OLDER wave first: of two workgroups that start
+    // together one finishes after ~2/3 of the launch and the other runs its last third alone, one wave per SIMD, which cannot fill
+    // the pipe (tools/trace_batch.py: workgroup 0 busy for 68 % of the launch; SQ_WAVE_CYCLES: 83 % occupancy).  With 8 x more, smaller
+    // ranges than resident workgroups a finished workgroup is replaced at once and the lone phase shrinks to the last range: +3-5 %
+    // at 9..16 queries (profiles/r02_logs/ab_batch_over.log; the pair form, 5..8 queries, does not gain and keeps one range per
+    // resident workgroup).  Only when one query block streams the corpus (no L2 sharing between blocks to preserve), and never down
+    // to ranges of fewer than ~16 documents.
+    static const int over_env = getenv("MSIM_BATCH_OVER") ? atoi(getenv("MSIM_BATCH_OVER")) : (NW == 4 ? 8 : 1);    // A/B knob
+    if (NW < 8 && a.n_qblocks == 1 && over_env > 1) {
+        int over = over_env;
+        while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
+        sub *= over;
+    }
     a.n_ranges = 8 * sub;
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
     // convoy (maxsim_batch.hip): only when several query blocks share a range AND all of them are resident at once
@@ -619,7 +632,7 @@ int launch_batch_panels(const FwdCall &c) {
     constexpr int lds = msim::kPanelStages * kPanels320 * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
-    msim::BatchArgs a;
+    msim::BatchArgs a{};
     a.ld = c.ld;
     a.n_q = c.n_q;
     a.Lq = c.Lq;
