@@ -1205,7 +1205,8 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
     if (!X || !sink) return fail(MSIM_EINVAL, "null pointer argument");
     if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
     if (rows < 256LL * 8 * 5 * 32) return fail(MSIM_EINVAL, "the MFMA probe needs at least %d rows of operands", 256 * 8 * 5 * 32);
-    if (iters <= 0 || variant < 0 || variant > 7) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
+    if (variant >= 8 && rows < 256LL * 16 * 3 * 32) return fail(MSIM_EINVAL, "MFMA probe variants 8..11 need at least %d rows of operands", 256 * 16 * 3 * 32);
+    if (iters <= 0 || variant < 0 || variant > 11) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X);
     int rc;
@@ -1217,6 +1218,11 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
         case 5: rc = run_probe_mfma16<true, false>(x, iters, sink, st); break;    // + A fragments from LDS
         case 6: rc = run_probe_mfma16<false, true>(x, iters, sink, st); break;    // + max folds
         case 7: rc = run_probe_mfma16<true, true>(x, iters, sink, st); break;     // K1s / K1b's instruction mix
+        // the same mix with three / four waves per SIMD (FLOP = 256 x 12 x iters x 48 x 16384 resp. 256 x 16 x iters x 32 x 16384)
+        case 8: rc = run_probe_mfma16w<3, 12, true, true>(x, iters, sink, st); break;
+        case 9: rc = run_probe_mfma16w<2, 16, true, true>(x, iters, sink, st); break;
+        case 10: rc = run_probe_mfma16w<3, 12, false, false>(x, iters, sink, st); break;
+        case 11: rc = run_probe_mfma16w<2, 16, false, false>(x, iters, sink, st); break;
         default: rc = run_probe_mfma<true, true>(x, iters, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_mfma_kernel launch failed (variant %d)", variant);

@@ -81,12 +81,14 @@ __global__ __launch_bounds__(512, 2) void probe_mfma_kernel(const uint16_t *__re
 // iteration = the FLOP of the kernel above.  This is the tile shape K1s / K1b use (maxsim_common.hpp); with LDSA + FOLD it is their
 // instruction mix: one ds_read_b128 per 8 MFMAs, 8 v_max3 per 16.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-template <int NT, bool LDSA, bool FOLD>
-__global__ __launch_bounds__(512, 2) void probe_mfma16_kernel(const uint16_t *__restrict__ X, int iters, float *__restrict__ sink) {
+// WAVES: waves per workgroup (8 = two per SIMD like K1b; 12 / 16 = three / four per SIMD with NT = 3 / 2 tiles each: does a third
+// instruction stream per SIMD fill the bubbles two streams leave?)
+template <int NT, bool LDSA, bool FOLD, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe_mfma16_kernel(const uint16_t *__restrict__ X, int iters, float *__restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t base = ((size_t)blockIdx.x * 8 + wave) * (NT + 1) * kTokTile;
+    const size_t base = ((size_t)blockIdx.x * WAVES + wave) * (NT + 1) * kTokTile;
     bf16x8 qf[NT][kKSteps];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -158,6 +160,17 @@ template <bool LDSA, bool FOLD>
 int run_probe_mfma16(const uint16_t *x, int iters, float *sink, hipStream_t st) {
     auto kern = msim::probe_mfma16_kernel<4, LDSA, FOLD>;
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), 8 * msim::kSlabBytes, st, x, iters, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+template <int NT, int WAVES, bool LDSA, bool FOLD>
+int run_probe_mfma16w(const uint16_t *x, int iters, float *sink, hipStream_t st) {
+    auto kern = msim::probe_mfma16_kernel<NT, LDSA, FOLD, WAVES>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * msim::kSlabBytes) != hipSuccess) return -3;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), WAVES * msim::kSlabBytes, st, x, iters, sink);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 template <bool LDSA, bool FOLD>

@@ -8,7 +8,7 @@ import bench, colpali_amd as amd
 
 dev = torch.device("cuda:0")
 L = amd._lib.lib()
-rows = 256 * 8 * 5 * 32
+rows = 256 * 16 * 4 * 32
 g = torch.Generator(device=dev).manual_seed(1)
 X = torch.nn.functional.normalize(torch.randn((rows, 128), generator=g, device=dev), dim=-1).to(torch.bfloat16)
 Z = torch.zeros_like(X)
@@ -17,8 +17,9 @@ st = torch.cuda.current_stream()
 for data, name in ((X, "random unit rows"), (Z, "zeros")):
     for variant, what in ((0, "A in registers"), (1, "A from LDS"), (2, "A in registers + max folds"), (3, "A from LDS + max folds"),
                           (4, "16x16x32 tiles, registers"), (5, "16x16x32, A from LDS"), (6, "16x16x32, registers + folds"),
-                          (7, "16x16x32, A from LDS + folds")):
-        for iters in (2000, 20000):
+                          (7, "16x16x32, A from LDS + folds"), (8, "mix, 12 waves x 3 tiles"), (9, "mix, 16 waves x 2 tiles"),
+                          (10, "registers, 12 waves x 3"), (11, "registers, 16 waves x 2"))[int(os.environ.get("PROBE_FROM", "0")):]:
+        for iters in (20000,):
             ms = []
             for i in range(5):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,5 +31,5 @@ for data, name in ((X, "random unit rows"), (Z, "zeros")):
                 if i >= 1:
                     ms.append(a.elapsed_time(b))
             t = sorted(ms)[len(ms) // 2]
-            flop = 256 * 8 * iters * 32 * 32768
+            flop = 256 * 8 * iters * 32 * 32768 if variant < 8 else 256 * 12 * iters * 48 * 16384 if variant in (8, 10) else 256 * 16 * iters * 32 * 16384
             print(f"{name:18s} variant {variant} ({what:28s}) iters {iters:6d}: {t:8.3f} ms  {flop / t / 1e9:7.0f} TFLOP/s = {flop / t / 1e9 / 2500:.3f} of 2.5 PF", flush=True)
