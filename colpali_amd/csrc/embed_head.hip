@@ -186,7 +186,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
         }
         if (total > 0) load_w(0);
         unsigned long long tr_vm = 0, tr_bar = 0, tr_issue = 0;
-        const bool tracing = a.trace != nullptr && blockIdx.x == 0;
+        const bool tracing = kTraceBuild && a.trace != nullptr && blockIdx.x == 0;
         for (int c = 0; c < total; ++c) {
             const unsigned long long t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             wait_vmcnt<0>();                 // W chunk c has landed
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
 
     int c_slot = 0, c_count = 0, w_slot = 0, seen_ready = 0;
     unsigned long long tr_issue = 0, tr_vm = 0, tr_bar = 0, tr_comp = 0, tr_epi = 0;
-    const bool tracing = !FLAGS && a.trace != nullptr && blockIdx.x == 0;
+    const bool tracing = kTraceBuild && !FLAGS && a.trace != nullptr && blockIdx.x == 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         f32x16 acc[4];
 #pragma unroll

@@ -227,8 +227,6 @@ int launch_batch(const FwdCall &c) {
         if (hipMemsetAsync(a.convoy, 0, (size_t)a.n_ranges * a.n_qblocks * sizeof(int), c.st) != hipSuccess)
             return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
     }
-    static const int tune = getenv("MSIM_BATCH_TUNE") ? atoi(getenv("MSIM_BATCH_TUNE")) : 2;   // A/B knob, see BatchArgs
-    a.tune = tune;
     a.trace = nullptr;
     if (const char *tp = getenv("MSIM_BATCH_TRACE_PTR"))     // debug knob: device address of 8 x 8 uint64 (tools/trace_batch.py)
         a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));

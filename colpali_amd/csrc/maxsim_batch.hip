@@ -45,13 +45,6 @@ struct BatchArgs {
     int n_ranges;        // document ranges (multiple of 8: XCD x owns ranges x*sub .. x*sub+sub-1)
     unsigned flags;
     int *convoy;         // [n_ranges, n_qblocks] progress counters (zeroed before the launch) or null: see the convoy below
-    int tune;            // MSIM_BATCH_TUNE (A/B knob, 8-wave form): bit 0 = issue priority alternates between the two waves of a SIMD
-                         // slab by slab (+0.5..1 %); bit 1 (the default) = waves 0..3 refill the ring for the whole workgroup
-                         // BEHIND their slabs.  The s_memtime trace (tools/trace_batch.py) shows the two waves of a SIMD leaving the
-                         // chunk barrier together, the older one (waves 0..3) winning the matrix pipe and reaching the next
-                         // barrier ~3000 of ~10300 cycles early, while waves 4..7 spend 460 cycles of their critical path in the
-                         // vector-memory issue queue before their first MFMA: with bit 1 the DMA issue happens in that slack
-                         // (+2.4..3 % at 32..256 queries, profiles/r02_logs/ab_batch_tune.log)
     unsigned long long *trace;   // debug (MSIM_BATCH_TRACE_PTR): per wave of workgroup 0, s_memtime ticks per phase of the chunk loop; null in production
 };
 
@@ -170,25 +163,13 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     };
     p_open();
     int p_slot = 0;
-    const bool feed_all = NW == 8 && (a.tune & 2);          // waves 0..3 also issue the share of waves 4..7 (which issue nothing)
-    const int mate_lds_off = ((wave + 4) >> 1) * kSlabBytes + ((wave + 4) & 1) * 4096;
-    const int mate_row_off = ((wave + 4) >> 1) * kSlabRows + ((wave + 4) & 1) * 16;
     auto produce = [&]() -> bool {
         if (p_idx >= d_hi) return false;
-        if (!(feed_all && wave >= 4)) {
-            char *dst = smem + p_slot * kChunkBytes + my_lds_off;
-            const int soff = (p_row + my_row_off) * kRowBytes;   // rows past the document end read as zeros (bounds check)
+        char *dst = smem + p_slot * kChunkBytes + my_lds_off;
+        const int soff = (p_row + my_row_off) * kRowBytes;   // rows past the document end read as zeros (bounds check)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, AUX);
-            if (feed_all) {
-                char *dst2 = smem + p_slot * kChunkBytes + mate_lds_off;
-                const int soff2 = (p_row + mate_row_off) * kRowBytes;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst2 + j * 1024), 16, src_off[j], soff2 + j * 1024, 0, AUX);
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, AUX);
         p_slot = (p_slot + 1 == kBatchRing) ? 0 : p_slot + 1;
         p_row += kChunkRows;
         if (p_row >= p_len) {
@@ -203,7 +184,9 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
 
     const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
     int c_slot = 0;
-    const bool tracing = a.trace != nullptr && blockIdx.x == 0;
+    // MSIM_TRACE builds only (make trace -> tools/_ab/libmaxsim_trace.so): even a never-taken tracing branch in the chunk loop costs
+    // the product kernel ~5 % (registers and schedule), so the stamps are compiled out of the shipped library
+    const bool tracing = kTraceBuild && a.trace != nullptr && blockIdx.x == 0;
     unsigned long long tr[7] = {0, 0, 0, 0, 0, 0, 0};     // vmcnt, convoy, barrier, DMA issue, slabs, document epilogue, chunks
 
     // the walk over [d_lo, d_hi) for a wave that holds NT token tiles (NT = 0: it only feeds the ring and keeps the barriers)
@@ -244,9 +227,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         for (int ch = 0; ch < nchunk; ++ch) {
             const unsigned long long t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             // my share of chunk `ch` has landed once at most (ring-2) later chunks of mine are still in flight
-            if (p_idx < d_hi) {
-                if (feed_all) wait_vmcnt<8 * (kBatchRing - 2)>(); else wait_vmcnt<4 * (kBatchRing - 2)>();
-            } else wait_vmcnt<0>();
+            if (p_idx < d_hi) wait_vmcnt<4 * (kBatchRing - 2)>(); else wait_vmcnt<0>();
             const unsigned long long t1 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             if (convoy_on && wave == 0 && (g_chunk & (kConvoyEvery - 1)) == 0) {
                 if (lane == 0) __hip_atomic_store(my_prog + qblock, g_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -264,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             const unsigned long long t2 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done reading the previous chunk
             const unsigned long long t3 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            if (!feed_all) produce();       // refill the buffer that was read in the previous iteration
+            produce();                      // refill the buffer that was read in the previous iteration
             const unsigned long long t4 = tracing ? __builtin_amdgcn_s_memtime() : 0;
 
             const int cbuf = c_slot * kChunkBytes;
@@ -273,16 +254,10 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             if constexpr (wave_has_queries) {
                 const int n_full = rows_in_chunk >= kChunkRows ? kChunkSlabs : rows_in_chunk / kSlabRows;
 #pragma unroll 1
-                for (int sl = 0; sl < n_full; ++sl) {
-                    if (NW == 8 && (a.tune & 1)) {
-                        if (((sl ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-                    }
-                    slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
-                }
+                for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
                 const int rem = rows_in_chunk - n_full * kSlabRows;
                 if (n_full < kChunkSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem);
             }
-            if (feed_all) produce();        // (waves 4..7: bookkeeping only)
             if (tracing) {
                 if constexpr (wave_has_queries) {   // the MFMAs have been issued, not retired: the running maxima must be readable
                     float sink = 0.f;

@@ -5,6 +5,13 @@
 
 namespace msim {
 
+// s_memtime phase traces inside K1b / K3 (tools/trace_batch.py, tools/trace_head.py) exist only in `make trace` builds
+#ifdef MSIM_TRACE
+constexpr bool kTraceBuild = true;
+#else
+constexpr bool kTraceBuild = false;
+#endif
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator fragment
 typedef __attribute__((ext_vector_type(4))) int i32x4;

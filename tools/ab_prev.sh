@@ -7,6 +7,9 @@ export AB_DOCS=${AB_DOCS:-65536}
 SIZES=${AB_SIZES:-8,12,16,24,32,64,256}
 run() { AB_TAG="$1" python tools/ab_variant.py "$SIZES" 2>&1 | grep -v amdgpu.ids; }
 COLPALI_AMD_LIB=tools/_ab/libmaxsim_prev.so AB_REF=write run "previous build"
-AB_REF=check run "this build"
-COLPALI_AMD_LIB=tools/_ab/libmaxsim_prev.so AB_REF=check run "previous build"
-AB_REF=check run "this build"
+export AB_REF=check
+for r in 1 2; do
+  run "this build"
+  if [ -n "${AB_THIS_ENV:-}" ]; then env $AB_THIS_ENV bash -c "AB_TAG='this build, $AB_THIS_ENV' python tools/ab_variant.py $SIZES 2>&1 | grep -v amdgpu.ids"; fi
+  COLPALI_AMD_LIB=tools/_ab/libmaxsim_prev.so run "previous build"
+done

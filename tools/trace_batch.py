@@ -5,6 +5,7 @@ slabs (operand reads + MFMAs + folds of the chunk), document epilogue."""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
+os.environ.setdefault("COLPALI_AMD_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ab", "libmaxsim_trace.so"))   # `make -C colpali_amd/csrc trace`
 dev = torch.device("cuda:0")
 trace = torch.zeros(8 * 8, dtype=torch.int64, device=dev)
 os.environ["MSIM_BATCH_TRACE_PTR"] = str(trace.data_ptr())

@@ -7,6 +7,7 @@ one), compute (20 operand reads + 16 MFMAs, stamped after the accumulators are r
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
+os.environ.setdefault("COLPALI_AMD_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ab", "libmaxsim_trace.so"))   # `make -C colpali_amd/csrc trace`
 dev = torch.device("cuda:0")
 trace = torch.zeros(9 * 8, dtype=torch.int64, device=dev)
 os.environ["MSIM_HEAD_TRACE_PTR"] = str(trace.data_ptr())
