@@ -493,3 +493,39 @@ def test_loss_is_fp32_under_autocast_like_the_reference(amd):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             assert getattr(amd, cls)()(Q, D).dtype == torch.float32
         assert getattr(amd, cls)()(Q, D).dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("cls,kind", [("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_symmetric_loss_documents_in_the_query_slot(amd, cls, kind, dtype):
+    """trainer/contrastive_trainer.py:201-205 (`compute_symetric_loss`): the second term is
+    `_compute_loss_from_outputs(doc_outputs, query_outputs)` -- the loss called with the PAGES as `query_embeddings`
+    ([B, 780, 128]: 25 token tiles per "query", beyond the tuned kernels' 4) and the queries as `doc_embeddings`
+    ([B, 32, 128]).  Same oracle, same tolerances as the forward direction."""
+    Q, D = _config5_inputs(0, seed=7)
+    B = 12
+    pages, queries = D[:B].to(dtype), Q[:B].to(dtype)
+    for kw in (dict(), dict(normalize_scores=False)):
+        want_loss, want_dp, want_dq = lo.loss_and_grads(kind, pages.float(), queries.float(), offset=0, **kw)
+        p_real = (pages.float().abs().sum(-1, keepdim=True) > 0)
+        q_real = (queries.float().abs().sum(-1, keepdim=True) > 0)
+        p, q = pages.cuda().requires_grad_(True), queries.cuda().requires_grad_(True)
+        loss = getattr(amd, cls)(**kw)(query_embeddings=p, doc_embeddings=q, offset=0)
+        assert loss.dtype == dtype and loss.dim() == 0
+        loss.backward()
+        if dtype == torch.float32:
+            assert abs(float(loss.detach()) - float(want_loss)) <= 1e-5 * abs(float(want_loss)) + 1e-6, kw
+            for got, want, mask in ((p.grad, want_dp, p_real), (q.grad, want_dq, q_real)):
+                if kind == "infonce" and kw:
+                    # un-normalised scores of 780-token "queries" (~300) over T = 0.02: logits of ~15 000, so one fp32 ulp of a score
+                    # moves a logit by 1.5e-3 and the softmax gradient with it -- ill-conditioned in fp32 for the reference too;
+                    # compare in norm instead of element by element
+                    diff = ((got.cpu().double() - want) * mask).norm() / (want * mask).norm()
+                    assert float(diff) < 5e-3, (kw, float(diff))
+                    continue
+                bad = ((got.cpu().double() - want).abs() > 1e-4 * want.abs() + 1e-6) & mask.expand_as(want)
+                assert int(bad.sum()) == 0, kw
+        else:
+            assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6, kw
+            assert grads_close(p.grad, want_dp, p_real.expand_as(want_dp)), kw
+            assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq)), kw
