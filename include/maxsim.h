@@ -269,6 +269,9 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
  *   variant bit 1: the 16 -> 1 max fold of every accumulator tile runs next to the MFMAs
  *   variants 4..7: the same four mixes on v_mfma_f32_16x16x32_bf16, the tile shape msim_fwd's kernels use (variant - 4 = the bits
  *   above): 7 = their instruction mix (A fragments from LDS + max folds), 4 = MFMAs alone
+ *   variants 8..11 (rows >= 256 * 16 * 3 * 32 = 393 216): the 16x16x32 mix with MORE waves per SIMD -- 8: 12 waves x 3 tiles, 9: 16 waves x
+ *   2 tiles (both A from LDS + folds), 10 / 11: the same two shapes with everything in registers.  FLOP = 256 x 12 x iters x 48 x 16384
+ *   (8, 10) resp. 256 x 16 x iters x 32 x 16384 (9, 11).
  */
 int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *sink, void *stream);
 
