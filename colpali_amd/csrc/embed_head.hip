@@ -91,7 +91,16 @@ struct HeadArgs {
 // IL:   a compute wave no longer issues the four LDS-DMA pieces of its next hidden-state chunk in front of the barrier (where all
 //       eight waves queue on the CU's one vector-memory issue path at the same moment, ~140 ticks per piece, with the matrix pipe
 //       idle) but one piece behind every k-step's MFMAs of the chunk it is multiplying.
-template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false, bool HALF = false, bool IL = false>
+// EPI3: the output rows leave through LDS, as whole rows, with the `nt` (streaming) policy.  Knock-outs (profiles/r02_logs/
+//       ab_head_epilogue.log): without its output stores the kernel ran 17-25 % faster although the output is 6-8 % of the bytes; the
+//       arithmetic of the epilogue (64 divisions, 16 butterflies) is worth 5-7 %.  The first form stores one 2-byte element per lane and
+//       instruction (64 store instructions per lane and tile, two 64-byte pieces each).  Here a wave writes 16 finished rows (bf16) into
+//       the hidden-state slot it has just consumed (4 KiB, private, free until the next refill), reads them back as 16 bytes per lane and
+//       stores whole 256-byte rows: 8 store instructions per lane and tile, full 128-byte lines.  That alone changed nothing; what the
+//       stores cost is their way through L2 / MALL next to the streaming reads: with `nt` on them +4 % (H = 2048), +8-12 % (1536),
+//       +13-14 % (3584) -- and the whole-row form gains 2-4 % more than the 2-byte form under the same policy.
+template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false, bool HALF = false, bool IL = false,
+          bool EPI3 = false>
 __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
@@ -100,6 +109,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!HALF || (!FLAGS && !DEEPW), "HALF has its own ring plan");
     static_assert(!IL || (!FLAGS && !PIPE && !HALF), "IL is built on the barrier form with the compiler's operand schedule");
+    static_assert(!EPI3 || (!FLAGS && !EPI2 && !HALF && !IL), "EPI3 stages through the slot the barrier form refills at the top of the next chunk");
     constexpr int kHeadWaves = HALF ? 4 : 8;                 // compute waves (shadows the namespace constants below)
     constexpr int kHeadBM = kHeadWaves * 32;
     constexpr int kHeadABytes = kHeadBM * kHeadBK * 2;
@@ -439,6 +449,46 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
                 acc[j][r] = y;
                 ss[r] = j == 0 ? y * y : ss[r] + y * y;
             }
+        if constexpr (EPI3) {
+            // the slot consumed last: private to this wave (its own 32 rows x 128 B) and not refilled before the next produce()
+            char *const stage = smem + (c_slot == 0 ? kRingA - 1 : c_slot - 1) * kHeadABytes + a_dst;
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                         // rows 16p .. 16p+15 of this wave's 32 = accumulator registers 8p .. 8p+7
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * p + rr;
+                    const float nrm = round_to_input<F16>(sqrtf(half_wave_sum(ss[r])));
+                    const int v_lo = rm[acc_row(r, 0)], v_hi = rm[acc_row(r, 32)];   // compile-time offsets, scalar loads
+                    const bool zero = (half ? v_hi : v_lo) < -1;
+                    // staged row = acc_row(r, lane) - 16p = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half; bit 2 of it is `half`: XOR-ing the
+                    // byte offset inside the row with half << 7 keeps the two halves of a write on different banks
+                    char *const row = stage + ((rr & 3) + 8 * ((rr >> 2) & 1) + 4 * half) * 256;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o = round_to_input<F16>(acc[j][r] / nrm);
+                        if (zero) o *= 0.0f;   // `proj * attention_mask`: +-0 (sign kept), NaN stays NaN -- what torch's multiply yields
+                        uint16_t bits;
+                        if constexpr (F16) bits = __builtin_bit_cast(uint16_t, (_Float16)o);
+                        else bits = (uint16_t)(__float_as_uint(o) >> 16);
+                        *reinterpret_cast<uint16_t *>(row + ((64 * j + 2 * l31) ^ (half << 7))) = bits;
+                    }
+                }
+                // read back: instruction i covers staged rows 4i .. 4i+3, lane -> (row 4i + (lane >> 4), 16-byte piece lane & 15)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rl = 4 * i + (lane >> 4);
+                    const u32x4_t val = *reinterpret_cast<const u32x4_t *>(stage + rl * 256 + ((((lane & 15) << 4)) ^ ((i & 1) << 7)));
+                    const int v0 = rm[16 * p + 4 * i], v1 = rm[16 * p + 4 * i + 1], v2 = rm[16 * p + 4 * i + 2], v3 = rm[16 * p + 4 * i + 3];
+                    const int sel = lane >> 4;
+                    const int v = sel == 0 ? v0 : sel == 1 ? v1 : sel == 2 ? v2 : v3;
+                    if (v != -1)
+                        __builtin_nontemporal_store(val, reinterpret_cast<u32x4_t *>(out + (size_t)(v < 0 ? -2 - v : v) * a.ld_out + ((lane & 15) << 3)));
+                }
+            }
+            if (tracing) tr_epi += __builtin_amdgcn_s_memtime() - te0;
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float nrm = round_to_input<F16>(sqrtf(half_wave_sum(ss[r])));
@@ -454,7 +504,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
                 uint16_t bits;
                 if constexpr (F16) bits = __builtin_bit_cast(uint16_t, (_Float16)o);
                 else bits = (uint16_t)(__float_as_uint(o) >> 16);
-                dst[j * 32] = bits;
+                __builtin_nontemporal_store(bits, dst + j * 32);   // streaming policy: see EPI3
             }
         }
         if (tracing) tr_epi += __builtin_amdgcn_s_memtime() - te0;

@@ -1010,15 +1010,22 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     };
     static std::atomic<int> configured[12][kMaxDevices];
     // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
-    // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (the default): loader two weight chunks ahead, rings 3 + 3; bit 4: two half-size workgroups per CU; bit 5: DMA pieces between the MFMAs
+    // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (default): loader two weight chunks ahead, rings 3 + 3; bit 4: two half-size workgroups per CU; bit 5: DMA pieces between the
+    // MFMAs; bit 6 (default): whole-row output stores through LDS
     // (tuning knob for A/B measurements, not part of the ABI; profiles/r02_logs/ab_head_variants.log)
-    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 63 : 8;
+    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 127 : 72;
     int rc;
     const bool f16 = dtype == MSIM_DTYPE_F16;
     const bool epi2 = (variant & 4) && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                       (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0);   // 8-byte stores, 4-byte bias loads
     // bit 3: loader two weight chunks ahead (rings 3 + 3)
-    if (variant & 32) {           // bit 5: hidden-state DMA pieces issued between the k-steps' MFMAs (+ bit 3 rings, + bit 2 epilogue)
+    // bit 6 (default): output rows staged through LDS and stored as whole rows; needs 16-byte aligned rows, else the 2-byte form
+    const bool epi3 = (variant & 64) && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (epi3) {
+        static std::atomic<int> configured5[2][kMaxDevices];
+        rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, false, true>, configured5[0], msim::kHeadFLds)
+                 : go(msim::embed_head_kernel<false, false, false, false, true, false, false, true>, configured5[1], msim::kHeadFLds);
+    } else if (variant & 32) {           // bit 5: hidden-state DMA pieces issued between the k-steps' MFMAs (+ bit 3 rings, + bit 2 epilogue)
         static std::atomic<int> configured4[6][kMaxDevices];
         if ((variant & 8) && (variant & 4) && epi2)
             rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true, false, true>, configured4[0], msim::kHeadFLds)
