@@ -213,7 +213,12 @@ def dropin_numbers(amd):
 def embed_head_numbers(amd, dev):
     """SURVEY 8(f) N1, the step before the path: hidden states of 500 ColPali pages (1030 x 2048 bf16, 2.1 GB) ->
     projection + L2 norm + mask, written as the scorer's corpus rows.  HBM-bound (128 FLOP per streamed byte)."""
-    B, S, H = 500, 1030, 2048
+    out = _embed_head_shape(amd, dev, 500, 1030, 2048)                      # BASELINE config 2: ColPali (PaliGemma-3B, hidden 2048)
+    out["colqwen2_1000x779x1536"] = _embed_head_shape(amd, dev, 1000, 779, 1536)   # config 3: ColQwen2 (Qwen2-VL-2B, hidden 1536)
+    return out
+
+
+def _embed_head_shape(amd, dev, B, S, H):
     g = torch.Generator(device=dev).manual_seed(3)
     hidden = torch.randn((B, S, H), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
     weight = (torch.randn((128, H), generator=g, device=dev) / H**0.5).to(torch.bfloat16)
