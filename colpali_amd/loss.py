@@ -8,11 +8,14 @@ interchangeable).  The MaxSim core every one of them starts with,
 
     raw = einsum("bnd,csd->bcns", Q, D); scores = raw.amax(dim=3).sum(dim=2)      (:297-298, :91)
 
-runs in the fused gfx950 kernels (no [B,C,Lq,Ld] tensor is materialised, forward or backward);
-the [B, C]-sized epilogues (normalisation, filtering, diagonal/topk/softplus, :300-313) are a
-handful of tiny torch ops on the GPU and go through torch autograd.  The backward recomputes the
-per-token arg-max only for the (query, doc) pairs whose upstream gradient is non-zero -- two per
-query for the pairwise loss -- instead of keeping the similarity tensor alive.
+runs in the fused gfx950 kernels (no [B,C,Lq,Ld] tensor is materialised, forward or backward).
+For the two in-batch losses (`ColbertPairwiseCELoss`, `ColbertLoss`) the [B, C]-sized epilogue
+(lengths, normalisation, filtering, diagonal / topk(2) / where / softplus resp. cross entropy,
+:296, :300-313, :164) AND its gradient are one more launch (msim_loss_epilogue): a training step
+has no host synchronisation and captures as one hipGraph.  The backward recomputes the per-token
+arg-max only for the (query, doc) pairs that carry a gradient -- the two per query the epilogue
+emits for the pairwise loss -- instead of keeping the similarity tensor alive.  The sigmoid and
+explicit-negative losses keep their (tiny) epilogues in torch on top of the same fused cores.
 """
 from __future__ import annotations
 
