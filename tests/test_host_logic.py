@@ -285,3 +285,19 @@ def test_native_host_gather_copies_every_buffer_to_its_offset():
                 assert dst[o + b.size] == 0xEE
     assert L.msim_host_gather(dst.ctypes.data, None, offs.ctypes.data, sizes.ctypes.data, len(bufs), 4) == -1
     assert L.msim_host_gather(dst.ctypes.data, srcs.ctypes.data, offs.ctypes.data, sizes.ctypes.data, 0, 4) == 0
+
+
+def test_measurement_tools_parse():
+    """tools/*.py and tools/*.sh are the scripts behind every log under profiles/: they must at least parse."""
+    import ast
+    import glob
+    import subprocess
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools")
+    scripts = sorted(glob.glob(os.path.join(root, "*.py")))
+    assert scripts
+    for path in scripts:
+        with open(path) as f:
+            ast.parse(f.read(), filename=path)
+    for path in sorted(glob.glob(os.path.join(root, "*.sh"))):
+        assert subprocess.run(["bash", "-n", path]).returncode == 0, path
