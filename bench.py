@@ -51,7 +51,7 @@ def parse_args():
                          "BASELINE config 4 over 8 GPUs")
     ap.add_argument("--doc-len", type=int, default=1024)
     ap.add_argument("--nq", type=int, default=4, help="queries per step (32 tokens each); 4 = BASELINE config 1's query batch")
-    ap.add_argument("--regimes", type=str, default="1,8,16,32,1000",
+    ap.add_argument("--regimes", type=str, default="1,6,8,10,12,16,32,1000",
                     help="other query-batch sizes measured after the headline and reported under 'regimes' ('' = none)")
     ap.add_argument("--q-len", type=int, default=32)
     ap.add_argument("--topk", type=int, default=10)
@@ -334,6 +334,54 @@ def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
         dt = float(t.item())
     kern_ms = [a.elapsed_time(b) for a, b in evs]
     return dt, kern_ms, scores, top
+
+
+def forced_collective_numbers(amd, q, corpus, topk, dev, steps=5):
+    """The multi-GPU merge path on the ONE GPU this run has: a 1-rank `nccl` (= RCCL) process group, and the step of
+    run_regime() with shard_topk(..., force_collective=True) -- message packing, all_gather_into_tensor on the uint8
+    message, strided-view merge -- checked against the non-collective result.  Context only, never `value`."""
+    import socket
+
+    import torch.distributed as dist
+
+    created = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            created = True
+        scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=dev)
+
+        def step(force):
+            amd.maxsim_scores(q, corpus, out=scores)
+            return amd.shard_topk(scores, topk, corpus.id_base, 1, dist, force_collective=force)
+
+        plain = step(False)
+        forced = step(True)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(plain[0], forced[0]) and torch.equal(plain[1], forced[1]))
+        times = {}
+        for force in (False, True):
+            step(force)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(force)
+            torch.cuda.synchronize()
+            times[force] = (time.perf_counter() - t0) / steps * 1e3
+        return {"what": "1-rank nccl (RCCL) group on this GPU: per-shard top-k written into the 12 B/candidate message, "
+                        "all_gather_into_tensor, merge on strided views of the gathered bytes",
+                "backend": dist.get_backend(), "world": dist.get_world_size(), "ids_and_scores_equal_to_non_collective": same,
+                "ms_per_step_non_collective": times[False], "ms_per_step_forced_collective": times[True]}
+    except Exception as e:  # context only: never take the bench line down
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def pmc_traffic(n_q, n_docs, doc_len):
@@ -620,6 +668,8 @@ def main():
         if rank == 0:
             out["topk_parity"] = par
             out["parity_max_rel_err_vs_oracle_sample"] = par["max_rel_err"]
+    if world == 1 and os.environ.get("BENCH_FORCE_COLLECTIVE", "1") != "0":
+        out["forced_collective_1rank"] = forced_collective_numbers(amd, q, corpus, args.topk, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
         out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)

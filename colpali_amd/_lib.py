@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLPALI_AMD_LIB") or os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def dtype_code(dtype) -> int:
@@ -82,6 +82,8 @@ def lib() -> ctypes.CDLL:
     L.msim_smooth_pairs_bwd.restype = i32
     L.msim_embed_head.argtypes = [i32, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp]
     L.msim_embed_head.restype = i32
+    L.msim_embed_head_bwd.argtypes = [i32, vp, vp, vp, i64, i32, vp, vp]
+    L.msim_embed_head_bwd.restype = i32
     L.msim_sim_matrix.argtypes = [i32, vp, i32, vp, i32, i32, vp, i64, u32, vp]
     L.msim_sim_matrix.restype = i32
     L.msim_pool_cluster.argtypes = [i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]

@@ -515,4 +515,54 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the norm / mask tail (training: modeling_colpali.py:65-78 sits inside the training graph).  What autograd derives for
+//     proj = proj / proj.norm(dim=-1, keepdim=True);  proj = proj * mask
+// with respect to the Linear output, written out:   dproj = mask * (g - y <g, y>) / n,   y = proj / n,   n = round(||proj||)
+// (n rounded to the model dtype as Tensor.norm returns it; everything else in fp32, ONE rounding of the result -- the reference's
+// autograd rounds five intermediates to the model dtype, so this is closer to the exact gradient than the reference is).
+// One row per 16 lanes (16-byte pieces), HBM-bound: 2 x 256 B read + 256 B written per row.  The two GEMMs on either side of it
+// (recomputing proj, and dX = dproj W, dW = dproj^T X) are plain library GEMMs on the host side (colpali_amd/embed.py).
+template <bool F16>
+__global__ __launch_bounds__(256) void embed_head_bwd_rows_kernel(const uint16_t *__restrict__ proj, const uint16_t *__restrict__ g,
+                                                               const int32_t *__restrict__ row_map, long long M,
+                                                               uint16_t *__restrict__ dproj) {
+    const int l16 = threadIdx.x & 15;
+    const long long rows_per_pass = (long long)gridDim.x * 16;
+    for (long long m = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += rows_per_pass) {
+        const bf16x8 pv = *reinterpret_cast<const bf16x8 *>(proj + m * kHeadN + l16 * 8);
+        const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(g + m * kHeadN + l16 * 8);
+        const bool keep = row_map[m] >= 0;
+        float p[8], gg[8], ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            p[i] = elem_to_float<F16>((uint16_t)pv[i]);
+            gg[i] = elem_to_float<F16>((uint16_t)gv[i]);
+            ss += p[i] * p[i];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float n = round_to_input<F16>(sqrtf(ss));
+        const float inv = 1.0f / n;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            p[i] *= inv;
+            dot += gg[i] * p[i];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        bf16x8 ov;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = keep ? (gg[i] - p[i] * dot) * inv : 0.0f;
+            uint16_t bits;
+            if constexpr (F16) bits = __builtin_bit_cast(uint16_t, (_Float16)d);
+            else bits = __builtin_bit_cast(uint16_t, (__bf16)d);
+            ov[i] = (short)bits;
+        }
+        *reinterpret_cast<bf16x8 *>(dproj + m * kHeadN + l16 * 8) = ov;
+    }
+}
+
 }  // namespace msim

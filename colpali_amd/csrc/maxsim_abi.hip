@@ -15,6 +15,9 @@
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
+#ifdef MSIM_AB
+#include "maxsim_batch8.hip"   // K1b8: measured, not shipped (make ab; profiles/r03_logs/ab_batch8*.log)
+#endif
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
 #include "maxsim_bwd.hip"
@@ -236,6 +239,50 @@ int launch_batch(const FwdCall &c) {
     return MSIM_OK;
 }
 
+#ifdef MSIM_AB
+// K1b8 (maxsim_batch8.hip): one 512-register wave per SIMD, up to 8 token tiles per wave, NW waves per document stream
+template <int TPQ, bool F16, int NW, int RING, int AUX, int VAR = 0>
+int launch_batch8(const FwdCall &c) {
+    auto kern = msim::maxsim_batch8_kernel<TPQ, F16, NW, RING, AUX, VAR>;
+    constexpr int lds = RING * NW * msim::kSlabBytes;               // 96 KiB (4 waves, ring 3) / 64 KiB (2 waves, ring 4)
+    constexpr int wg_per_cu = 4 / NW;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    msim::BatchArgs a{};
+    a.ld = c.ld;
+    a.n_q = c.n_q;
+    a.Lq = c.Lq;
+    a.n_d = c.n_d;
+    a.flags = c.flags;
+    const int q_per_block = NW * (8 / TPQ);
+    a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
+    const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
+    int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
+    static const int over_env = getenv("MSIM_BATCH8_OVER") ? atoi(getenv("MSIM_BATCH8_OVER")) : 1;    // A/B knob
+    if (a.n_qblocks == 1 && over_env > 1) {
+        int over = over_env;
+        while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
+        sub *= over;
+    }
+    a.n_ranges = 8 * sub;
+    const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
+    a.convoy = nullptr;
+    static const bool convoy_off = getenv("MSIM_BATCH_CONVOY") && atoi(getenv("MSIM_BATCH_CONVOY")) == 0;   // A/B knob
+    if (c.workspace && !convoy_off && a.n_qblocks > 1 && a.n_qblocks <= cus_per_xcd && a.n_qblocks <= 64 &&
+        (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
+        a.convoy = static_cast<int *>(c.workspace);
+        if (hipMemsetAsync(a.convoy, 0, (size_t)a.n_ranges * a.n_qblocks * sizeof(int), c.st) != hipSuccess)
+            return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
+    }
+    a.trace = nullptr;
+    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch8_kernel<%d,%d> launch: %s", TPQ, NW, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+#endif   // MSIM_AB
+
 // MSIM_BATCH_NW=2|4|8 forces the number of waves that share a document stream in K1b (tuning knob for A/B measurements, not
 // part of the ABI; 2 is only legal up to 8 token tiles).
 int batch_nw_override() {
@@ -249,11 +296,35 @@ int batch_nw_override() {
 
 template <int TPQ, bool F16>
 int batch_dispatch(const FwdCall &c) {
-    // 5..8 token tiles: the pair form; 9..20: two 4-wave workgroups per CU cover each other's chunk barriers; above: one
+    // 5..8 token tiles: the pair form; 9..16: two 4-wave workgroups per CU cover each other's chunk barriers; above: one
     // 8-wave workgroup per CU (profiles/r02_logs/ab_ridge.log: 16 queries 6.57 ms with 4 waves vs 7.01 with 8, 24 queries
-    // 9.97 vs 9.73)
+    // 9.97 vs 9.73).  17..20 tiles used to go to the 4-wave form, which holds 16: TWO passes over the corpus -- 17 queries 8.79 ms,
+    // 20 queries 8.93 against 7.00 / 7.52 in one pass of the 8-wave form (profiles/r03_logs/ab_batch8_final.log)
     const int tiles = c.n_q * TPQ;
-    int nw = tiles <= 8 ? 2 : (tiles <= 20 ? 4 : 8);
+#ifdef MSIM_AB
+    // MSIM_BATCH8: 0 = K1b only, 1 = K1b8 from `MSIM_BATCH8_MIN` tiles up; MSIM_B8_VAR: maxsim_batch8.hip's VAR (A/B knobs;
+    // one-tile bf16 queries only, to bound the build time of the measurement library)
+    if constexpr (TPQ == 1 && !F16) {
+        static const int b8 = getenv("MSIM_BATCH8") ? atoi(getenv("MSIM_BATCH8")) : 1;
+        static const int b8_min = getenv("MSIM_BATCH8_MIN") ? atoi(getenv("MSIM_BATCH8_MIN")) : 21;
+        static const int var = getenv("MSIM_B8_VAR") ? atoi(getenv("MSIM_B8_VAR")) : 0;
+        if (b8 && tiles >= b8_min) {
+            if (tiles <= 16) return (var & 1) ? launch_batch8<1, false, 2, 4, 2, 1>(c) : launch_batch8<1, false, 2, 4, 2, 0>(c);
+            if (tiles <= 32) return (var & 1) ? launch_batch8<1, false, 4, 3, 2, 1>(c) : launch_batch8<1, false, 4, 3, 2, 0>(c);
+            switch (var) {
+                case 1: return launch_batch8<1, false, 4, 3, 0, 1>(c);
+                case 2: return launch_batch8<1, false, 4, 3, 0, 2>(c);
+                case 3: return launch_batch8<1, false, 4, 3, 0, 3>(c);
+                case 4: return launch_batch8<1, false, 4, 3, 0, 4>(c);
+                case 7: return launch_batch8<1, false, 4, 3, 0, 7>(c);
+                case 8: return launch_batch8<1, false, 4, 3, 0, 8>(c);
+                case 9: return launch_batch8<1, false, 4, 3, 0, 9>(c);
+                default: return launch_batch8<1, false, 4, 3, 0, 0>(c);
+            }
+        }
+    }
+#endif
+    int nw = tiles <= 8 ? 2 : (tiles <= 16 ? 4 : 8);
     const int forced = batch_nw_override();
     if (forced && (forced != 2 || tiles <= 8)) nw = forced;
     // one query block = every corpus byte is read once by one workgroup: stream it past L2 / MALL (nt), like K1s does.
@@ -969,6 +1040,32 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void 
 }
 
 // ---------------------------------------------------------------- embedding head (the producer of the corpus format)
+int msim_embed_head_bwd(int dtype, const void *proj, const void *grad_out, const int32_t *row_map, int64_t M, int n_out,
+                        void *dproj, void *stream) {
+    if (M < 0) return fail(MSIM_EINVAL, "bad size (M=%lld)", (long long)M);
+    if (M == 0) return MSIM_OK;
+    if (!proj || !grad_out || !row_map || !dproj) return fail(MSIM_EINVAL, "null pointer argument");
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16)
+        return fail(MSIM_EUNSUPPORTED, "dtype code %d: the embedding head takes bfloat16 (0) or float16 (1)", dtype);
+    if (n_out != msim::kHeadN) return fail(MSIM_EUNSUPPORTED, "n_out=%d: the embedding head is built for 128 output columns", n_out);
+    if ((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(dproj)) & 15)
+        return fail(MSIM_EINVAL, "proj, grad_out and dproj must be 16-byte aligned");
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    const long long blocks = (M + 15) / 16;
+    const int grid = (int)(blocks < (long long)di->cus * 16 ? blocks : (long long)di->cus * 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *p = static_cast<const uint16_t *>(proj), *g = static_cast<const uint16_t *>(grad_out);
+    uint16_t *o = static_cast<uint16_t *>(dproj);
+    if (dtype == MSIM_DTYPE_F16)
+        hipLaunchKernelGGL(msim::embed_head_bwd_rows_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, row_map, (long long)M, o);
+    else
+        hipLaunchKernelGGL(msim::embed_head_bwd_rows_kernel<false>, dim3(grid), dim3(256), 0, st, p, g, row_map, (long long)M, o);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_bwd_rows_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
 int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, const void *bias, int n_out,
                     const int32_t *row_map, void *out, int64_t ld_out, void *stream) {
     if (M < 0 || H <= 0) return fail(MSIM_EINVAL, "bad size (M=%lld H=%d)", (long long)M, H);
@@ -1211,7 +1308,7 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
     if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
     if (rows < 256LL * 8 * 5 * 32) return fail(MSIM_EINVAL, "the MFMA probe needs at least %d rows of operands", 256 * 8 * 5 * 32);
     if (variant >= 8 && rows < 256LL * 16 * 3 * 32) return fail(MSIM_EINVAL, "MFMA probe variants 8..11 need at least %d rows of operands", 256 * 16 * 3 * 32);
-    if (iters <= 0 || variant < 0 || variant > 11) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
+    if (iters <= 0 || variant < 0 || variant > 23) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X);
     int rc;
@@ -1228,6 +1325,20 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
         case 9: rc = run_probe_mfma16w<2, 16, true, true>(x, iters, sink, st); break;
         case 10: rc = run_probe_mfma16w<3, 12, false, false>(x, iters, sink, st); break;
         case 11: rc = run_probe_mfma16w<2, 16, false, false>(x, iters, sink, st); break;
+        // round 3: K1b's exact slab body (FLOP = 256 x WAVES x iters x NT x 16 x 16384); 12 = the shipped plan, 13..17 = one
+        // 512-register wave per SIMD with 8 / 6 token tiles per operand fetch
+        case 12: rc = run_probe_mix<4, 8, true>(x, iters, sink, st); break;
+        case 13: rc = run_probe_mix<8, 4, true>(x, iters, sink, st); break;
+        case 14: rc = run_probe_mix<8, 4, false>(x, iters, sink, st); break;
+        case 15: rc = run_probe_mix<6, 4, true>(x, iters, sink, st); break;
+        case 16: rc = run_probe_mix<4, 8, false>(x, iters, sink, st); break;
+        case 17: rc = run_probe_mix<4, 4, true>(x, iters, sink, st); break;      // the shipped tile count, ONE wave per SIMD
+        case 18: rc = run_probe_mix<8, 4, true, true>(x, iters, sink, st); break;  // 13 with the next slab's fragments prefetched
+        case 19: rc = run_probe_mix<6, 4, true, true>(x, iters, sink, st); break;
+        case 20: rc = run_probe_mix<8, 4, true, true, 1>(x, iters, sink, st); break;   // 18 + the fold of tile t-1 under the MFMAs of tile t
+        case 21: rc = run_probe_mix<8, 4, true, true, 2>(x, iters, sink, st); break;   // ... with the interleave pinned (sched_group_barrier)
+        case 22: rc = run_probe_mix<6, 4, true, true, 1>(x, iters, sink, st); break;
+        case 23: rc = run_probe_mix<8, 4, false, false, 1>(x, iters, sink, st); break;  // A in registers, deferred folds
         default: rc = run_probe_mfma<true, true>(x, iters, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_mfma_kernel launch failed (variant %d)", variant);

@@ -179,3 +179,129 @@ int run_probe_mfma(const uint16_t *x, int iters, float *sink, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), 8 * msim::kSlabBytes, st, x, iters, sink);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+namespace msim {
+// Round 3: the EXACT slab body of K1b (QueryTile / TileAcc, 8 conflict-free ds_read_b128 per 32-row slab, then per token tile 16
+// v_mfma_f32_16x16x32 into four accumulator chains and 8 v_max3), looped over a wave-private LDS slab with no DMA and no barrier, for
+//   NT = 4, WAVES = 8: the shipped register plan (two waves per SIMD, 4 tiles = 128 B-operand registers each);
+//   NT = 8, WAVES = 4: the plan the round-2 review asks to price before building it -- ONE 512-register wave per SIMD holding 8
+//                      tiles (256 B-operand registers, which only fit if they live in AGPRs), i.e. one operand fetch per 16 MFMAs;
+//   NT = 6, WAVES = 4: the same with 6 tiles.
+// LDSA = false keeps the A fragments in registers (what the operand path through LDS costs in that plan).
+template <int NT, int WAVES, bool LDSA, bool PF = false, int DEFER = 0>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe_mix_kernel(const uint16_t *__restrict__ X, int iters, float *__restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t base = ((size_t)blockIdx.x * WAVES + wave) * (NT + 1) * kTokTile;
+    QueryTile qt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_query_tile(qt[t], X + (base + (size_t)t * kTokTile) * kDim, 0, kTokTile, lane, true);
+    // B operands of tiles 4.. are pinned to AGPRs (MFMA srcA/srcB accept either file on gfx950): left to itself hipcc keeps 256 VGPRs
+    // and shuffles the overflow through AGPR copies (80 v_accvgpr_read/write per 128 MFMAs)
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) {
+                if (t >= 4) asm volatile("" : "+a"(qt[t].f[h][ks]));
+                else asm volatile("" : "+v"(qt[t].f[h][ks]));
+            }
+    char *slab = smem + wave * kSlabBytes;
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
+    bf16x8 areg[2][kKSteps16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) {
+            areg[g][ks] = *reinterpret_cast<const bf16x8 *>(X + (base + (size_t)NT * kTokTile + 16 * g + (lane & 15)) * kDim + ks * 32 + (lane >> 4) * 8);
+            *reinterpret_cast<bf16x8 *>(slab + rd_off[g][ks]) = areg[g][ks];
+        }
+    __syncthreads();
+    float m[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) m[t][0] = m[t][1] = -INFINITY;
+    auto fetch = [&](bf16x8 (&af)[2][kKSteps16]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) {
+                if constexpr (LDSA) {
+                    int o = rd_off[g][ks];
+                    asm volatile("" : "+v"(o));
+                    af[g][ks] = *reinterpret_cast<const bf16x8 *>(slab + o);
+                } else {
+                    asm volatile("" : "+v"(areg[g][ks]));
+                    af[g][ks] = areg[g][ks];
+                }
+            }
+    };
+    auto tile_mfmas = [&](TileAcc &acc, const bf16x8 (&af)[2][kKSteps16], int t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc.a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks)
+#pragma unroll
+            for (int hg = 0; hg < 4; ++hg)
+                acc.a[hg >> 1][hg & 1] = mfma16<false>(af[hg & 1][ks], qt[t].f[hg >> 1][ks], acc.a[hg >> 1][hg & 1]);
+    };
+    auto compute = [&](const bf16x8 (&af)[2][kKSteps16]) {
+        if constexpr (DEFER) {
+            // the 16 -> 1 fold of tile t - 1 runs underneath the MFMAs of tile t (two accumulator sets): a lone wave on its SIMD has
+            // nobody to cover the wait states between a tile's last MFMA and the VALU reads of its accumulators
+            TileAcc acc[2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                tile_mfmas(acc[t & 1], af, t);
+                if (t > 0) tile_fold(m[t - 1], acc[(t - 1) & 1]);
+                if constexpr (DEFER == 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {        // emitted order: two MFMAs, one fold instruction, ...
+                        __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+                    }
+                }
+            }
+            tile_fold(m[NT - 1], acc[(NT - 1) & 1]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                TileAcc acc;
+                tile_mfmas(acc, af, t);
+                tile_fold(m[t], acc);
+            }
+        }
+    };
+    if constexpr (PF) {            // operand fragments of the NEXT slab fetched underneath the MFMAs of the current one
+        bf16x8 af0[2][kKSteps16], af1[2][kKSteps16];
+        fetch(af0);
+        for (int it = 0; it < iters; it += 2) {
+            fetch(af1);
+            compute(af0);
+            fetch(af0);
+            compute(af1);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            bf16x8 af[2][kKSteps16];
+            fetch(af);
+            compute(af);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s += (m[t][0] == -INFINITY ? 0.f : m[t][0]) + (m[t][1] == -INFINITY ? 0.f : m[t][1]);
+    if (s == 123.456f) sink[0] = s;
+}
+}  // namespace msim
+template <int NT, int WAVES, bool LDSA, bool PF = false, int DEFER = 0>
+int run_probe_mix(const uint16_t *x, int iters, float *sink, hipStream_t st) {
+    auto kern = msim::probe_mix_kernel<NT, WAVES, LDSA, PF, DEFER>;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(WAVES * 64), WAVES * msim::kSlabBytes, st, x, iters, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

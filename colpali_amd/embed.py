@@ -80,11 +80,50 @@ def _row_ids(n: int, device):
     return t
 
 
+class _EmbeddingHeadFn(torch.autograd.Function):
+    """The fused head inside a training graph (modeling_colpali.py:65-78 is part of the graph the reference trainers
+    back-propagate through, trainer/contrastive_trainer.py:135-162).  Forward = the fused kernel.  Backward: the Linear
+    output is recomputed by a library GEMM, the norm / mask Jacobian runs in `msim_embed_head_bwd` (fp32 inside, one
+    rounding), and dX = dproj W, dW = dproj^T X, db = sum dproj are library GEMMs / a reduction again -- the same three
+    products torch's own autograd runs for nn.Linear."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, row_map):
+        B, S, _ = hidden.shape
+        out = torch.empty((B * S, HEAD_DIM), dtype=hidden.dtype, device=hidden.device)
+        _launch(hidden, weight, bias, row_map, out)
+        ctx.save_for_backward(hidden, weight, bias, row_map)
+        return out.view(B, S, HEAD_DIM)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        hidden, weight, bias, row_map = ctx.saved_tensors
+        B, S, H = hidden.shape
+        M = B * S
+        x2 = hidden.reshape(M, H)
+        g = grad_out.reshape(M, HEAD_DIM).to(hidden.dtype).contiguous()
+        with torch.autocast("cuda", enabled=False):
+            proj = torch.nn.functional.linear(x2, weight, bias)                  # :67 again: a plain library GEMM
+            dproj = torch.empty_like(proj)
+            L = _lib.lib()
+            with torch.cuda.device(hidden.device):
+                rc = L.msim_embed_head_bwd(_lib.dtype_code(hidden.dtype), _lib.ptr(proj), _lib.ptr(g), _lib.ptr(row_map), M,
+                                           HEAD_DIM, _lib.ptr(dproj), _lib.current_stream_handle(hidden.device))
+            _lib.check(rc, "msim_embed_head_bwd")
+            d_hidden = (dproj @ weight).view(B, S, H) if ctx.needs_input_grad[0] else None
+            d_weight = dproj.t() @ x2 if ctx.needs_input_grad[1] else None
+            d_bias = dproj.sum(dim=0) if bias is not None and ctx.needs_input_grad[2] else None
+        return d_hidden, d_weight, d_bias, None
+
+
 def embedding_head(hidden_states: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                    attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense drop-in for modeling_colpali.py:67-77: [B, S, hidden] -> [B, S, 128] (unit rows, masked rows zero).
 
-    `extra_mask` is the optional image-token mask of `mask_non_image_embeddings` ([B, S] or [B, S, 1])."""
+    `extra_mask` is the optional image-token mask of `mask_non_image_embeddings` ([B, S] or [B, S, 1]).
+    Differentiable: when autograd is recording and the hidden states, the weight or the bias require a gradient, the
+    result carries a graph node whose backward is `_EmbeddingHeadFn.backward` (never a silent detach)."""
     _check(hidden_states, weight, bias, attention_mask)
     B, S, _ = hidden_states.shape
     keep = attention_mask.reshape(-1) != 0
@@ -96,6 +135,9 @@ def embedding_head(hidden_states: torch.Tensor, weight: torch.Tensor, bias: Opti
     else:
         row_map = _padded_map(B * S, hidden_states.device)
         torch.where(keep, rows, zero_rows, out=row_map[: B * S])
+    if torch.is_grad_enabled() and (hidden_states.requires_grad or weight.requires_grad
+                                    or (bias is not None and bias.requires_grad)):
+        return _EmbeddingHeadFn.apply(hidden_states, weight, bias, row_map)
     out = torch.empty((B * S, HEAD_DIM), dtype=hidden_states.dtype, device=hidden_states.device)
     _launch(hidden_states, weight, bias, row_map, out)
     return out.view(B, S, HEAD_DIM)
@@ -122,8 +164,15 @@ class CorpusWriter:
 
     def append(self, hidden_states: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor] = None) -> int:
-        """Returns the number of pages appended.  Asynchronous: no host synchronisation."""
+        """Returns the number of pages appended.  Asynchronous: no host synchronisation.
+        Indexing only: the rows are written into the resident blob, outside any autograd graph -- inputs that are being
+        recorded for a gradient are refused instead of silently detached (call it under torch.no_grad(), as README.md:121
+        does for inference, or use `embedding_head`, which is differentiable)."""
         _check(hidden_states, weight, bias, attention_mask)
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or weight.requires_grad
+                                        or (bias is not None and bias.requires_grad)):
+            raise RuntimeError("CorpusWriter.append writes into the resident corpus and has no backward: call it under "
+                               "torch.no_grad() (indexing), or use colpali_amd.embedding_head inside a training graph")
         if hidden_states.dtype != self.blob.dtype or hidden_states.device != self.device:
             raise ValueError("hidden states must have the writer's dtype and device")
         B, S, _ = hidden_states.shape

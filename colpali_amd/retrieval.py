@@ -78,14 +78,19 @@ def merge_gathered(all_s: torch.Tensor, all_i: torch.Tensor, k: int,
 
 
 def shard_topk(scores: torch.Tensor, k: int, id_base: int, world: int = 1, dist=None, group=None,
-               select: Callable = topk) -> Tuple[torch.Tensor, torch.Tensor]:
+               select: Callable = topk, force_collective: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Per-shard top-k of a local score matrix, then (world > 1) all-gather + merge.
 
     `scores` [n_q, n_local]: column j is document id_base + j.  Returns the same global
-    (scores [n_q, k], ids [n_q, k]) on every rank.
+    (scores [n_q, k], ids [n_q, k]) on every rank.  `force_collective=True` sends a single rank through the
+    message packing, the all-gather (RCCL under the `nccl` backend) and the strided-view merge as well: the
+    multi-GPU code path, exercised on the one GPU a test box has (the result is the same by construction).
     """
-    if world <= 1:
+    if world <= 1 and not force_collective:
         return select(scores, k, id_base, None)
+    world = max(world, 1)
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLW0642 - the default collective library
     # one message per rank: [scores fp32 n_q*k | pad to 8 | ids int64 n_q*k] -- ONE all-gather of 12 bytes per candidate
     n_q = scores.shape[0]
     sb = n_q * k * 4
@@ -112,10 +117,11 @@ class ShardedRetriever:
     """One instance per process/GPU; holds this rank's resident shard of the corpus."""
 
     def __init__(self, shard: PackedCorpus, world: int = 1, rank: int = 0, dist=None, group=None,
-                 score_fn: Callable = maxsim_scores, select: Callable = topk):
+                 score_fn: Callable = maxsim_scores, select: Callable = topk, force_collective: bool = False):
         self.shard, self.world, self.rank = shard, world, rank
         self.dist, self.group = dist, group
         self._score, self._select = score_fn, select
+        self.force_collective = force_collective
         if world > 1 and dist is None:
             import torch.distributed as dist_mod
 
@@ -124,4 +130,5 @@ class ShardedRetriever:
     def search(self, queries: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         """queries: bf16 [n_q, Lq, 128] on this rank's GPU (replicated on every rank)."""
         scores = self._score(queries, self.shard)
-        return shard_topk(scores, k, self.shard.id_base, self.world, self.dist, self.group, self._select)
+        return shard_topk(scores, k, self.shard.id_base, self.world, self.dist, self.group, self._select,
+                          force_collective=self.force_collective)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 12
+#define MSIM_ABI_VERSION 13
 
 /* error codes */
 #define MSIM_OK 0
@@ -200,6 +200,20 @@ int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C,
 int msim_embed_head(int dtype, const void *X, int64_t M, int H,
                     const void *W, const void *bias, int n_out,
                     const int32_t *row_map, void *out, int64_t ld_out, void *stream);
+
+/*
+ * Backward of the norm / mask tail of the embedding head -- what torch autograd derives for
+ *   colpali_engine/models/paligemma/colpali/modeling_colpali.py:70  proj = proj / proj.norm(dim=-1, keepdim=True)
+ *                                                                :72  proj = proj * attention_mask.unsqueeze(-1)      (+ :74-77)
+ * with respect to the nn.Linear output (:67), for a model whose head runs inside the training graph
+ * (trainer/contrastive_trainer.py:135-162 back-propagates through it):
+ *   dproj[m, :] = row_map[m] >= 0 ? (g[m, :] - y <g[m, :], y>) / n : 0,    y = proj[m, :] / n,    n = ||proj[m, :]|| rounded to dtype
+ *   proj [M, 128] = the Linear output, grad_out [M, 128] = the upstream gradient, dproj [M, 128]: dense rows, dtype bf16 | f16;
+ *   row_map as in msim_embed_head (>= 0: the position was kept; < 0: masked, gradient exactly 0).
+ * The GEMMs on either side (proj itself; dX = dproj W, dW = dproj^T X, db = sum dproj) are plain library GEMMs, left to the host.
+ */
+int msim_embed_head_bwd(int dtype, const void *proj, const void *grad_out, const int32_t *row_map, int64_t M, int n_out,
+                        void *dproj, void *stream);
 
 /*
  * Plain similarity matrix, no reduction:   out[i, j] = <A[i, :], B[j, :]>   (fp32 accumulate)

@@ -273,6 +273,28 @@ def head_golden():
         out[f"weight_{tag}"] = conv(m.custom_text_proj.weight.detach())
         out[f"bias_{tag}"] = conv(m.custom_text_proj.bias.detach())
         out[f"out_{tag}"] = conv(y)
+        # the same forward inside the training graph (modeling_colpali.py:65-78 is part of it): autograd's gradients of the
+        # head's weight / bias and of the hidden states it received, for the upstream gradient G (colpali_amd.embedding_head's
+        # backward is pinned on these)
+        gG = torch.Generator().manual_seed(2)
+        G = torch.randn(B, S, 128, generator=gG).to(dtype)
+        cap2 = {}
+
+        def keep_grad(mod, inp):
+            h = inp[0].detach().clone().requires_grad_(True)
+            cap2["h"] = h
+            return (h,)
+
+        hook = m.custom_text_proj.register_forward_pre_hook(keep_grad)
+        m.zero_grad(set_to_none=True)
+        y2 = m(input_ids=ids, attention_mask=mask)
+        hook.remove()
+        assert torch.equal(y2.detach(), y)
+        (y2 * G).sum().backward()
+        out[f"gout_{tag}"] = conv(G)
+        out[f"dweight_{tag}"] = conv(m.custom_text_proj.weight.grad)
+        out[f"dbias_{tag}"] = conv(m.custom_text_proj.bias.grad)
+        out[f"dhidden_{tag}"] = conv(cap2["h"].grad)
     save("head_colpali_tiny.npz", **out)
 
 

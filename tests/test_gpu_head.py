@@ -179,3 +179,100 @@ def test_corpus_writer_rejected_append_leaves_the_writer_usable(amd):
     assert writer.rows_written() == 20
     assert writer.append(h, w, None, torch.ones(2, 40, dtype=torch.long, device=dev)) == 2   # 20 + 80 fits
     assert len(writer.finish()) == 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The head inside a training graph (modeling_colpali.py:65-78 is part of what the reference trainers back-propagate through).
+
+def _truth_grads(hidden, weight, bias, mask, G, extra=None):
+    """float64 autograd through oracle/head_oracle.py's restatement of the reference lines: the three gradients, and for each
+    the sum of the ABSOLUTE terms of the product that forms it (|dproj| |W|, |dproj|^T |X|, sum |dproj|): dproj is rounded
+    to the 16-bit model dtype before the products, so the error of a gradient scales with that sum, not with the (possibly
+    cancelled) value."""
+    h = hidden.double().requires_grad_(True)
+    w = weight.double().requires_grad_(True)
+    b = None if bias is None else bias.double().requires_grad_(True)
+    cap = {}
+    orig = torch.nn.functional.linear
+
+    def linear_keep(x, ww, bb=None):
+        y = orig(x, ww, bb)
+        y.retain_grad()
+        cap["proj"] = y
+        return y
+
+    ho.F.linear = linear_keep
+    try:
+        y = ho.head_literal(h, w, b, mask, extra)
+    finally:
+        ho.F.linear = orig
+    (y * G.double()).sum().backward()
+    dproj = cap["proj"].grad.abs()
+    flat = dproj.reshape(-1, dproj.shape[-1])
+    bounds = ((dproj @ w.detach().abs()), flat.t() @ h.detach().abs().reshape(-1, h.shape[-1]), flat.sum(0))
+    return (h.grad, w.grad, None if b is None else b.grad), bounds
+
+
+def _grad_close(got, want, bound, dtype):
+    """|error| <= ulp-of-the-result + one 16-bit rounding per term of the product (worst case, see _truth_grads)."""
+    rel = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-11
+    err = (got.cpu().double() - want).abs()
+    return bool(torch.all(err <= rel * want.abs() + rel * bound + 1e-30))
+
+
+def test_backward_against_live_reference_autograd_golden(amd):
+    z = load_golden("head_colpali_tiny.npz")
+    h, w, b, G = (_bf16(z[k]) for k in ("hidden_bf16", "weight_bf16", "bias_bf16", "gout_bf16"))
+    mask = torch.from_numpy(z["attention_mask"])
+    hx, wx, bx = (t.cuda().requires_grad_(True) for t in (h, w, b))
+    out = amd.embedding_head(hx, wx, bx, mask.cuda())
+    assert out.requires_grad and out.grad_fn is not None
+    (out * G.cuda()).sum().backward()
+    wants, bounds = _truth_grads(h, w, b, mask, G)
+    for got, want, bound, ref_key in zip((hx.grad, wx.grad, bx.grad), wants, bounds, ("dhidden_bf16", "dweight_bf16", "dbias_bf16")):
+        assert got.dtype == torch.bfloat16
+        assert _grad_close(got, want, bound, torch.bfloat16)
+        # the live reference's own bf16 autograd (five 16-bit roundings between the upstream gradient and dproj where this
+        # backward has one) is what is being replaced: it must sit around the same truth, a few times looser
+        ref = _bf16(z[ref_key]).double()
+        assert bool(torch.all((ref - want).abs() <= 4 * (2.0**-8) * (want.abs() + bound) + 1e-30))
+    assert torch.count_nonzero(hx.grad.cpu()[mask == 0]) == 0            # masked positions receive exactly no gradient
+
+
+@pytest.mark.parametrize("B,S,H,dtype,with_bias,with_extra", [
+    (3, 50, 64, torch.bfloat16, True, False),
+    (2, 333, 1536, torch.bfloat16, True, True),      # rows not a multiple of the 256-row tile, image mask
+    (2, 130, 2048, torch.float16, False, False),
+])
+def test_backward_random_cases_against_float64_autograd(amd, B, S, H, dtype, with_bias, with_extra):
+    hidden, weight, bias, mask = _case(B * 10 + S, B, S, H, dtype)
+    bias = bias if with_bias else None
+    extra = (torch.arange(S)[None, :] % 4 != 1).expand(B, S).unsqueeze(-1) if with_extra else None
+    G = torch.randn(B, S, 128, generator=torch.Generator().manual_seed(S)).to(dtype)
+    hx, wx = hidden.cuda().requires_grad_(True), weight.cuda().requires_grad_(True)
+    bx = None if bias is None else bias.cuda().requires_grad_(True)
+    out = amd.embedding_head(hx, wx, bx, mask.cuda(), None if extra is None else extra.cuda())
+    (out.float() * G.cuda().float()).sum().backward()
+    (want_h, want_w, want_b), (bd_h, bd_w, bd_b) = _truth_grads(hidden, weight, bias, mask, G, extra)
+    assert _grad_close(hx.grad, want_h, bd_h, dtype) and _grad_close(wx.grad, want_w, bd_w, dtype)
+    if bx is not None:
+        assert _grad_close(bx.grad, want_b, bd_b, dtype)
+
+
+def test_a_silent_detach_is_impossible(amd):
+    hidden, weight, bias, mask = _case(3, 2, 40, 128, torch.bfloat16)
+    h, w, b, m = hidden.cuda(), weight.cuda(), bias.cuda(), mask.cuda()
+    assert not amd.embedding_head(h, w, b, m).requires_grad               # nothing to differentiate: the plain launch
+    for which in range(3):
+        args = [t.clone().requires_grad_(i == which) for i, t in enumerate((h, w, b))]
+        out = amd.embedding_head(*args, m)
+        assert out.requires_grad and out.grad_fn is not None
+        out.float().square().sum().backward()
+        assert args[which].grad is not None and torch.isfinite(args[which].grad.float()).all()
+        with torch.no_grad():
+            assert not amd.embedding_head(*args, m).requires_grad
+    writer = amd.CorpusWriter(capacity_rows=100, device=h.device)
+    with pytest.raises(RuntimeError, match="no_grad"):
+        writer.append(h, w.clone().requires_grad_(True), b, m)
+    with torch.no_grad():
+        assert writer.append(h, w.clone().requires_grad_(True), b, m) == 2
