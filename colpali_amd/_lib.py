@@ -11,8 +11,22 @@ import os
 import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime (libamdhip64.so) we bind to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# COLPALI_AMD_LIB: load another build of the same ABI instead (A/B measurements of two builds inside one process run; tools/ only)
-LIB_PATH = os.environ.get("COLPALI_AMD_LIB") or os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
+# COLPALI_AMD_LIB: load another build of the same ABI instead -- measurement builds under tools/_ab/ only (`make ab`, `make trace`,
+# a kept previous build: A/B runs inside one gpurun); any other path is refused, the product loads the in-tree library
+_AB_DIR = os.path.realpath(os.path.join(_HERE, "..", "tools", "_ab"))
+
+
+def _lib_path() -> str:
+    override = os.environ.get("COLPALI_AMD_LIB")
+    if override:
+        real = os.path.realpath(override)
+        if os.path.dirname(real) != _AB_DIR:
+            raise RuntimeError(f"COLPALI_AMD_LIB={override}: only measurement builds under {_AB_DIR} can replace the in-tree library")
+        return real
+    return os.path.join(_HERE, "csrc", "libmaxsim_gfx950.so")
+
+
+LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
 ABI_VERSION = 13
@@ -119,6 +133,37 @@ def check(rc: int, what: str) -> None:
         if rc == -1:
             raise ValueError(f"{what}: {msg}")
         raise MaxSimLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+class StreamConstCache:
+    """Small read-only device constants (index lists, row ids), cached per (key, device, stream).  An entry is only ever
+    used on the stream it was allocated on, so evicting it -- oldest first, under a lock -- hands its memory back to the
+    caching allocator in stream order; nothing is cleared wholesale under another thread's feet."""
+
+    def __init__(self, capacity: int):
+        import collections
+        import threading
+
+        self._d = collections.OrderedDict()
+        self._lock = threading.Lock()
+        self._cap = capacity
+
+    def get(self, key, device, make):
+        k = (key, str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
+        with self._lock:
+            t = self._d.get(k)
+            if t is not None:
+                self._d.move_to_end(k)
+                return t
+        t = make()
+        with self._lock:
+            self._d[k] = t
+            while len(self._d) > self._cap:
+                self._d.popitem(last=False)
+        return t
+
+    def __len__(self):
+        return len(self._d)
 
 
 def ptr(t) -> int:

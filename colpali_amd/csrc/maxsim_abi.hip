@@ -42,6 +42,17 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// an integer A/B knob from the environment -- measurement builds only (maxsim_common.hpp: kAbBuild); the shipped library returns
+// the default without looking
+int ab_env(const char *name, int dflt) {
+    if constexpr (msim::kAbBuild) {
+        const char *e = getenv(name);
+        return e ? atoi(e) : dflt;
+    }
+    (void)name;
+    return dflt;
+}
+
 struct DeviceInfo {
     int cus = 0;
     int lds_per_cu = 0;
@@ -132,10 +143,7 @@ constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves 
 // (do not allocate in L2 / MALL).  Measured on MI355X, 16 GiB shard: 6.31 -> 7.02 TB/s at 1 query, 6.08 -> 6.45 TB/s
 // at 4 queries.  MSIM_STREAM_NT=0 switches it off for A/B measurements (tuning knob, not part of the ABI).
 int stream_nt() {
-    static const int v = [] {
-        const char *e = getenv("MSIM_STREAM_NT");
-        return e ? (atoi(e) != 0) : 1;
-    }();
+    static const int v = ab_env("MSIM_STREAM_NT", 1) != 0;
     return v;
 }
 
@@ -164,10 +172,7 @@ int launch_stream_aux(const FwdCall &c) {
 // shard (profiles/r01_logs/ab_stream_il.log): 4 queries 6.37-6.43 -> 6.52-6.55 TB/s, 6-8 queries +1 %, 1-2 queries unchanged.
 // MSIM_STREAM_IL=0 selects the block-issue variant (tuning knob, not part of the ABI).
 int stream_il() {
-    static const int v = [] {
-        const char *e = getenv("MSIM_STREAM_IL");
-        return e ? (atoi(e) != 0) : 1;
-    }();
+    static const int v = ab_env("MSIM_STREAM_IL", 1) != 0;
     return v;
 }
 
@@ -177,15 +182,19 @@ int launch_stream(const FwdCall &c) {
     // other's DMA issue / operand reads / max folds: 4 queries 6.51-6.55 -> 6.82 TB/s (85 % of spec); 1-2 tiles are at the stream
     // ceiling either way, 5+ tiles need more than 256 registers per wave (one wave per SIMD) and keep the deeper ring.
     // MSIM_STREAM_RING=2|4 forces one of them (tuning knob, not part of the ABI).
-    static const int ring_env = getenv("MSIM_STREAM_RING") ? atoi(getenv("MSIM_STREAM_RING")) : 0;
-    const int ring = ring_env ? ring_env : ((QT == 3 || QT == 4) ? 2 : kStreamRing);
-    static const bool tile_major = getenv("MSIM_STREAM_TILEMAJOR") && atoi(getenv("MSIM_STREAM_TILEMAJOR")) != 0;   // A/B knob
-    if constexpr (QT == 4 && TPQ == 1 && !F16) {
-        if (ring == 2 && tile_major) return launch_stream_aux<QT, TPQ, F16, 2, true, 2, true>(c);
+    constexpr int ring_default = (QT == 3 || QT == 4) ? 2 : kStreamRing;
+    if constexpr (msim::kAbBuild) {
+        static const int ring_env = ab_env("MSIM_STREAM_RING", 0);
+        const int ring = ring_env ? ring_env : ring_default;
+        static const bool tile_major = ab_env("MSIM_STREAM_TILEMAJOR", 0) != 0;
+        if constexpr (QT == 4 && TPQ == 1 && !F16) {
+            if (ring == 2 && tile_major) return launch_stream_aux<QT, TPQ, F16, 2, true, 2, true>(c);
+        }
+        if (ring == 2) return launch_stream_aux<QT, TPQ, F16, 2, true, 2>(c);
+        if (stream_il() && stream_nt()) return launch_stream_aux<QT, TPQ, F16, 2, true>(c);
+        return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
     }
-    if (ring == 2) return launch_stream_aux<QT, TPQ, F16, 2, true, 2>(c);
-    if (stream_il() && stream_nt()) return launch_stream_aux<QT, TPQ, F16, 2, true>(c);
-    return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
+    return launch_stream_aux<QT, TPQ, F16, 2, true, ring_default>(c);     // nt stream, interleaved DMA issue
 }
 
 template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0>
@@ -213,7 +222,7 @@ int launch_batch(const FwdCall &c) {
     // at 9..16 queries (profiles/r02_logs/ab_batch_over.log; the pair form, 5..8 queries, does not gain and keeps one range per
     // resident workgroup).  Only when one query block streams the corpus (no L2 sharing between blocks to preserve), and never down
     // to ranges of fewer than ~16 documents.
-    static const int over_env = getenv("MSIM_BATCH_OVER") ? atoi(getenv("MSIM_BATCH_OVER")) : (NW == 4 ? 8 : 1);    // A/B knob
+    static const int over_env = ab_env("MSIM_BATCH_OVER", NW == 4 ? 8 : 1);
     if (NW < 8 && a.n_qblocks == 1 && over_env > 1) {
         int over = over_env;
         while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
@@ -223,7 +232,7 @@ int launch_batch(const FwdCall &c) {
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
     // convoy (maxsim_batch.hip): only when several query blocks share a range AND all of them are resident at once
     a.convoy = nullptr;
-    static const bool convoy_off = getenv("MSIM_BATCH_CONVOY") && atoi(getenv("MSIM_BATCH_CONVOY")) == 0;   // A/B knob
+    static const bool convoy_off = ab_env("MSIM_BATCH_CONVOY", 1) == 0;
     if (c.workspace && !convoy_off && a.n_qblocks > 1 && a.n_qblocks <= cus_per_xcd && a.n_qblocks <= 64 &&
         (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
         a.convoy = static_cast<int *>(c.workspace);
@@ -231,8 +240,9 @@ int launch_batch(const FwdCall &c) {
             return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
     }
     a.trace = nullptr;
-    if (const char *tp = getenv("MSIM_BATCH_TRACE_PTR"))     // debug knob: device address of 8 x 8 uint64 (tools/trace_batch.py)
-        a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
+    if constexpr (msim::kTraceBuild) {                       // `make trace` only: device address of 8 x 8 uint64 (tools/trace_batch.py)
+        if (const char *tp = getenv("MSIM_BATCH_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
+    }
     hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", TPQ, NW, hipGetErrorString(e));
@@ -258,7 +268,7 @@ int launch_batch8(const FwdCall &c) {
     a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
     int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
-    static const int over_env = getenv("MSIM_BATCH8_OVER") ? atoi(getenv("MSIM_BATCH8_OVER")) : 1;    // A/B knob
+    static const int over_env = ab_env("MSIM_BATCH8_OVER", 1);
     if (a.n_qblocks == 1 && over_env > 1) {
         int over = over_env;
         while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
@@ -267,7 +277,7 @@ int launch_batch8(const FwdCall &c) {
     a.n_ranges = 8 * sub;
     const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
     a.convoy = nullptr;
-    static const bool convoy_off = getenv("MSIM_BATCH_CONVOY") && atoi(getenv("MSIM_BATCH_CONVOY")) == 0;   // A/B knob
+    static const bool convoy_off = ab_env("MSIM_BATCH_CONVOY", 1) == 0;
     if (c.workspace && !convoy_off && a.n_qblocks > 1 && a.n_qblocks <= cus_per_xcd && a.n_qblocks <= 64 &&
         (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
         a.convoy = static_cast<int *>(c.workspace);
@@ -287,27 +297,42 @@ int launch_batch8(const FwdCall &c) {
 // part of the ABI; 2 is only legal up to 8 token tiles).
 int batch_nw_override() {
     static const int v = [] {
-        const char *e = getenv("MSIM_BATCH_NW");
-        const int x = e ? atoi(e) : 0;
+        const int x = ab_env("MSIM_BATCH_NW", 0);
         return (x == 2 || x == 4 || x == 8) ? x : 0;
     }();
     return v;
 }
 
+// The shape K1b runs a problem in -- ONE definition, shared by the dispatch below and by msim_fwd_workspace_bytes (which must
+// report scratch exactly when launch_batch would use it: round-2 advisor finding).
+// 5..8 token tiles: the pair form; 9..16: two 4-wave workgroups per CU cover each other's chunk barriers; above: one
+// 8-wave workgroup per CU (profiles/r02_logs/ab_ridge.log: 16 queries 6.57 ms with 4 waves vs 7.01 with 8, 24 queries
+// 9.97 vs 9.73).  17..20 tiles used to go to the 4-wave form, which holds 16: TWO passes over the corpus -- 17 queries 8.79 ms,
+// 20 queries 8.93 against 7.00 / 7.52 in one pass of the 8-wave form (profiles/r03_logs/ab_batch8_final.log)
+struct BatchPlan {
+    int nw;          // waves per document stream
+    int n_qblocks;   // query blocks (passes over a document range)
+};
+BatchPlan batch_plan(int n_q, int tpq) {
+    const int tiles = n_q * tpq;
+    int nw = tiles <= 8 ? 2 : (tiles <= 16 ? 4 : 8);
+    const int forced = batch_nw_override();
+    if (forced && (forced != 2 || tiles <= 8)) nw = forced;
+    const int q_per_block = nw * (4 / tpq);
+    return BatchPlan{nw, (n_q + q_per_block - 1) / q_per_block};
+}
+
 template <int TPQ, bool F16>
 int batch_dispatch(const FwdCall &c) {
-    // 5..8 token tiles: the pair form; 9..16: two 4-wave workgroups per CU cover each other's chunk barriers; above: one
-    // 8-wave workgroup per CU (profiles/r02_logs/ab_ridge.log: 16 queries 6.57 ms with 4 waves vs 7.01 with 8, 24 queries
-    // 9.97 vs 9.73).  17..20 tiles used to go to the 4-wave form, which holds 16: TWO passes over the corpus -- 17 queries 8.79 ms,
-    // 20 queries 8.93 against 7.00 / 7.52 in one pass of the 8-wave form (profiles/r03_logs/ab_batch8_final.log)
     const int tiles = c.n_q * TPQ;
+    (void)tiles;
 #ifdef MSIM_AB
     // MSIM_BATCH8: 0 = K1b only, 1 = K1b8 from `MSIM_BATCH8_MIN` tiles up; MSIM_B8_VAR: maxsim_batch8.hip's VAR (A/B knobs;
     // one-tile bf16 queries only, to bound the build time of the measurement library)
     if constexpr (TPQ == 1 && !F16) {
-        static const int b8 = getenv("MSIM_BATCH8") ? atoi(getenv("MSIM_BATCH8")) : 1;
-        static const int b8_min = getenv("MSIM_BATCH8_MIN") ? atoi(getenv("MSIM_BATCH8_MIN")) : 21;
-        static const int var = getenv("MSIM_B8_VAR") ? atoi(getenv("MSIM_B8_VAR")) : 0;
+        static const int b8 = ab_env("MSIM_BATCH8", 1);
+        static const int b8_min = ab_env("MSIM_BATCH8_MIN", 21);
+        static const int var = ab_env("MSIM_B8_VAR", 0);
         if (b8 && tiles >= b8_min) {
             if (tiles <= 16) return (var & 1) ? launch_batch8<1, false, 2, 4, 2, 1>(c) : launch_batch8<1, false, 2, 4, 2, 0>(c);
             if (tiles <= 32) return (var & 1) ? launch_batch8<1, false, 4, 3, 2, 1>(c) : launch_batch8<1, false, 4, 3, 2, 0>(c);
@@ -324,12 +349,10 @@ int batch_dispatch(const FwdCall &c) {
         }
     }
 #endif
-    int nw = tiles <= 8 ? 2 : (tiles <= 16 ? 4 : 8);
-    const int forced = batch_nw_override();
-    if (forced && (forced != 2 || tiles <= 8)) nw = forced;
+    const int nw = batch_plan(c.n_q, TPQ).nw;
     // one query block = every corpus byte is read once by one workgroup: stream it past L2 / MALL (nt), like K1s does.
     // MSIM_BATCH_NT=0 switches that off for A/B measurements (tuning knob, not part of the ABI).
-    static const bool nt_off = getenv("MSIM_BATCH_NT") && atoi(getenv("MSIM_BATCH_NT")) == 0;
+    static const bool nt_off = ab_env("MSIM_BATCH_NT", 1) == 0;
     const int q_per_block = nw * (4 / TPQ);
     const bool single_block = c.n_q <= q_per_block && !nt_off;
     if (nw == 2) return single_block ? launch_batch<TPQ, F16, 2, 4, 2>(c) : launch_batch<TPQ, F16, 2, 4, 0>(c);
@@ -567,7 +590,7 @@ int smooth_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_r
     const int tpq = (a.Lq + msim::kTokTile - 1) / msim::kTokTile;
     const int cg = (a.dim + 32 * msim::kSmoothCB - 1) / (32 * msim::kSmoothCB);
     const bool hoist = a.row_bytes <= 256;                       // the owner tile's fragments fit 8 registers quads
-    static const bool no_stage = getenv("MSIM_SMOOTH_NO_STAGE") != nullptr;   // A/B knob, not part of the ABI
+    static const bool no_stage = ab_env("MSIM_SMOOTH_NO_STAGE", 0) != 0;   // A/B knob (measurement builds)
     const int slabs = (max_doc_rows + 31) / 32;
     if constexpr (DT != msim::kDtypeF32) {
         if (a.row_bytes == msim::kRowBytes && a.dim == msim::kDim && !no_stage) {   // 128 x 16-bit rows: staged "other" tiles
@@ -748,10 +771,12 @@ const char *msim_last_error(void) { return g_err; }
 
 size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim) {
     // the only scratch msim_fwd uses: the progress counters of K1b's convoy, needed once more than one query block streams a
-    // document range (more than 32 token tiles of bf16 / fp16, width 128).  Passing NULL instead only switches the convoy off.
+    // document range (bf16 / fp16, width 128).  Passing NULL instead only switches the convoy off; a non-null workspace must hold
+    // at least the bytes reported here (4096 whenever it is non-zero).
     if (n_q <= 0 || n_d <= 0 || Lq <= 0 || !is_tuned(dtype, dim, Lq)) return 0;
-    const long long tiles = (long long)n_q * ((Lq + msim::kTokTile - 1) / msim::kTokTile);
-    return tiles > 32 ? kFwdWorkspaceBytes : 0;
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+    if ((long long)n_q * tpq <= 4) return 0;                                        // K1s: no scratch
+    return batch_plan(n_q, tpq).n_qblocks > 1 ? kFwdWorkspaceBytes : 0;             // exactly launch_batch's condition
 }
 
 int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
@@ -1085,8 +1110,9 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     a.H = H;
     a.ld_out = ld_out;
     a.trace = nullptr;
-    if (const char *tp = getenv("MSIM_HEAD_TRACE_PTR"))      // debug knob: device address of 9 x 8 uint64 (tools/trace_head.py)
-        a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
+    if constexpr (msim::kTraceBuild) {                       // `make trace` only: device address of 9 x 8 uint64 (tools/trace_head.py)
+        if (const char *tp = getenv("MSIM_HEAD_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
+    }
     const long long tiles = (M + msim::kHeadBM - 1) / msim::kHeadBM;
     const int grid = tiles < di->cus ? (int)tiles : di->cus;
     const long long tiles_h = (M + 127) / 128;                               // HALF variant: 128-row tiles, two workgroups per CU
@@ -1105,57 +1131,71 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         hipLaunchKernelGGL(kern, dim3(grid_h), dim3(320), lds, st, x, w, b, row_map, o, a);
         return MSIM_OK;
     };
-    static std::atomic<int> configured[12][kMaxDevices];
-    // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
-    // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (default): loader two weight chunks ahead, rings 3 + 3; bit 4: two half-size workgroups per CU; bit 5: DMA pieces between the
-    // MFMAs; bit 6 (default): whole-row output stores through LDS
-    // (tuning knob for A/B measurements, not part of the ABI; profiles/r02_logs/ab_head_variants.log)
-    static const int variant = getenv("MSIM_HEAD_VARIANT") ? atoi(getenv("MSIM_HEAD_VARIANT")) & 127 : 72;
     int rc;
     const bool f16 = dtype == MSIM_DTYPE_F16;
-    const bool epi2 = (variant & 4) && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
-                      (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0);   // 8-byte stores, 4-byte bias loads
-    // bit 3: loader two weight chunks ahead (rings 3 + 3)
-    // bit 6 (default): output rows staged through LDS and stored as whole rows; needs 16-byte aligned rows, else the 2-byte form
-    const bool epi3 = (variant & 64) && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    if (epi3) {
-        static std::atomic<int> configured5[2][kMaxDevices];
-        rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, false, true>, configured5[0], msim::kHeadFLds)
-                 : go(msim::embed_head_kernel<false, false, false, false, true, false, false, true>, configured5[1], msim::kHeadFLds);
-    } else if (variant & 32) {           // bit 5: hidden-state DMA pieces issued between the k-steps' MFMAs (+ bit 3 rings, + bit 2 epilogue)
-        static std::atomic<int> configured4[6][kMaxDevices];
-        if ((variant & 8) && (variant & 4) && epi2)
-            rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true, false, true>, configured4[0], msim::kHeadFLds)
-                     : go(msim::embed_head_kernel<false, false, false, true, true, false, true>, configured4[1], msim::kHeadFLds);
-        else if (variant & 8)
-            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, true>, configured4[2], msim::kHeadFLds)
-                     : go(msim::embed_head_kernel<false, false, false, false, true, false, true>, configured4[3], msim::kHeadFLds);
+    // Shipped: loader two weight chunks ahead (rings 3 + 3), output rows staged through LDS and stored as whole rows with the
+    // streaming policy (needs 16-byte aligned output rows; the 2-byte-store form of the same kernel otherwise).  Every other
+    // variant of embed_head_kernel was measured and not kept; they are compiled into measurement builds only.
+    if constexpr (!msim::kAbBuild) {
+        const bool whole_rows = ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        static std::atomic<int> cfg[4][kMaxDevices];
+        if (whole_rows)
+            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, false, true>, cfg[0], msim::kHeadFLds)
+                     : go(msim::embed_head_kernel<false, false, false, false, true, false, false, true>, cfg[1], msim::kHeadFLds);
         else
-            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, false, false, true>, configured4[4], msim::kHeadLds)
-                     : go(msim::embed_head_kernel<false, false, false, false, false, false, true>, configured4[5], msim::kHeadLds);
-    } else if (variant & 16) {           // bit 4: two half-size workgroups per CU
-        static std::atomic<int> configured3[2][kMaxDevices];
-        rc = f16 ? go_half(msim::embed_head_kernel<true, false, false, false, false, true>, configured3[0])
-                 : go_half(msim::embed_head_kernel<false, false, false, false, false, true>, configured3[1]);
-    } else if ((variant & 8) && (variant & 4) && epi2) {
-        static std::atomic<int> configured2[2][kMaxDevices];
-        rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true>, configured2[0], msim::kHeadFLds)
-                 : go(msim::embed_head_kernel<false, false, false, true, true>, configured2[1], msim::kHeadFLds);
-    } else if (variant & 8) {
-        rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true>, configured[10], msim::kHeadFLds)
-                 : go(msim::embed_head_kernel<false, false, false, false, true>, configured[11], msim::kHeadFLds);
-    } else
-    switch (epi2 ? 4 : (variant & 3)) {
-        case 1: rc = f16 ? go(msim::embed_head_kernel<true, true, false>, configured[0], msim::kHeadFLds)
-                         : go(msim::embed_head_kernel<false, true, false>, configured[1], msim::kHeadFLds); break;
-        case 2: rc = f16 ? go(msim::embed_head_kernel<true, false, true>, configured[2], msim::kHeadLds)
-                         : go(msim::embed_head_kernel<false, false, true>, configured[3], msim::kHeadLds); break;
-        case 3: rc = f16 ? go(msim::embed_head_kernel<true, true, true>, configured[4], msim::kHeadFLds)
-                         : go(msim::embed_head_kernel<false, true, true>, configured[5], msim::kHeadFLds); break;
-        case 4: rc = f16 ? go(msim::embed_head_kernel<true, false, false, true>, configured[8], msim::kHeadLds)
-                         : go(msim::embed_head_kernel<false, false, false, true>, configured[9], msim::kHeadLds); break;
-        default: rc = f16 ? go(msim::embed_head_kernel<true, false, false>, configured[6], msim::kHeadLds)
-                          : go(msim::embed_head_kernel<false, false, false>, configured[7], msim::kHeadLds); break;
+            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true>, cfg[2], msim::kHeadFLds)
+                     : go(msim::embed_head_kernel<false, false, false, false, true>, cfg[3], msim::kHeadFLds);
+    } else {
+        static std::atomic<int> configured[12][kMaxDevices];
+        // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
+        // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (default): loader two weight chunks ahead, rings 3 + 3; bit 4: two half-size workgroups per CU; bit 5: DMA pieces between the
+        // MFMAs; bit 6 (default): whole-row output stores through LDS
+        // (tuning knob for A/B measurements, not part of the ABI; profiles/r02_logs/ab_head_variants.log)
+        static const int variant = ab_env("MSIM_HEAD_VARIANT", 72) & 127;
+        const bool epi2 = (variant & 4) && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
+                          (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0);   // 8-byte stores, 4-byte bias loads
+        // bit 3: loader two weight chunks ahead (rings 3 + 3)
+        // bit 6 (default): output rows staged through LDS and stored as whole rows; needs 16-byte aligned rows, else the 2-byte form
+        const bool epi3 = (variant & 64) && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        if (epi3) {
+            static std::atomic<int> configured5[2][kMaxDevices];
+            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, false, true>, configured5[0], msim::kHeadFLds)
+                     : go(msim::embed_head_kernel<false, false, false, false, true, false, false, true>, configured5[1], msim::kHeadFLds);
+        } else if (variant & 32) {           // bit 5: hidden-state DMA pieces issued between the k-steps' MFMAs (+ bit 3 rings, + bit 2 epilogue)
+            static std::atomic<int> configured4[6][kMaxDevices];
+            if ((variant & 8) && (variant & 4) && epi2)
+                rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true, false, true>, configured4[0], msim::kHeadFLds)
+                         : go(msim::embed_head_kernel<false, false, false, true, true, false, true>, configured4[1], msim::kHeadFLds);
+            else if (variant & 8)
+                rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, true>, configured4[2], msim::kHeadFLds)
+                         : go(msim::embed_head_kernel<false, false, false, false, true, false, true>, configured4[3], msim::kHeadFLds);
+            else
+                rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, false, false, true>, configured4[4], msim::kHeadLds)
+                         : go(msim::embed_head_kernel<false, false, false, false, false, false, true>, configured4[5], msim::kHeadLds);
+        } else if (variant & 16) {           // bit 4: two half-size workgroups per CU
+            static std::atomic<int> configured3[2][kMaxDevices];
+            rc = f16 ? go_half(msim::embed_head_kernel<true, false, false, false, false, true>, configured3[0])
+                     : go_half(msim::embed_head_kernel<false, false, false, false, false, true>, configured3[1]);
+        } else if ((variant & 8) && (variant & 4) && epi2) {
+            static std::atomic<int> configured2[2][kMaxDevices];
+            rc = f16 ? go(msim::embed_head_kernel<true, false, false, true, true>, configured2[0], msim::kHeadFLds)
+                     : go(msim::embed_head_kernel<false, false, false, true, true>, configured2[1], msim::kHeadFLds);
+        } else if (variant & 8) {
+            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true>, configured[10], msim::kHeadFLds)
+                     : go(msim::embed_head_kernel<false, false, false, false, true>, configured[11], msim::kHeadFLds);
+        } else
+        switch (epi2 ? 4 : (variant & 3)) {
+            case 1: rc = f16 ? go(msim::embed_head_kernel<true, true, false>, configured[0], msim::kHeadFLds)
+                             : go(msim::embed_head_kernel<false, true, false>, configured[1], msim::kHeadFLds); break;
+            case 2: rc = f16 ? go(msim::embed_head_kernel<true, false, true>, configured[2], msim::kHeadLds)
+                             : go(msim::embed_head_kernel<false, false, true>, configured[3], msim::kHeadLds); break;
+            case 3: rc = f16 ? go(msim::embed_head_kernel<true, true, true>, configured[4], msim::kHeadFLds)
+                             : go(msim::embed_head_kernel<false, true, true>, configured[5], msim::kHeadFLds); break;
+            case 4: rc = f16 ? go(msim::embed_head_kernel<true, false, false, true>, configured[8], msim::kHeadLds)
+                             : go(msim::embed_head_kernel<false, false, false, true>, configured[9], msim::kHeadLds); break;
+            default: rc = f16 ? go(msim::embed_head_kernel<true, false, false>, configured[6], msim::kHeadLds)
+                              : go(msim::embed_head_kernel<false, false, false>, configured[7], msim::kHeadLds); break;
+        }
     }
     if (rc) return rc;
     hipError_t e = hipGetLastError();

@@ -11,6 +11,13 @@ constexpr bool kTraceBuild = true;
 #else
 constexpr bool kTraceBuild = false;
 #endif
+// A/B knobs (MSIM_* environment variables), kernel variants that were measured and not kept, and the kernels behind them exist
+// only in measurement builds (`make ab`, `make trace` -> tools/_ab/): the shipped library never reads the environment
+#if defined(MSIM_AB) || defined(MSIM_TRACE)
+constexpr bool kAbBuild = true;
+#else
+constexpr bool kAbBuild = false;
+#endif
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator fragment

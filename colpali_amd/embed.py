@@ -64,20 +64,17 @@ def _padded_map(n: int, device) -> torch.Tensor:
     return torch.full(((n + _TILE - 1) // _TILE * _TILE,), -1, dtype=torch.int32, device=device)
 
 
-_row_id_cache = {}
+_row_id_cache = _lib.StreamConstCache(8)
 
 
 def _row_ids(n: int, device):
     """(arange(n), -2 - arange(n)) as int32 on `device`: the row-map values of kept / zeroed rows of the dense output
-    (read-only constants, cached per size: building them costs more launches than the rest of the wrapper)."""
-    key = (n, str(device))
-    t = _row_id_cache.get(key)
-    if t is None:
-        if len(_row_id_cache) >= 8:
-            _row_id_cache.clear()
+    (read-only constants, cached per size, device and stream: building them costs more launches than the rest of the wrapper)."""
+    def make():
         rows = torch.arange(n, dtype=torch.int32, device=device)
-        t = _row_id_cache[key] = (rows, -2 - rows)
-    return t
+        return rows, -2 - rows
+
+    return _row_id_cache.get(n, device, make)
 
 
 class _EmbeddingHeadFn(torch.autograd.Function):

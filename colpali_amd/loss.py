@@ -203,29 +203,23 @@ def smooth_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
     return scores, lse
 
 
-_all_pairs_cache = {}
+_all_pairs_cache = _lib.StreamConstCache(32)
 
 
 def _all_pairs(B: int, C: int, device: torch.device) -> torch.Tensor:
-    """int32 [B*C, 2]: every (query, doc) pair in row-major order (cached per shape and device)."""
-    key = (B, C, str(device))
-    t = _all_pairs_cache.get(key)
-    if t is None:
-        if len(_all_pairs_cache) > 16:
-            _all_pairs_cache.clear()
+    """int32 [B*C, 2]: every (query, doc) pair in row-major order (a read-only constant, cached per shape, device and stream)."""
+    def make():
         b = torch.arange(B, dtype=torch.int32, device=device).repeat_interleave(C)
         c = torch.arange(C, dtype=torch.int32, device=device).repeat(B)
-        t = _all_pairs_cache[key] = torch.stack([b, c], dim=1).contiguous()
-    return t
+        return torch.stack([b, c], dim=1).contiguous()
+
+    return _all_pairs_cache.get(("pairs", B, C), device, make)
 
 
 def _all_pairs_order(B: int, C: int, device: torch.device) -> torch.Tensor:
     """int32 [B*C]: indices of the row-major all-pairs list sorted by document, then query (what a stable sort by doc gives)."""
-    key = ("order", B, C, str(device))
-    t = _all_pairs_cache.get(key)
-    if t is None:
-        t = _all_pairs_cache[key] = torch.arange(B * C, dtype=torch.int32, device=device).view(B, C).t().contiguous().view(-1)
-    return t
+    return _all_pairs_cache.get(("order", B, C), device,
+                                lambda: torch.arange(B * C, dtype=torch.int32, device=device).view(B, C).t().contiguous().view(-1))
 
 
 def _smooth_backward(qc, dc, offsets, pairs, gp, tau, lse=None, order=None):
@@ -335,19 +329,12 @@ def maxsim_smooth_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.T
     return _MaxSimPairsSmooth.apply(_widen32(query_embeddings), _widen32(doc_embeddings), pairs, float(tau))
 
 
-_epi_ws = {}
-
-
 def _epilogue_workspace(B: int, device: torch.device) -> torch.Tensor:
-    """Zero-filled scratch of msim_loss_epilogue, one per (device, stream): the call leaves it ready for the next one."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    """Zero-filled scratch of msim_loss_epilogue (its ticket counter and per-row terms: cross-workgroup state of ONE launch).
+    Allocated per call -- about 12 * B bytes from the caching allocator, capturable -- so two launches in flight (other
+    streams, threads, replays of captured graphs) can never share a ticket (round-2 advisor finding)."""
     need = _lib.lib().msim_loss_epilogue_workspace_bytes(B)
-    ws = _epi_ws.get(key)
-    if ws is None or ws.numel() < need:
-        if len(_epi_ws) > 32:
-            _epi_ws.clear()
-        ws = _epi_ws[key] = torch.zeros((max(need, 16 + 3 * 4 * 1024),), dtype=torch.uint8, device=device)
-    return ws
+    return torch.zeros((max(need, 16),), dtype=torch.uint8, device=device)
 
 
 MODE_PAIRWISE, MODE_INFONCE = 0, 1
@@ -467,6 +454,29 @@ def maxsim(query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, dense_g
     return _MaxSim.apply(_widen(query_embeddings), _widen(doc_embeddings), dense_grad)
 
 
+_bounds_modules = None
+
+
+def _register_bounds_flush(module) -> None:
+    """Weak registry of modules with reports in flight; flushed once at interpreter exit."""
+    global _bounds_modules
+    if _bounds_modules is None:
+        import atexit
+        import weakref
+
+        _bounds_modules = weakref.WeakSet()
+
+        def _flush_all():
+            for m in list(_bounds_modules):
+                try:
+                    m._flush_bounds(wait=True)
+                except Exception:   # interpreter shutdown: the device may be gone already
+                    pass
+
+        atexit.register(_flush_all)
+    _bounds_modules.add(module)
+
+
 class ColbertModule(torch.nn.Module):
     """Shared hyper-parameters and [B, C]-sized helpers (late_interaction_losses.py:6-107)."""
 
@@ -510,27 +520,43 @@ class ColbertModule(torch.nn.Module):
         if torch.cuda.is_current_stream_capturing():
             return
         self._flush_bounds(wait=False)
-        if getattr(self, "_bounds_pending", None) is not None:
-            return                                           # the previous report is still in flight: keep that one
+        pending = self.__dict__.setdefault("_bounds_pending", [])
+        if len(pending) >= 64:                               # never grow without bound: wait for the oldest report
+            self._flush_bounds(wait=True, only_first=True)
         host = torch.empty((2,), dtype=torch.float32, pin_memory=True)
         host.copy_(lo_hi[-2:], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(lo_hi.device))
-        self._bounds_pending = (host, ev)
+        pending.append((host, ev))
+        _register_bounds_flush(self)
 
-    def _flush_bounds(self, wait: bool = True) -> None:
-        pending = getattr(self, "_bounds_pending", None)
-        if pending is None:
-            return
-        host, ev = pending
-        if wait:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        self._bounds_pending = None
-        lo, hi = float(host[0]), float(host[1])
-        if lo < -self.norm_tol or hi > 1 + self.norm_tol:
-            print(f"Scores out of bounds after normalization: min={lo:.4f}, max={hi:.4f}, tol={self.norm_tol}")
+    def _flush_bounds(self, wait: bool = True, only_first: bool = False) -> None:
+        """Print every queued report whose copy has arrived, in step order (`wait=True`: all of them, blocking)."""
+        pending = self.__dict__.get("_bounds_pending")
+        while pending:
+            host, ev = pending[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            pending.pop(0)
+            lo, hi = float(host[0]), float(host[1])
+            if lo < -self.norm_tol or hi > 1 + self.norm_tol:
+                print(f"Scores out of bounds after normalization: min={lo:.4f}, max={hi:.4f}, tol={self.norm_tol}")
+            if only_first:
+                return
+
+    def flush_bounds(self) -> None:
+        """Block until every pending out-of-bounds report of this module has been printed (the last training step's report has
+        no later step to ride on; this also runs at interpreter exit)."""
+        self._flush_bounds(wait=True)
+
+    def __getstate__(self):
+        # the in-flight diagnostics (pinned buffers, events) are not part of the module: pickle and copy.deepcopy (which goes
+        # through __reduce_ex__ and therefore through here) skip them
+        state = dict(self.__dict__)
+        state.pop("_bounds_pending", None)
+        return state
 
     def _aggregate(self, scores_raw: torch.Tensor, use_smooth_max: bool, dim_max: int, dim_sum: int) -> torch.Tensor:
         reduced = self._smooth_max(scores_raw, dim=dim_max) if use_smooth_max else scores_raw.amax(dim=dim_max)

@@ -44,20 +44,20 @@ def _require_gpu(device: Union[str, torch.device]) -> torch.device:
     return dev
 
 
-_fwd_ws = {}
-
-
 def _fwd_workspace(nbytes: int, device: torch.device) -> Optional[torch.Tensor]:
-    """msim_fwd's scratch (include/maxsim.h: one per stream; the call initialises what it uses), cached per (device, stream)."""
-    if nbytes == 0:
-        return None
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    ws = _fwd_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        if len(_fwd_ws) > 64:
-            _fwd_ws.clear()
-        ws = _fwd_ws[key] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-    return ws
+    """msim_fwd's scratch (include/maxsim.h: one per launch in flight; the call initialises what it uses).  Allocated per
+    call from torch's caching allocator -- stream-ordered reuse, capturable, nothing shared between streams, threads or
+    graph replays."""
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+
+
+def _ref_rounding_from_env() -> bool:
+    """COLPALI_AMD_REF_ROUNDING=1: the drop-in `score_multi_vector` returns what the reference LITERALLY returns for 16-bit
+    embeddings -- every similarity rounded to the input dtype before the max, the token sum rounded to it
+    (processing_utils.py:179 evaluated on bf16 / fp16 tensors) -- instead of the fp32-accurate score (default; the two are
+    4.7e-3 apart on bf16 inputs, SURVEY finding 3).  The reference's signature has no room for the switch, hence the
+    environment; `maxsim_scores(..., ref_rounding=True)` is the explicit form."""
+    return os.environ.get("COLPALI_AMD_REF_ROUNDING", "0") not in ("", "0")
 
 
 def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: bool = False,
@@ -116,11 +116,12 @@ def score_multi_vector(
     if len(ps) == 0:
         raise ValueError("No passages provided")
     dev = _require_gpu(device)
+    ref_rounding = _ref_rounding_from_env()
     q = pack_queries(qs, dev)
     cols = []
     for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
         corpus = pack_passages(ps[lo:hi], dev, batch_size=batch_size)
-        cols.append(maxsim_scores(q, corpus).cpu())
+        cols.append(maxsim_scores(q, corpus, ref_rounding=ref_rounding).cpu())
         del corpus
     scores = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
     assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"

@@ -65,10 +65,11 @@ int msim_abi_version(void);
 const char *msim_last_error(void);
 
 /* Number of bytes of scratch msim_fwd can use for this problem (16-byte aligned device memory, contents irrelevant: the
- * call initialises what it uses on the stream).  Non-zero only when several query blocks stream the same document range
- * (more than 32 token tiles): the workgroups of an XCD then keep in step through progress counters so that the range is
- * fetched from HBM once and served to the others from that XCD's L2.  Passing NULL is legal and only switches that off.
- * One workspace per stream. */
+ * call initialises what it uses on the stream).  Non-zero exactly when several query blocks stream the same document range
+ * (from 33 token tiles up, and for some shapes of 2- and 3-tile queries from 9): the workgroups of an XCD then keep in step
+ * through progress counters so that the range is fetched from HBM once and served to the others from that XCD's L2.
+ * Passing NULL is legal and only switches that off; a non-NULL workspace must hold at least the number of bytes this function
+ * reports for the same problem (4096 whenever it is not 0).  One workspace per stream. */
 size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim);
 
 /*

@@ -38,3 +38,8 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+# the reference's own test files (copied, not committed: tests/reference_suite/README.md) and the stub package they import are
+# run in a subprocess by tests/test_gpu_reference_suite.py, never collected into this session
+collect_ignore = ["_reference_tests", "reference_suite"]

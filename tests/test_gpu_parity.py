@@ -60,6 +60,20 @@ def test_golden_config1_truth_and_literal(amd):
     assert np.mean(lit == z["literal"]) > 0.9
 
 
+def test_literal_tier_is_reachable_through_the_drop_in_signature(amd, monkeypatch):
+    """COLPALI_AMD_REF_ROUNDING=1: score_multi_vector (whose reference signature has no room for a switch) returns what the
+    reference literally returns for bf16 inputs -- the live reference's own bf16 CPU output, score_config1.npz['literal']."""
+    z = load_golden("score_config1.npz")
+    qs, ps = config1_inputs(z)
+    monkeypatch.setenv("COLPALI_AMD_REF_ROUNDING", "1")
+    lit = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(z["literal"]))) - 7)
+    assert np.all(np.abs(lit - z["literal"]) <= ulp) and np.mean(lit == z["literal"]) > 0.9
+    assert np.all(lit == lit.astype(np.float32)) and not close(lit, z["truth"])     # bf16-valued: not the fp32-accurate tier
+    monkeypatch.setenv("COLPALI_AMD_REF_ROUNDING", "0")
+    assert close(amd.score_multi_vector(qs, ps, device="cuda:0").numpy(), z["truth"])
+
+
 def test_golden_negative_similarities_and_zero_padding(amd):
     z = load_golden("score_negative_clamp.npz")
     q, short, long_ = (bits_to_bf16(z[k]) for k in ("q_bits", "short_bits", "long_bits"))

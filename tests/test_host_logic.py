@@ -301,3 +301,64 @@ def test_measurement_tools_parse():
             ast.parse(f.read(), filename=path)
     for path in sorted(glob.glob(os.path.join(root, "*.sh"))):
         assert subprocess.run(["bash", "-n", path]).returncode == 0, path
+
+
+def test_fwd_workspace_bytes_reports_scratch_exactly_when_several_query_blocks_share_a_range():
+    """Round-2 advisor finding: msim_fwd_workspace_bytes must agree with the launch path's use of the workspace (the convoy
+    counters of K1b: needed whenever the plan has more than one query block).  Host-only function, no GPU needed."""
+    L = colpali_amd._lib.lib()
+
+    def ws(n_q, lq, dtype=0, dim=128):
+        return L.msim_fwd_workspace_bytes(dtype, n_q, lq, 1000, dim)
+
+    assert ws(1, 32) == 0 and ws(4, 32) == 0                       # K1s
+    assert ws(8, 32) == 0 and ws(16, 32) == 0 and ws(32, 32) == 0  # one query block (pair / 4-wave / 8-wave form)
+    assert ws(17, 32) == 0 and ws(20, 32) == 0                     # one pass of the 8-wave form since round 3
+    assert ws(33, 32) == 4096 and ws(1000, 32) == 4096
+    # three-tile queries: a wave holds ONE (4 / 3), so 5 queries (15 tiles, 4 waves) and 9..10 (8 waves) are two query blocks
+    assert ws(5, 96) == 4096 and ws(9, 96) == 4096 and ws(10, 96) == 4096
+    assert ws(4, 96) == 0 and ws(6, 96) == 0 and ws(8, 96) == 0    # 12 tiles on 4 waves, 18 / 24 tiles on 8 waves: one block
+    assert ws(17, 64) == 4096 and ws(16, 64) == 0 and ws(8, 64) == 0   # two-tile queries: 16 per 8-wave block
+    assert ws(100, 32, dtype=2) == 0 and ws(100, 32, dim=320) == 0 and ws(100, 200) == 0   # generic / panel kernels: none
+
+
+def test_the_shipped_library_never_reads_the_environment():
+    """A/B knobs and trace hooks are compiled into measurement builds only (make ab / make trace)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--undefined-only", colpali_amd._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out
+    blob = open(colpali_amd._lib.LIB_PATH, "rb").read()
+    assert b"MSIM_HEAD_VARIANT" not in blob and b"MSIM_BATCH_NW" not in blob and b"TRACE_PTR" not in blob
+
+
+def test_library_override_is_confined_to_measurement_builds(monkeypatch, tmp_path):
+    monkeypatch.setenv("COLPALI_AMD_LIB", str(tmp_path / "evil.so"))
+    with pytest.raises(RuntimeError, match="measurement builds"):
+        colpali_amd._lib._lib_path()
+    monkeypatch.setenv("COLPALI_AMD_LIB", os.path.join(ROOT, "tools", "_ab", "libmaxsim_ab.so"))
+    assert colpali_amd._lib._lib_path().endswith(os.path.join("tools", "_ab", "libmaxsim_ab.so"))
+    monkeypatch.delenv("COLPALI_AMD_LIB")
+    assert colpali_amd._lib._lib_path().endswith(os.path.join("csrc", "libmaxsim_gfx950.so"))
+
+
+def test_loss_modules_survive_deepcopy_and_pickle_with_reports_in_flight():
+    import copy
+    import pickle
+    import threading
+
+    m = colpali_amd.ColbertPairwiseCELoss(temperature=0.5)
+    m.__dict__["_bounds_pending"] = [(threading.Lock(), threading.Lock())]     # unpicklable stand-ins for (pinned tensor, event)
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone.temperature == 0.5 and "_bounds_pending" not in clone.__dict__
+        assert clone.state_dict() == {}                                        # zero state, like the reference (:27)
+    assert len(m.__dict__["_bounds_pending"]) == 1
+
+
+def test_stream_const_cache_evicts_oldest_first_and_is_bounded():
+    cache = colpali_amd._lib.StreamConstCache(3)
+    made = []
+    for i in range(5):
+        cache.get(i, "cpu", lambda i=i: made.append(i) or i)
+    assert len(cache) == 3 and made == [0, 1, 2, 3, 4]
+    assert cache.get(4, "cpu", lambda: "new") == 4 and cache.get(0, "cpu", lambda: "again") == "again"

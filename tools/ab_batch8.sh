@@ -1,6 +1,8 @@
 #!/bin/bash
 # K1b (two 256-register waves per SIMD, 4 tiles each) against K1b8 (one 512-register wave per SIMD, 8 tiles) inside ONE gpurun,
 # interleaved twice; the first run writes the reference scores, every later run is compared with them bit for bit.
+# the MSIM_* knobs exist in the measurement build only: `make -C colpali_amd/csrc ab` first
+export COLPALI_AMD_LIB=${COLPALI_AMD_LIB:-tools/_ab/libmaxsim_ab.so}
 set -u
 export AB_DOCS=${AB_DOCS:-65536}
 SIZES=${AB_SIZES:-9,10,12,14,16,20,24,32,64,256,1000}

@@ -16,9 +16,31 @@ def timed(fn, reps=20):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+def ref_loss(kind):
+    """colpali_engine/loss/late_interaction_losses.py:296-313 / :152-164 with the reference's own torch calls (class defaults:
+    normalize_scores=True, temperature 1.0 / 0.02), on this GPU -- the module being replaced, timed beside ours."""
+    def f(q, d):
+        lengths = (q[:, :, 0] != 0).sum(dim=1)
+        raw = torch.einsum("bnd,csd->bcns", q, d)
+        scores = raw.amax(dim=3).sum(dim=2) / lengths.unsqueeze(1)
+        if kind == "ColbertPairwiseCELoss":
+            pos = scores.diagonal()
+            top2 = scores.topk(2, dim=1).values
+            neg = torch.where(top2[:, 0] == pos, top2[:, 1], top2[:, 0])
+            return torch.nn.functional.softplus(neg - pos).mean()
+        return torch.nn.functional.cross_entropy(scores / 0.02, torch.arange(q.shape[0], device=dev))
+    return f
+
+
 for cls in ("ColbertPairwiseCELoss", "ColbertLoss"):
     mod = getattr(amd, cls)()
-    def step(a, b):
+    ref = ref_loss(cls)
+
+    def step(fn, a, b):
         a = a.detach().requires_grad_(True); b = b.detach().requires_grad_(True)
-        mod(a, b).backward()
-    print(f"{cls}: forward direction {timed(lambda: step(queries, pages)):.3f} ms, symmetric direction {timed(lambda: step(pages, queries)):.3f} ms", flush=True)
+        fn(a, b).backward()
+
+    ours_f, ours_s = timed(lambda: step(mod, queries, pages)), timed(lambda: step(mod, pages, queries))
+    ref_f, ref_s = timed(lambda: step(ref, queries, pages)), timed(lambda: step(ref, pages, queries))
+    print(f"{cls:22s} B={B}: forward direction ours {ours_f:.3f} ms / reference module on this GPU {ref_f:.3f} ms;   "
+          f"symmetric direction (pages as queries) ours {ours_s:.3f} ms / reference {ref_s:.3f} ms", flush=True)

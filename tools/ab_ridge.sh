@@ -4,6 +4,8 @@
 # The log committed as profiles/r02_logs/ab_ridge.log was taken with the round-2 development knobs of that commit (32x32x16
 # tiles; K1s up to 8 tiles, two-pass K1b as "default"); this script reproduces the sweep on the current build.
 # Usage on the GPU box:  bash tools/ab_ridge.sh > gpurun_out/ab_ridge.log 2>&1
+# the MSIM_* knobs exist in the measurement build only: `make -C colpali_amd/csrc ab` first
+export COLPALI_AMD_LIB=${COLPALI_AMD_LIB:-tools/_ab/libmaxsim_ab.so}
 set -u
 export AB_DOCS=${AB_DOCS:-65536}
 run() { AB_TAG="$1" python tools/ab_variant.py "$2" 2>&1 | grep -v amdgpu.ids; }

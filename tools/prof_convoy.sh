@@ -1,5 +1,7 @@
 #!/bin/bash
 # HBM traffic of K1b at 1000 queries with and without the convoy: one FETCH_SIZE pass each (separate --pmc runs).
+# the MSIM_* knobs exist in the measurement build only: `make -C colpali_amd/csrc ab` first
+export COLPALI_AMD_LIB=${COLPALI_AMD_LIB:-tools/_ab/libmaxsim_ab.so}
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_convoy
 mkdir -p $OUT
