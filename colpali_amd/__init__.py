@@ -18,7 +18,8 @@ from .loss import (ColbertLoss, ColbertModule, ColbertNegativeCELoss, ColbertPai
                    ColbertPairwiseNegativeCELoss, ColbertSigmoidLoss, maxsim, maxsim_paired)
 from .pooling import HierarchicalTokenPooler, TokenPoolingOutput
 from .patch import patch_colpali_engine, unpatch_colpali_engine
-from .retrieval import ShardedRetriever, merge_gathered, shard_range, shard_topk, topk
+from .retrieval import (ExactMaxSimIndex, ShardedRetriever, create_plaid_index, get_topk_plaid, merge_gathered, shard_range,
+                        shard_topk, topk)
 from .scoring import (get_similarity_maps_from_embeddings, get_torch_device, maxsim_scores, score_multi_vector,
                       score_single_vector, similarity_matrix)
 
@@ -37,6 +38,9 @@ __all__ = [
     "PackedCorpus",
     "maxsim",
     "ShardedRetriever",
+    "ExactMaxSimIndex",
+    "create_plaid_index",
+    "get_topk_plaid",
     "merge_gathered",
     "shard_range",
     "shard_topk",

@@ -5,7 +5,8 @@
 After the call
   * `BaseVisualRetrieverProcessor.score_multi_vector` (inherited by every Col*Processor and reached
     through `processor.score(...)`, e.g. models/paligemma/colpali/processing_colpali.py:96-106)
-    is colpali_amd.score_multi_vector;
+    is colpali_amd.score_multi_vector; `create_plaid_index` / `get_topk_plaid` (:189-244, the reference's only
+    top-k API) build and query the exact resident index instead of fast_plaid's approximate one;
   * `colpali_engine.loss.ColbertPairwiseCELoss` / `ColbertLoss` / `ColbertSigmoidLoss`
     (and the same names in `colpali_engine.loss.late_interaction_losses`) are the fused versions, so
     YAML configs that name the class by dotted path (scripts/configs/qwen2/train_colqwen2_model.yaml:24-25)
@@ -19,6 +20,7 @@ import sys
 
 from . import loss as _loss
 from .pooling import HierarchicalTokenPooler
+from .retrieval import create_plaid_index, get_topk_plaid
 from .scoring import get_similarity_maps_from_embeddings, score_multi_vector, score_single_vector
 
 _LOSS_NAMES = ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss", "ColbertNegativeCELoss",
@@ -34,6 +36,10 @@ def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
         cls.score_multi_vector = staticmethod(score_multi_vector)
         _saved.setdefault("score_single_vector", cls.__dict__["score_single_vector"])
         cls.score_single_vector = staticmethod(score_single_vector)
+        for name, fn in (("get_topk_plaid", get_topk_plaid), ("create_plaid_index", create_plaid_index)):
+            if name in cls.__dict__:                       # the reference's experimental top-k API (processing_utils.py:189-244)
+                _saved.setdefault(name, cls.__dict__[name])
+                setattr(cls, name, staticmethod(fn))
         sm = sys.modules.get("colpali_engine.interpretability.similarity_map_utils")
         if sm is not None:   # only when the user has imported the interpretability helpers
             _saved.setdefault((sm.__name__, "get_similarity_maps_from_embeddings"), sm.get_similarity_maps_from_embeddings)
@@ -58,7 +64,7 @@ def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
 
 def unpatch_colpali_engine() -> None:
     for key, obj in list(_saved.items()):
-        if key in ("score_multi_vector", "score_single_vector"):
+        if key in ("score_multi_vector", "score_single_vector", "get_topk_plaid", "create_plaid_index"):
             pu = importlib.import_module("colpali_engine.utils.processing_utils")
             setattr(pu.BaseVisualRetrieverProcessor, key, obj)
         else:

@@ -132,3 +132,54 @@ class ShardedRetriever:
         scores = self._score(queries, self.shard)
         return shard_topk(scores, k, self.shard.id_base, self.world, self.dist, self.group, self._select,
                           force_collective=self.force_collective)
+
+
+class ExactMaxSimIndex:
+    """What `create_plaid_index` returns here: the resident packed corpus behind the interface the reference's
+    `get_topk_plaid` talks to -- `index.search(queries_embeddings=[n, Lq, dim], top_k=k)` (processing_utils.py:217-220).
+    The reference delegates that call to the third-party `fast_plaid.search.FastPlaid` (not vendored in the reference
+    checkout, unpinned: README.md:108-111 `pip install --no-deps fast-plaid fastkmeans`), an APPROXIMATE centroid-pruned
+    index; this one is exact: fused MaxSim over every page + the deterministic (score desc, id asc) top-k.  `search`
+    returns FastPlaid's published result shape: per query a list of (document id, score) tuples, best first."""
+
+    def __init__(self, corpus: PackedCorpus, world: int = 1, rank: int = 0, dist=None, group=None):
+        self.retriever = ShardedRetriever(corpus, world, rank, dist, group)
+
+    def search(self, queries_embeddings: torch.Tensor, top_k: int = 10):
+        dev = self.retriever.shard.device
+        q = queries_embeddings.to(device=dev, dtype=self.retriever.shard.blob.dtype).contiguous()
+        if q.dim() != 3:
+            raise ValueError("queries_embeddings must be [n_queries, query_length, dim]")
+        top_s, top_i = self.retriever.search(q, k=top_k)
+        top_s, top_i = top_s.cpu().tolist(), top_i.cpu().tolist()
+        return [[(int(i), float(s)) for s, i in zip(row_s, row_i) if i >= 0] for row_s, row_i in zip(top_s, top_i)]
+
+
+def create_plaid_index(ps, device=None) -> ExactMaxSimIndex:
+    """Drop-in for `BaseVisualRetrieverProcessor.create_plaid_index` (processing_utils.py:226-244): same arguments; builds
+    the resident packed corpus instead of a FastPlaid index (see ExactMaxSimIndex).  Like the reference -- which hands
+    FastPlaid the unpadded pages -- no block zero-padding semantics apply here (`batch_size=None`)."""
+    from .corpus import pack_passages
+    from .scoring import _require_gpu, get_torch_device
+
+    if len(ps) == 0:
+        raise ValueError("No passages provided")
+    dev = _require_gpu(device or get_torch_device("auto"))
+    return ExactMaxSimIndex(pack_passages(list(ps) if not isinstance(ps, torch.Tensor) else ps, dev, batch_size=None))
+
+
+def get_topk_plaid(qs, plaid_index, k: int = 10, batch_size: int = 128, device=None):
+    """Drop-in for `BaseVisualRetrieverProcessor.get_topk_plaid` (processing_utils.py:189-223): the same loop over
+    blocks of `batch_size` queries, `pad_sequence(padding_value=0)` per block, one `plaid_index.search(...)` per block,
+    and the same return value: the list of per-block results."""
+    from .scoring import get_torch_device
+
+    device = device or get_torch_device("auto")
+    if len(qs) == 0:
+        raise ValueError("No queries provided")
+    scores_list = []
+    for i in range(0, len(qs), batch_size):
+        block = qs[i: i + batch_size]
+        qs_batch = torch.nn.utils.rnn.pad_sequence(list(block), batch_first=True, padding_value=0).to(device)
+        scores_list.append(plaid_index.search(queries_embeddings=qs_batch, top_k=k))
+    return scores_list

@@ -151,3 +151,28 @@ def test_drop_in_entry_point_ranking_equals_live_reference(amd):
     scores = amd.score_multi_vector(qs, ps, device="cuda:0")
     assert scores.device.type == "cpu" and scores.dtype == torch.float32
     np.testing.assert_array_equal(scores.topk(10, dim=1).indices.numpy(), z["ragged_top10_bs128"])
+
+
+def test_plaid_signature_top_k_is_the_exact_ranking_of_the_live_reference(amd):
+    """The reference's only top-k API (processing_utils.py:189-244: create_plaid_index / get_topk_plaid, experimental,
+    third-party fast_plaid behind it) on its own signature: the index built from the page list, queried in blocks of
+    `batch_size` queries, per block a list (one entry per query) of (document id, score) tuples, best first.  Here the
+    index is exact, so on the planted corpus the ids are the live reference's torch.topk of its full score matrix."""
+    z = load_golden("topk_planted.npz")
+    qs, ps = planted_inputs(z, "ragged")
+    index = amd.create_plaid_index(ps, device="cuda:0")
+    blocks = amd.get_topk_plaid(qs, index, k=10, batch_size=3, device="cuda:0")
+    assert len(blocks) == (len(qs) + 2) // 3 and sum(len(b) for b in blocks) == len(qs)
+    rows = [row for b in blocks for row in b]
+    ids = np.array([[doc for doc, _ in row] for row in rows])
+    np.testing.assert_array_equal(ids, z["ragged_top10"])
+    ref = z["ragged_scores"]
+    for r, row in enumerate(rows):
+        assert all(isinstance(doc, int) and isinstance(s, float) for doc, s in row)
+        assert all(abs(s - ref[r, doc]) <= 1e-5 * max(abs(ref[r, doc]), 1.0) for doc, s in row)
+        assert [s for _, s in row] == sorted((s for _, s in row), reverse=True)
+    with pytest.raises(ValueError, match="No queries"):
+        amd.get_topk_plaid([], index)
+    # k beyond the corpus: every page once, no padding entries
+    small = amd.create_plaid_index(ps[:4], device="cuda:0")
+    assert [len(r) for r in amd.get_topk_plaid(qs[:2], small, k=10)[0]] == [4, 4]
