@@ -548,6 +548,11 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to stdout when the first
+    # communicator is created): keep the real stdout aside and point file descriptor 1 at stderr until the line is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -693,7 +698,8 @@ def main():
     out["regimes"] = regimes
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

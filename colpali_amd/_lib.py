@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def dtype_code(dtype) -> int:
@@ -83,8 +83,10 @@ def lib() -> ctypes.CDLL:
     L.msim_fwd.restype = i32
     L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
     L.msim_pairs_argmax.restype = i32
-    L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.msim_pairs_bwd.restype = i32
+    L.msim_pairs_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.msim_pairs_bwd_workspace_bytes.restype = sz
     f32 = ctypes.c_float
     L.msim_smooth_fwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, f32, vp, i64, vp]
     L.msim_smooth_fwd.restype = i32

@@ -414,17 +414,42 @@ int pairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const i
     }
 }
 
+// dD for SHORT documents with LONG entry lists (the trainer's symmetric direction: maxsim_bwd.hip, dense form): number of splits of
+// every document's pair list, 0 = use the row-range kernel.  A function of the sizes alone (host side, no device read).
+int dd_dense_splits(int n_pairs, int Lq, int n_d, int max_doc_rows, int cus) {
+    if (n_d <= 0 || n_pairs <= 0 || max_doc_rows <= 0 || max_doc_rows > msim::kBwdRows) return 0;
+    const long long entries_per_doc = (long long)n_pairs * Lq / n_d;
+    if (entries_per_doc < 4096) return 0;                        // the row-range kernel is fine: few entries per document
+    const int pairs_per_doc = (n_pairs + n_d - 1) / n_d;
+    int splits = (2 * cus + n_d - 1) / n_d;                       // ~2 workgroups per CU
+    if (splits > pairs_per_doc) splits = pairs_per_doc;           // at least one pair per split
+    if (splits > 64) splits = 64;
+    return splits < 1 ? 1 : splits;
+}
+
+template <int DT>
+void launch_dd_dense(const char *Q, const int32_t *d_off, int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc,
+                     const float *g, const int32_t *argmax, float *dD, float *partial, const msim::PairsArgs &a, int dim, int splits,
+                     hipStream_t st) {
+    const int lds = 2 * max_doc_rows * 128 * (int)sizeof(float);  // <= 64 KiB
+    hipLaunchKernelGGL(msim::maxsim_bwd_dd_dense_kernel<DT>, dim3(a.n_d, splits, (dim + 127) / 128), dim3(256), lds, st, Q, d_off,
+                       pairs, order_by_doc, g, argmax, partial, a, dim, max_doc_rows, splits);
+    hipLaunchKernelGGL(msim::maxsim_bwd_dd_sum_kernel, dim3(a.n_d), dim3(256), 0, st, partial, d_off, dD, a.n_d, dim, max_doc_rows, splits);
+}
+
 template <bool F16>
 void launch_pairs_bwd(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
                       const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
-                      const msim::PairsArgs &a, hipStream_t st) {
+                      const msim::PairsArgs &a, hipStream_t st, float *partial = nullptr, int splits = 0) {
     constexpr int DT = F16 ? msim::kDtypeF16 : msim::kDtypeBf16;
     const char *q = reinterpret_cast<const char *>(Q), *d = reinterpret_cast<const char *>(D);
     if (a.n_q > 0 && a.Lq > 0)
         hipLaunchKernelGGL(msim::maxsim_bwd_dq_kernel<DT>, dim3((a.n_q * a.Lq + 3) / 4), dim3(256), 0, st, d, d_off, pairs, g, argmax,
                            dQ, a, msim::kDim * 2);
     const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
-    if (a.n_d > 0 && ry > 0)
+    if (a.n_d > 0 && ry > 0 && splits > 0 && partial)
+        launch_dd_dense<DT>(q, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dD, partial, a, msim::kDim, splits, st);
+    else if (a.n_d > 0 && ry > 0)
         hipLaunchKernelGGL(msim::maxsim_bwd_dd_kernel<DT>, dim3(a.n_d, ry, 1), dim3(256), 0, st, q, d_off, pairs, order_by_doc, g,
                            argmax, dD, a, msim::kDim);
 }
@@ -507,12 +532,14 @@ int generic_pairs_argmax(const char *Q, const char *D, const int32_t *d_off, con
 template <int DT>
 void generic_pairs_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
                        const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
-                       const msim::PairsArgs &a, int dim, hipStream_t st) {
+                       const msim::PairsArgs &a, int dim, hipStream_t st, float *partial = nullptr, int splits = 0) {
     if (a.n_q > 0 && a.Lq > 0)
         hipLaunchKernelGGL(msim::maxsim_bwd_dq_kernel<DT>, dim3((a.n_q * a.Lq + 3) / 4), dim3(256), 0, st, D, d_off, pairs, g, argmax,
                            dQ, a, dim * msim::elem_size<DT>());
     const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
-    if (a.n_d > 0 && ry > 0)
+    if (a.n_d > 0 && ry > 0 && splits > 0 && partial)
+        launch_dd_dense<DT>(Q, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dD, partial, a, dim, splits, st);
+    else if (a.n_d > 0 && ry > 0)
         hipLaunchKernelGGL(msim::maxsim_bwd_dd_kernel<DT>, dim3(a.n_d, ry, (dim + 127) / 128), dim3(256), 0, st, Q, d_off, pairs,
                            order_by_doc, g, argmax, dD, a, dim);
 }
@@ -871,9 +898,17 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, 
                : pairs_argmax_dispatch<false>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
 }
 
+size_t msim_pairs_bwd_workspace_bytes(int n_q, int Lq, int n_d, int dim, int max_doc_rows, int n_pairs) {
+    (void)n_q;
+    const DeviceInfo *di = nullptr;
+    const int cus = device_info(&di) == MSIM_OK ? di->cus : 256;            // the plan only has to be the same in both calls
+    const int splits = dd_dense_splits(n_pairs, Lq, n_d, max_doc_rows, cus);
+    return splits > 0 && dim > 0 ? (size_t)splits * n_d * max_doc_rows * dim * sizeof(float) : 0;
+}
+
 int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
                    int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g,
-                   const int32_t *argmax, int n_pairs, float *dQ, float *dD, void *stream) {
+                   const int32_t *argmax, int n_pairs, float *dQ, float *dD, void *workspace, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
     if (!dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
     if (n_pairs > 0 && (!pairs || !order_by_doc || !g || !argmax)) return fail(MSIM_EINVAL, "null pair-list argument");
@@ -884,18 +919,27 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, con
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
     const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // short documents with long entry lists (the trainer's symmetric direction): the dense dD form, through the caller's scratch
+    int splits = 0;
+    float *partial = static_cast<float *>(workspace);
+    if (partial) {
+        const DeviceInfo *di = nullptr;
+        if (int rc = device_info(&di)) return rc;
+        splits = dd_dense_splits(n_pairs, Lq, n_d, max_doc_rows, di->cus);
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
+    }
     if (!is_tuned(dtype, dim, Lq)) {
         const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
         if (dtype == MSIM_DTYPE_F32)
-            generic_pairs_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st);
+            generic_pairs_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st, partial, splits);
         else if (dtype == MSIM_DTYPE_F16)
-            generic_pairs_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st);
+            generic_pairs_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st, partial, splits);
         else
-            generic_pairs_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st);
+            generic_pairs_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st, partial, splits);
     } else if (dtype == MSIM_DTYPE_F16)
-        launch_pairs_bwd<true>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);
+        launch_pairs_bwd<true>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st, partial, splits);
     else
-        launch_pairs_bwd<false>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st);
+        launch_pairs_bwd<false>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st, partial, splits);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_bwd launch: %s", hipGetErrorString(e));
     return MSIM_OK;

@@ -129,9 +129,12 @@ def _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax):
     dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
     dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        # scratch of the dense dD form (short documents, long entry lists: the trainer's symmetric direction), per call
+        ws_bytes = L.msim_pairs_bwd_workspace_bytes(B, Lq, C, dim, Ld, pairs.shape[0])
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
         rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
                               _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
-                              _lib.ptr(dq), _lib.ptr(dd), _lib.current_stream_handle(dev))
+                              _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws), _lib.current_stream_handle(dev))
     _lib.check(rc, "msim_pairs_bwd")
     return dq, dd
 

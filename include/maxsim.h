@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 13
+#define MSIM_ABI_VERSION 14
 
 /* error codes */
 #define MSIM_OK 0
@@ -118,12 +118,18 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq,
  * contribution are set to 0).  Deterministic: no floating-point atomics.
  * `pairs` must be sorted by query index; `order_by_doc` is a permutation of 0..n_pairs-1 that
  * sorts the pairs by document index (stable); `max_doc_rows` >= the longest document.
+ * `workspace`: msim_pairs_bwd_workspace_bytes() bytes of 16-byte aligned device scratch (contents irrelevant), or NULL.  It is
+ * non-zero when short documents (<= 64 rows) collect long entry lists -- the symmetric direction of the reference trainer
+ * (trainer/contrastive_trainer.py:202-206: pages as query_embeddings, queries as doc_embeddings): every document's pair list
+ * is then split over several workgroups whose partial sums are added in split order (still deterministic, still no atomics).
+ * NULL is legal and only selects the one-workgroup-per-row-range form (the same values up to fp32 summation order).
  */
+size_t msim_pairs_bwd_workspace_bytes(int n_q, int Lq, int n_d, int dim, int max_doc_rows, int n_pairs);
 int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
                    const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
                    const int32_t *pairs, const int32_t *order_by_doc,
                    const float *g, const int32_t *argmax, int n_pairs,
-                   float *dQ, float *dD, void *stream);
+                   float *dQ, float *dD, void *workspace, void *stream);
 
 /*
  * Smooth-max late interaction (training losses constructed with use_smooth_max=True):
@@ -287,6 +293,11 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
  *   variants 8..11 (rows >= 256 * 16 * 3 * 32 = 393 216): the 16x16x32 mix with MORE waves per SIMD -- 8: 12 waves x 3 tiles, 9: 16 waves x
  *   2 tiles (both A from LDS + folds), 10 / 11: the same two shapes with everything in registers.  FLOP = 256 x 12 x iters x 48 x 16384
  *   (8, 10) resp. 256 x 16 x iters x 32 x 16384 (9, 11).
+ *   variants 12..23 (round 3, iters even): msim_fwd's EXACT slab body (8 fragment reads per 32-row slab, then per token tile 16
+ *   v_mfma_f32_16x16x32 + 8 v_max3) under other register plans -- 12: the shipped plan (8 waves x 4 tiles), 16: the same with the
+ *   fragments in registers, 17: 4 waves x 4 tiles; 13 / 15: ONE 512-register wave per SIMD x 8 / 6 tiles (B operands in AGPRs),
+ *   14: 13 with the fragments in registers, 18 / 19: 13 / 15 with the next slab's fragments prefetched, 20 / 21 / 22: + the fold
+ *   of tile t-1 under tile t (21: interleave pinned), 23: 14 with deferred folds.  FLOP = 256 x waves x iters x tiles x 16 x 16384.
  */
 int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *sink, void *stream);
 

@@ -498,7 +498,7 @@ def test_loss_is_fp32_under_autocast_like_the_reference(amd):
 @pytest.mark.parametrize("cls,kind", [("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_symmetric_loss_documents_in_the_query_slot(amd, cls, kind, dtype):
-    """trainer/contrastive_trainer.py:201-205 (`compute_symetric_loss`): the second term is
+    """trainer/contrastive_trainer.py:202-206 (`compute_symetric_loss`): the second term is
     `_compute_loss_from_outputs(doc_outputs, query_outputs)` -- the loss called with the PAGES as `query_embeddings`
     ([B, 780, 128]: 25 token tiles per "query", beyond the tuned kernels' 4) and the queries as `doc_embeddings`
     ([B, 32, 128]).  Same oracle, same tolerances as the forward direction."""
@@ -529,3 +529,48 @@ def test_symmetric_loss_documents_in_the_query_slot(amd, cls, kind, dtype):
             assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6, kw
             assert grads_close(p.grad, want_dp, p_real.expand_as(want_dp)), kw
             assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq)), kw
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_dense_dd_form_equals_the_row_range_form_and_the_float64_scatter(amd, dtype):
+    """msim_pairs_bwd with and without its workspace: short documents (32 rows) that collect long entry lists (all pairs of
+    780-token 'queries': the trainer's symmetric direction) take the dense dD form when scratch is passed -- every document's
+    pair list split over several workgroups, partial sums added in split order -- and the one-workgroup-per-row-range form
+    without.  Both must equal the float64 scatter-add of g[p] * Q[b_p, i, :] into row argmax[p, i] of document c_p."""
+    from colpali_amd import _lib, loss as L_
+
+    g = torch.Generator().manual_seed(3)
+    B, C, Lq, Ld = 9, 7, 780, 32
+    q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1).to(dtype).cuda()
+    d = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1).to(dtype).cuda()
+    d[2, 20:] = 0                                                          # a document with zero padding rows
+    gp = torch.randn(B * C, generator=g).cuda()
+    pairs, order = L_._all_pairs(B, C, q.device), L_._all_pairs_order(B, C, q.device)
+    offsets = L_._dense_corpus(d).offsets
+    _, argmax = L_.maxsim_pairs(q, d, offsets, pairs, want_scores=False)
+    lib = _lib.lib()
+    assert lib.msim_pairs_bwd_workspace_bytes(B, Lq, C, 128, Ld, B * C) > 0
+    assert lib.msim_pairs_bwd_workspace_bytes(32, 32, 256, 128, 780, 64) == 0          # config 5, forward direction: no scratch
+    outs = []
+    for use_ws in (True, False):
+        dq = torch.full((B, Lq, 128), float("nan"), device=q.device)
+        dd = torch.full((C, Ld, 128), float("nan"), device=q.device)
+        nbytes = lib.msim_pairs_bwd_workspace_bytes(B, Lq, C, 128, Ld, B * C)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device) if use_ws else None
+        rc = lib.msim_pairs_bwd(_lib.dtype_code(dtype), _lib.ptr(q), B, Lq, _lib.ptr(d), _lib.ptr(offsets), C, 128, Ld, _lib.ptr(pairs),
+                                _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), B * C, _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws),
+                                _lib.current_stream_handle(q.device))
+        _lib.check(rc, "msim_pairs_bwd")
+        outs.append((dq.cpu(), dd.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])                            # dQ does not depend on the dD form
+    want = torch.zeros(C, Ld, 128, dtype=torch.float64)
+    am, pr, gg, qq = argmax.cpu().long(), pairs.cpu().long(), gp.cpu().double(), q.cpu().double()
+    for p in range(B * C):
+        b, c = int(pr[p, 0]), int(pr[p, 1])
+        rows = am[p]
+        ok = rows >= 0
+        want[c].index_add_(0, rows[ok], gg[p] * qq[b][ok])
+    scale = float(want.abs().max())
+    for dq, dd in outs:
+        assert torch.isfinite(dd).all()
+        assert float((dd.double() - want).abs().max()) <= 2e-6 * scale
