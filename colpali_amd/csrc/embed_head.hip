@@ -99,8 +99,11 @@ struct HeadArgs {
 //       stores whole 256-byte rows: 8 store instructions per lane and tile, full 128-byte lines.  That alone changed nothing; what the
 //       stores cost is their way through L2 / MALL next to the streaming reads: with `nt` on them +4 % (H = 2048), +8-12 % (1536),
 //       +13-14 % (3584) -- and the whole-row form gains 2-4 % more than the 2-byte form under the same policy.
+// PAIR (round 3, measurement builds): the hidden-state chunks are requested TWO AT A TIME, every other iteration, piece by piece
+//       (rows 8i..8i+7 of chunk c, then the same rows of chunk c + 1): the two 128-byte pieces of a row reach the memory system back
+//       to back, 256 contiguous bytes of one DRAM page instead of two visits a chunk period apart.  Hidden-state ring 4, weight ring 2.
 template <bool F16, bool FLAGS = false, bool PIPE = false, bool EPI2 = false, bool DEEPW = false, bool HALF = false, bool IL = false,
-          bool EPI3 = false>
+          bool EPI3 = false, bool PAIR = false>
 __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(const uint16_t *__restrict__ X,     // [M, H]
                                                                      const uint16_t *__restrict__ W,     // [128, H]
                                                                      const uint16_t *__restrict__ bias,  // [128] or null
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
     static_assert(!HALF || (!FLAGS && !DEEPW), "HALF has its own ring plan");
     static_assert(!IL || (!FLAGS && !PIPE && !HALF), "IL is built on the barrier form with the compiler's operand schedule");
     static_assert(!EPI3 || (!FLAGS && !EPI2 && !HALF && !IL), "EPI3 stages through the slot the barrier form refills at the top of the next chunk");
+    static_assert(!PAIR || (!FLAGS && !DEEPW && !HALF && !IL), "PAIR is built on the 4 + 2 ring plan of the barrier form");
     constexpr int kHeadWaves = HALF ? 4 : 8;                 // compute waves (shadows the namespace constants below)
     constexpr int kHeadBM = kHeadWaves * 32;
     constexpr int kHeadABytes = kHeadBM * kHeadBK * 2;
@@ -268,8 +272,28 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
         produce_advance();
         return true;
     };
+    // PAIR: two chunks at once, their pieces interleaved row group by row group
+    auto produce2 = [&]() {
+        char *dst[2];
+        int soff[2];
+        bool live[2];
+        __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
-    for (int i = 0; i < kRingA - 1; ++i) produce();
+        for (int k = 0; k < 2; ++k) {
+            live[k] = p_tile < n_tiles;
+            dst[k] = smem + p_slot * kHeadABytes + a_dst;
+            soff[k] = p_chunk * (kHeadBK * 2);
+            rs[k] = a_rsrc;
+            if (live[k]) produce_advance();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (live[k]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[k], MSIM_LDS(dst[k] + i * 1024), 16, a_src[i], soff[k], 0, 2);
+    };
+#pragma unroll
+    for (int i = 0; i < (PAIR ? 2 : kRingA - 1); ++i) produce();
 
     int c_slot = 0, c_count = 0, w_slot = 0, seen_ready = 0;
     unsigned long long tr_issue = 0, tr_vm = 0, tr_bar = 0, tr_comp = 0, tr_epi = 0;
@@ -293,11 +317,21 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
                 if (ahead >= kRingA - 2) wait_vmcnt<4 * (kRingA - 2)>();
                 else if (kRingA > 3 && ahead == 1) wait_vmcnt<4>();
                 else wait_vmcnt<0>();
+            } else if constexpr (PAIR) {
+                if ((c_count & 1) == 0) produce2();
             } else {
                 issued = produce();
             }
             const unsigned long long t1 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            if constexpr (!IL) {
+            if constexpr (PAIR) {
+                // loads retire in order: the youngest 4 * ahead are the chunks behind the one about to be read (an epilogue's stores
+                // among them only make the wait longer, never shorter)
+                const int ahead = p_issued - c_count - 1;
+                if (ahead >= 3) wait_vmcnt<12>();
+                else if (ahead == 2) wait_vmcnt<8>();
+                else if (ahead == 1) wait_vmcnt<4>();
+                else wait_vmcnt<0>();
+            } else if constexpr (!IL) {
                 if (issued) wait_vmcnt<4 * (kRingA - 1)>(); else wait_vmcnt<0>();
             }
             const unsigned long long t2 = tracing ? __builtin_amdgcn_s_memtime() : 0;

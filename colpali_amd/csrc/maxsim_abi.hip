@@ -1201,7 +1201,12 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         // bit 3: loader two weight chunks ahead (rings 3 + 3)
         // bit 6 (default): output rows staged through LDS and stored as whole rows; needs 16-byte aligned rows, else the 2-byte form
         const bool epi3 = (variant & 64) && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-        if (epi3) {
+        static const int pair_env = ab_env("MSIM_HEAD_PAIR", 0);       // round 3: chunks requested two at a time (rings 4 + 2, whole-row stores)
+        if (pair_env && epi3) {
+            static std::atomic<int> configured6[2][kMaxDevices];
+            rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, false, false, false, true, true>, configured6[0], msim::kHeadLds)
+                     : go(msim::embed_head_kernel<false, false, false, false, false, false, false, true, true>, configured6[1], msim::kHeadLds);
+        } else if (epi3) {
             static std::atomic<int> configured5[2][kMaxDevices];
             rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true, false, false, true>, configured5[0], msim::kHeadFLds)
                      : go(msim::embed_head_kernel<false, false, false, false, true, false, false, true>, configured5[1], msim::kHeadFLds);
