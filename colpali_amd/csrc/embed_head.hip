@@ -66,6 +66,8 @@ struct HeadArgs {
     int H;                // hidden size (multiple of 64)
     long long ld_out;     // elements between consecutive output rows (>= 128)
     unsigned long long *trace;   // debug (MSIM_HEAD_TRACE_PTR): per wave of workgroup 0, cycles spent per phase; null in production
+    int stagger;                 // > 0: workgroup b delays its start by (b % stagger) * stagger_sleep x ~64 cycles (see the kernel's prologue)
+    int stagger_sleep;
 };
 
 // row_map[m] (int32, ceil(M / 256) * 256 entries):  v >= 0: write the normalised row to out row v;
@@ -142,6 +144,17 @@ __global__ __launch_bounds__(HALF ? 320 : kHeadThreads) void embed_head_kernel(c
     // One LDS-DMA wave-instruction fills 1 KiB = 8 rows x 128 B linearly: lane -> (row = lane >> 3, physical chunk lane & 7).
     const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int total = my_tiles * n_chunks;                                   // chunks this workgroup walks (= its barriers)
+
+    // Start-up stagger.  Every workgroup walks the K chunks of its rows in the same order and at the same pace, so at any instant the
+    // WHOLE CHIP requests bytes at one offset (mod the row stride) of 65 536 different rows.  When the row stride is a multiple of
+    // 4 KiB (hidden 2048, 4096) those addresses differ only above bit 12 and camp on a fraction of the memory channels: the bare access
+    // pattern loses 14 % there (tools/probe_strides.py: 6.04 TB/s at a 4096-byte stride, 7.06 at 4224).  Delaying workgroup b by
+    // (b % stagger) chunk periods puts the workgroups at different K offsets for the rest of the launch -- without touching the order
+    // in which any row accumulates its chunks (results are bit-identical by construction).
+    if (a.stagger > 1) {
+        const int phase = (int)(blockIdx.x % (unsigned)a.stagger);
+        for (int i = 0; i < phase * a.stagger_sleep; ++i) __builtin_amdgcn_s_sleep(64);
+    }
 
     if constexpr (FLAGS) {
         if (threadIdx.x < 16) f_ready[threadIdx.x] = 0;      // the only workgroup barrier of the kernel: counters zeroed

@@ -1154,6 +1154,8 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     a.H = H;
     a.ld_out = ld_out;
     a.trace = nullptr;
+    a.stagger = ab_env("MSIM_HEAD_STAGGER", 0);
+    a.stagger_sleep = ab_env("MSIM_HEAD_STAGGER_SLEEP", 1);
     if constexpr (msim::kTraceBuild) {                       // `make trace` only: device address of 9 x 8 uint64 (tools/trace_head.py)
         if (const char *tp = getenv("MSIM_HEAD_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
     }
