@@ -1378,6 +1378,7 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
     switch (variant) {
         case MSIM_PROBE_ROWS256B: piece = 256; tile_rows = 128; break;
         case MSIM_PROBE_PIECES128B: piece = 128; break;
+        case 11: case 12: case 13: piece = 128; break;          // round 3: the 128-byte pattern with other lane -> (row, chunk) mappings
         case MSIM_PROBE_PIECES512B: piece = 512; tile_rows = 128; break;
         default: return fail(MSIM_EINVAL, "unknown probe variant %d", variant);
     }
@@ -1388,6 +1389,9 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
     switch (variant) {
         case MSIM_PROBE_ROWS256B: rc = run_probe<256, 32, 4, 4>(x, rows, row_elems, sink, st); break;     // K1s: 4 waves, 4 slabs of 8 KiB each
         case MSIM_PROBE_PIECES128B: rc = run_probe<128, 32, 4, 8>(x, rows, row_elems, sink, st); break;   // K3's hidden-state stream
+        case 11: rc = run_probe<128, 32, 4, 8, 1>(x, rows, row_elems, sink, st); break;   // 128-byte pieces, rows of an instruction 16 KiB apart
+        case 12: rc = run_probe<128, 32, 4, 8, 2>(x, rows, row_elems, sink, st); break;   // ... every row of an instruction at another K chunk
+        case 13: rc = run_probe<128, 32, 4, 8, 3>(x, rows, row_elems, sink, st); break;   // ... every instruction of a wave at another K chunk
         default: rc = run_probe<512, 16, 2, 8>(x, rows, row_elems, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_stream_kernel launch failed (variant %d)", variant);

@@ -11,12 +11,13 @@ dev = torch.device("cuda:0")
 L = amd._lib.lib()
 sink = torch.zeros(4, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream()
-for H in (1536, 1984, 2048, 2112, 2560, 3072, 3584, 4096):
+for H in [int(x) for x in os.environ.get("PS_WIDTHS", "1536,1984,2048,2112,2560,3072,3584,4096").split(",")]:
     rows = (2 << 30) // (2 * H) // 256 * 256
     x = torch.empty((rows, H), dtype=torch.bfloat16, device=dev).normal_()
     line = f"row width {H:5d} ({2 * H:5d} B stride), {rows * 2 * H / 2**30:.2f} GiB:"
-    for variant, name in ((1, "128-B pieces x 32 rows"), (0, "256-B pieces x 32 rows"), (2, "512-B pieces x 16 rows")):
-        piece = {1: 128, 0: 256, 2: 512}[variant]
+    for variant, name in ((1, "128-B x 32 rows"), (0, "256-B x 32 rows"), (2, "512-B x 16 rows"), (11, "128-B, rows 16 KiB apart"),
+                          (12, "128-B, chunk skewed per row"), (13, "128-B, chunk skewed per instruction")):
+        piece = {1: 128, 0: 256, 2: 512, 11: 128, 12: 128, 13: 128}[variant]
         if (2 * H) % piece:
             line += f"   {name}: n/a"
             continue
