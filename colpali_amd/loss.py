@@ -108,7 +108,10 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
     the list (zero gradients contribute zero): no data-dependent count, hence no host synchronisation.  `argmax_all`: the
     [B*C, Lq] routing in row-major order when the forward kept it; otherwise it is recomputed here (one pass of the
     arg-max pair kernel, about the cost of the forward).  The losses whose gradient is 2-sparse per query (pairwise) do not
-    come through here: their epilogue kernel hands the backward its 2B pairs directly (_FusedInBatchLoss)."""
+    come through here: their epilogue kernel hands the backward its 2B pairs directly (_FusedInBatchLoss).
+    Cost, whatever the sparsity of `grad_scores`: a [B*C, Lq] int32 routing tensor (4 * B * C * Lq bytes: 1 MiB at B = 32,
+    C = 256, Lq = 32) and a B*C-pair gather / scatter -- the price of never reading a count back.  A pair with gradient 0
+    contributes 0 * row, i.e. NaN if that row holds inf / NaN, exactly like the dense matmuls of the reference's autograd."""
     B, C = qc.shape[0], dc.shape[0]
     dev = qc.device
     if B * C == 0:
