@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe_mix_kernel(const 
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int ks = 0; ks < kKSteps16; ++ks) {
-                if (t >= 4) asm volatile("" : "+a"(qt[t].f[h][ks]));
+                if (t >= ((WAVES == 8 && NT > 4) ? 1 : 4)) asm volatile("" : "+a"(qt[t].f[h][ks]));   // 5 tiles on two waves per SIMD: 4 of them in AGPRs
                 else asm volatile("" : "+v"(qt[t].f[h][ks]));
             }
     char *slab = smem + wave * kSlabBytes;

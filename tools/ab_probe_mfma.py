@@ -8,7 +8,7 @@ import bench, colpali_amd as amd
 
 dev = torch.device("cuda:0")
 L = amd._lib.lib()
-rows = 256 * 16 * 4 * 32
+rows = 256 * 16 * 4 * 32          # >= 256 x 8 x (5 + 1) x 32 for the five-tile plan
 g = torch.Generator(device=dev).manual_seed(1)
 X = torch.nn.functional.normalize(torch.randn((rows, 128), generator=g, device=dev), dim=-1).to(torch.bfloat16)
 Z = torch.zeros_like(X)
@@ -23,7 +23,7 @@ for data, name in ((X, "random unit rows"), (Z, "zeros")):
                           (13, "K1b body: 4 waves x 8 tiles"), (14, "K1b body, 4x8, A in registers"), (15, "K1b body: 4 waves x 6 tiles"),
                           (18, "K1b body 4x8 + prefetch"), (19, "K1b body 4x6 + prefetch"),
                           (20, "4x8 + prefetch + deferred fold"), (21, "4x8 + pf + deferred, pinned"), (22, "4x6 + pf + deferred fold"),
-                          (23, "4x8 A in regs, deferred fold"))[int(os.environ.get("PROBE_FROM", "0")):]:
+                          (23, "4x8 A in regs, deferred fold"), (24, "K1b body: 8 waves x 5 tiles"))[int(os.environ.get("PROBE_FROM", "0")):]:
         for iters in (20000,):
             ms = []
             for i in range(5):
@@ -36,7 +36,7 @@ for data, name in ((X, "random unit rows"), (Z, "zeros")):
                 if i >= 1:
                     ms.append(a.elapsed_time(b))
             t = sorted(ms)[len(ms) // 2]
-            mix = {12: (8, 4), 16: (8, 4), 17: (4, 4), 13: (4, 8), 14: (4, 8), 15: (4, 6), 18: (4, 8), 19: (4, 6), 20: (4, 8), 21: (4, 8), 22: (4, 6), 23: (4, 8)}
+            mix = {12: (8, 4), 16: (8, 4), 17: (4, 4), 13: (4, 8), 14: (4, 8), 15: (4, 6), 18: (4, 8), 19: (4, 6), 20: (4, 8), 21: (4, 8), 22: (4, 6), 23: (4, 8), 24: (8, 5)}
             if variant in mix:
                 flop = 256 * mix[variant][0] * iters * mix[variant][1] * 16 * 16384
             else:
