@@ -102,6 +102,14 @@ bool is_tuned(int dtype, int dim, int Lq) {
            (Lq + msim::kTokTile - 1) / msim::kTokTile <= 4;
 }
 
+// queries longer than 128 tokens in the tuned dtype / width: scored as 128-token segments on K1b (MaxSim is a sum over query
+// tokens) when the caller passes scratch for the partial sums; otherwise (and for every other shape) the generic kernels take them
+constexpr int kLongSegRows = 4 * msim::kTokTile;
+bool is_long_tuned(int dtype, int dim, int Lq) {
+    return (dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) && dim == msim::kDim && Lq > kLongSegRows;
+}
+int long_segments(int Lq) { return (Lq + kLongSegRows - 1) / kLongSegRows; }
+
 int elem_bytes(int dtype) { return dtype == MSIM_DTYPE_F32 ? 4 : 2; }
 
 int check_common(const void *Q, const void *D, const int32_t *d_off, int dtype, int dim, int Lq) {
@@ -133,6 +141,7 @@ struct FwdCall {
     const DeviceInfo *di;
     hipStream_t st;
     void *workspace = nullptr;   // msim_fwd_workspace_bytes() bytes or null
+    int n_seg = 1;               // > 1: n_q counts 128-token segments of n_q / n_seg long queries (BatchArgs::n_seg)
 };
 
 constexpr size_t kFwdWorkspaceBytes = 4096;   // K1b's convoy counters: n_ranges * n_qblocks <= 8 * 64 ints
@@ -210,6 +219,7 @@ int launch_batch(const FwdCall &c) {
     a.Lq = c.Lq;
     a.n_d = c.n_d;
     a.flags = c.flags;
+    a.n_seg = c.n_seg;
     const int q_per_block = NW * (4 / TPQ);                         // at most; the kernel splits n_q evenly over the blocks
     a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
@@ -800,7 +810,10 @@ size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim) {
     // the only scratch msim_fwd uses: the progress counters of K1b's convoy, needed once more than one query block streams a
     // document range (bf16 / fp16, width 128).  Passing NULL instead only switches the convoy off; a non-null workspace must hold
     // at least the bytes reported here (4096 whenever it is non-zero).
-    if (n_q <= 0 || n_d <= 0 || Lq <= 0 || !is_tuned(dtype, dim, Lq)) return 0;
+    if (n_q <= 0 || n_d <= 0 || Lq <= 0) return 0;
+    if (is_long_tuned(dtype, dim, Lq))                                              // segments on K1b: counters + the partial sums
+        return kFwdWorkspaceBytes + (size_t)n_q * long_segments(Lq) * n_d * sizeof(float);
+    if (!is_tuned(dtype, dim, Lq)) return 0;
     const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
     if ((long long)n_q * tpq <= 4) return 0;                                        // K1s: no scratch
     return batch_plan(n_q, tpq).n_qblocks > 1 ? kFwdWorkspaceBytes : 0;             // exactly launch_batch's condition
@@ -832,6 +845,42 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
             c.st = static_cast<hipStream_t>(stream);
             return dtype == MSIM_DTYPE_F16 ? panels_dispatch<true>(c) : panels_dispatch<false>(c);
         }
+    }
+    if (is_long_tuned(dtype, dim, Lq) && workspace != nullptr && (long long)n_q * long_segments(Lq) <= 0x7fffffff / 8) {
+        // long queries (pages as queries, image-to-image retrieval, the trainer's symmetric direction): 128-token segments on K1b,
+        // partial token sums into the scratch, added in segment order -- 3-4 x the generic kernels' rate on a large corpus
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
+        const int n_seg = long_segments(Lq);
+        float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + kFwdWorkspaceBytes);
+        FwdCall c;
+        if (int rc = device_info(&c.di)) return rc;
+        c.Q = static_cast<const uint16_t *>(Q);
+        c.D = static_cast<const uint16_t *>(D);
+        c.d_off = d_off;
+        c.clamp0 = d_clamp0;
+        c.scores = partial;
+        c.ld = n_d;
+        c.n_q = n_q * n_seg;
+        c.Lq = Lq;
+        c.n_d = n_d;
+        c.flags = flags | msim::kFlagPartial;
+        c.st = static_cast<hipStream_t>(stream);
+        c.workspace = workspace;
+        c.n_seg = n_seg;
+        const bool f16 = dtype == MSIM_DTYPE_F16;
+        if (int rc = f16 ? batch_dispatch<4, true>(c) : batch_dispatch<4, false>(c)) return rc;
+        const dim3 grid((n_d + 255) / 256, n_q);
+        const bool round_total = (flags & MSIM_FLAG_REF_ROUNDING) != 0;
+        if (n_q > 65535) return fail(MSIM_EUNSUPPORTED, "too many long queries (%d) for one launch", n_q);
+        if (f16)
+            hipLaunchKernelGGL(msim::segment_sum_kernel<true>, grid, dim3(256), 0, c.st, partial, (long long)n_d, n_seg, n_d, scores,
+                               (long long)ld_scores, round_total);
+        else
+            hipLaunchKernelGGL(msim::segment_sum_kernel<false>, grid, dim3(256), 0, c.st, partial, (long long)n_d, n_seg, n_d, scores,
+                               (long long)ld_scores, round_total);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "segment_sum_kernel launch: %s", hipGetErrorString(e));
+        return MSIM_OK;
     }
     if (!is_tuned(dtype, dim, Lq)) {
         GenericCall c;

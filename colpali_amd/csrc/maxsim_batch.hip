@@ -7,7 +7,7 @@
 //     each = 32 VGPRs) in registers as MFMA B operands and scores them against every slab of the stream:
 //       NW = 2 ("pair", 5..8 tiles):  four pairs per CU -- two waves per SIMD at <= 256 registers where one wave holding all
 //               8 tiles needs 300+ and runs alone on its SIMD; one 32-row slab per barrier, and the barrier spans two waves only;
-//       NW = 4 (9..20 tiles):         two workgroups per CU, 64-row chunks: one computes while the other sits at its barrier;
+//       NW = 4 (9..16 tiles):         two workgroups per CU, 64-row chunks: one computes while the other sits at its barrier;
 //       NW = 8 (more):                one workgroup per CU, 128-row chunks, up to 32 tiles per query block -- the fewest passes
 //               over the corpus;
 //     the queries are split EVENLY over the query blocks and dealt to the waves of a block round-robin (query j of the block ->
@@ -41,6 +41,8 @@ constexpr int kBatchLds = kBatchRing * kChunkBytes;      // 96 KiB
 struct BatchArgs {
     long long ld;        // leading dimension of scores
     int n_q, Lq, n_d;
+    int n_seg;           // > 1: the n_q "queries" are 128-token SEGMENTS of n_q / n_seg real queries of Lq tokens each (segment s of query r
+                         // = rows 128 s .. of it; the last one may be shorter); scores row = the segment's index (msim_fwd sums the segments)
     int n_qblocks;       // query blocks: block b holds n_q / n_qblocks (+1 for the first n_q % n_qblocks) queries, <= 8 * (4 / TPQ)
     int n_ranges;        // document ranges (multiple of 8: XCD x owns ranges x*sub .. x*sub+sub-1)
     unsigned flags;
@@ -123,8 +125,12 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
 #pragma unroll
     for (int t = 0; t < NTMAX; ++t) {
         const bool live = t / TPQ < my_q;
-        const int q = qb0 + wave + kB1Waves * (t / TPQ);
-        load_query_tile(qt[t], Q + (size_t)(live ? q : 0) * a.Lq * kDim, (t % TPQ) * kTokTile, a.Lq, lane, live);
+        const int q = live ? qb0 + wave + kB1Waves * (t / TPQ) : 0;
+        const int n_seg = a.n_seg > 1 ? a.n_seg : 1;
+        const int seg_rows = n_seg > 1 ? TPQ * kTokTile : a.Lq;           // long queries: segments of TPQ = 4 tiles
+        const int qr = q / n_seg, sg = q - qr * n_seg;
+        const int valid = a.Lq - sg * seg_rows < seg_rows ? a.Lq - sg * seg_rows : seg_rows;
+        load_query_tile(qt[t], Q + ((size_t)qr * a.Lq + (size_t)sg * seg_rows) * kDim, (t % TPQ) * kTokTile, valid, lane, live);
     }
     wait_vmcnt<0>();
 #pragma unroll
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
                     float tot = 0.0f;
 #pragma unroll
                     for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[qq * TPQ + tt];
-                    if (ref_bf16) tot = round_to_input<F16>(tot);
+                    if (ref_bf16 && !(a.flags & kFlagPartial)) tot = round_to_input<F16>(tot);
                     scores[(size_t)(qb0 + wave + kB1Waves * qq) * a.ld + c_idx] = tot;
                 }
             }
@@ -308,6 +314,22 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         case 3: if constexpr (QPW >= 3) run(std::integral_constant<int, 3 * TPQ>{}); break;
         default: if constexpr (QPW >= 4) run(std::integral_constant<int, 4 * TPQ>{}); break;
     }
+}
+
+// scores[q, c] = sum over the segments s of partial[q * n_seg + s, c], in segment order (long queries: msim_fwd scores them as
+// 128-token segments on K1b and adds the partial token sums here); `round_f16` / `round_bf16`: the literal tier's rounding of the
+// token sum to the embedding dtype, applied once, to the total
+template <bool F16>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ partial, long long ld_part, int n_seg, int n_d,
+                                                          float *__restrict__ scores, long long ld, bool round_total) {
+    const int q = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_d) return;
+    const float *p = partial + (size_t)q * n_seg * ld_part + c;
+    float acc = 0.0f;
+    for (int s = 0; s < n_seg; ++s) acc += p[(size_t)s * ld_part];
+    if (round_total) acc = round_to_input<F16>(acc);
+    scores[(size_t)q * ld + c] = acc;
 }
 
 }  // namespace msim

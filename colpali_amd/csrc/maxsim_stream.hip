@@ -36,6 +36,7 @@ struct StreamArgs {
 };
 
 constexpr unsigned kFlagRefBf16 = 1u;
+constexpr unsigned kFlagPartial = 2u;     // internal (long queries scored in 128-token segments): the token sum is a PARTIAL sum, not rounded here
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

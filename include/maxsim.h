@@ -68,8 +68,12 @@ const char *msim_last_error(void);
  * call initialises what it uses on the stream).  Non-zero exactly when several query blocks stream the same document range
  * (from 33 token tiles up, and for some shapes of 2- and 3-tile queries from 9): the workgroups of an XCD then keep in step
  * through progress counters so that the range is fetched from HBM once and served to the others from that XCD's L2.
- * Passing NULL is legal and only switches that off; a non-NULL workspace must hold at least the number of bytes this function
- * reports for the same problem (4096 whenever it is not 0).  One workspace per stream. */
+ * Queries longer than 128 tokens (bf16 / f16, width 128: pages as queries, the trainer's symmetric direction) are scored as
+ * 128-token segments on the tuned kernels -- MaxSim is a sum over query tokens -- and need room for the partial sums:
+ * 4096 + n_q * ceil(Lq / 128) * n_d * 4 bytes.
+ * Passing NULL is legal and only switches those off (no convoy; long queries take the generic kernels: the same scores up to fp32
+ * summation order, 3-4 x slower on a large corpus); a non-NULL workspace must hold at least the number of bytes this function
+ * reports for the same problem.  One workspace per launch in flight. */
 size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim);
 
 /*

@@ -359,3 +359,38 @@ def test_dim320_many_documents_and_literal_rounding(amd):
     want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], mode="bf16ref")
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-3))) - 7)
     assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
+
+
+@pytest.mark.parametrize("n_q,lq,n_d,ld_max,dtype", [
+    (3, 780, 200, 300, torch.bfloat16),       # pages as queries: 7 segments, the last one of 12 tokens
+    (2, 129, 150, 700, torch.bfloat16),       # one token beyond a segment
+    (5, 200, 64, 100, torch.float16),         # 128 + 72
+    (11, 256, 300, 64, torch.bfloat16),       # exactly two full segments; 22 pseudo-queries = 88 tiles: three query blocks
+])
+def test_long_queries_score_as_segments_on_the_tuned_kernels(amd, n_q, lq, n_d, ld_max, dtype):
+    """Queries longer than 128 tokens (bf16 / f16, width 128) are scored as 128-token segments on K1b and the partial token sums
+    added in segment order (msim_fwd with its workspace); without the workspace the generic kernels take them.  Both against the
+    oracle, and against each other to fp32 summation-order noise; ragged queries (zero padding rows) and clamp0 included."""
+    from colpali_amd import _lib
+
+    qs, ps = _random_case(500 + n_q + lq, n_q, lq, n_d, ld_max)
+    qs[0] = torch.nn.functional.normalize(torch.randn(lq, 128), dim=-1).to(torch.bfloat16)      # one query of the full length
+    qs, ps = [q.float().to(dtype) for q in qs], [p.float().to(dtype) for p in ps]
+    want = _oracle(qs, ps, 7)
+    got = amd.score_multi_vector(qs, ps, batch_size=7, device="cuda:0").numpy()                    # blocks of 7: clamp0 flags everywhere
+    assert close(got, want)
+    dev = torch.device("cuda:0")
+    q, corpus = amd.pack_queries(qs, dev), amd.pack_passages(ps, dev, batch_size=7)
+    L = _lib.lib()
+    assert L.msim_fwd_workspace_bytes(_lib.dtype_code(dtype), n_q, q.shape[1], n_d, 128) == 4096 + n_q * ((q.shape[1] + 127) // 128) * n_d * 4
+    generic = torch.empty((n_q, n_d), dtype=torch.float32, device=dev)
+    rc = L.msim_fwd(_lib.dtype_code(dtype), _lib.ptr(q), n_q, q.shape[1], _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
+                    _lib.ptr(corpus.clamp0), n_d, 128, _lib.ptr(generic), n_d, 0, None, _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_fwd")
+    assert close(generic.cpu().numpy(), want)
+    assert np.max(np.abs(generic.cpu().numpy() - got) / np.maximum(np.abs(want), 1.0)) <= 4e-6
+    if dtype == torch.bfloat16:                                                                     # the literal tier, rounded once, on the total
+        lit = amd.maxsim_scores(q, corpus, ref_rounding=True).cpu().numpy()
+        ref = mo.score_multi_vector([x.float().numpy() for x in qs], [x.float().numpy() for x in ps], batch_size=7, mode="bf16ref")
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 7)
+        assert np.all(np.abs(lit - ref) <= ulp) and np.mean(lit == ref) > 0.8
