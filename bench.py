@@ -336,6 +336,49 @@ def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
     return dt, kern_ms, scores, top
 
 
+def power_sample(amd, q, corpus, seconds=1.2):
+    """Socket power and shader clock while msim_fwd runs back to back for `seconds` (rocm-smi sampled by a thread; context
+    only).  The MI355X clocks to its power budget: next to a regime's roofline fraction this says whether the chip was at its
+    cap (1400 W) and how much clock the power management took (2400 MHz nominal)."""
+    import re
+    import subprocess
+    import threading
+
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=q.device)
+    got, stop = [], threading.Event()
+
+    def sampler():
+        time.sleep(0.3)
+        while not stop.is_set():
+            try:
+                out = subprocess.run([smi, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+                card = json.loads(out)
+                card = card[sorted(card.keys())[0]]
+                pw = next((float(v) for k, v in card.items() if "ower" in k and re.match(r"^[0-9.]+$", str(v))), None)
+                m = re.search(r"(\d+)\s*Mhz", next((str(v) for k, v in card.items() if k.lower().startswith("sclk")), ""), re.I)
+                got.append((pw, int(m.group(1)) if m else None))
+            except Exception:
+                return
+
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(max(1, 32 // q.shape[0])):
+            amd.maxsim_scores(q, corpus, out=scores)
+        torch.cuda.synchronize()
+    stop.set()
+    th.join()
+    pw = [p for p, _ in got if p is not None]
+    ck = [c for _, c in got if c is not None]
+    if not pw or not ck:
+        return None
+    return {"socket_power_w_avg": sum(pw) / len(pw), "socket_power_w_max": max(pw), "sclk_mhz_avg": sum(ck) / len(ck), "samples": len(got)}
+
+
 def forced_collective_numbers(amd, q, corpus, topk, dev, steps=5):
     """The multi-GPU merge path on the ONE GPU this run has: a 1-rank `nccl` (= RCCL) process group, and the step of
     run_regime() with shard_topk(..., force_collective=True) -- message packing, all_gather_into_tensor on the uint8
@@ -673,6 +716,10 @@ def main():
         if rank == 0:
             out["topk_parity"] = par
             out["parity_max_rel_err_vs_oracle_sample"] = par["max_rel_err"]
+    if world == 1 and os.environ.get("BENCH_POWER_SAMPLE", "1") != "0":
+        ps = power_sample(amd, q, corpus)
+        if ps:
+            out["roofline"]["power"] = ps
     if world == 1 and os.environ.get("BENCH_FORCE_COLLECTIVE", "1") != "0":
         out["forced_collective_1rank"] = forced_collective_numbers(amd, q, corpus, args.topk, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -694,6 +741,10 @@ def main():
                         "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"]})
         if ceil_m and r["bound"] == "mfma":
             regimes[-1]["frac_of_mfma_ceiling"] = r["mfma_tflops"] / ceil_m["kernel_mix_tflops"]
+        if world == 1 and os.environ.get("BENCH_POWER_SAMPLE", "1") != "0":
+            ps = power_sample(amd, qq, corpus)
+            if ps:
+                regimes[-1]["power"] = ps
         del qq
     out["regimes"] = regimes
 

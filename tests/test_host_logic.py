@@ -319,7 +319,9 @@ def test_fwd_workspace_bytes_reports_scratch_exactly_when_several_query_blocks_s
     assert ws(5, 96) == 4096 and ws(9, 96) == 4096 and ws(10, 96) == 4096
     assert ws(4, 96) == 0 and ws(6, 96) == 0 and ws(8, 96) == 0    # 12 tiles on 4 waves, 18 / 24 tiles on 8 waves: one block
     assert ws(17, 64) == 4096 and ws(16, 64) == 0 and ws(8, 64) == 0   # two-tile queries: 16 per 8-wave block
-    assert ws(100, 32, dtype=2) == 0 and ws(100, 32, dim=320) == 0 and ws(100, 200) == 0   # generic / panel kernels: none
+    assert ws(100, 32, dtype=2) == 0 and ws(100, 32, dim=320) == 0 and ws(100, 200, dtype=2) == 0   # generic / panel kernels: none
+    # queries longer than 128 tokens (16-bit, width 128): 128-token segments on K1b -- counters + n_q x segments x n_d partial sums
+    assert ws(100, 200) == 4096 + 100 * 2 * 1000 * 4 and ws(1, 780) == 4096 + 7 * 1000 * 4 and ws(3, 129, dtype=1) == 4096 + 3 * 2 * 1000 * 4
 
 
 def test_the_shipped_library_never_reads_the_environment():
