@@ -429,10 +429,10 @@ int pairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const i
 int dd_dense_splits(int n_pairs, int Lq, int n_d, int max_doc_rows, int cus) {
     if (n_d <= 0 || n_pairs <= 0 || max_doc_rows <= 0 || max_doc_rows > msim::kBwdRows) return 0;
     const long long entries_per_doc = (long long)n_pairs * Lq / n_d;
-    if (entries_per_doc < 4096) return 0;                        // the row-range kernel is fine: few entries per document
-    const int pairs_per_doc = (n_pairs + n_d - 1) / n_d;
-    int splits = (2 * cus + n_d - 1) / n_d;                       // ~2 workgroups per CU
-    if (splits > pairs_per_doc) splits = pairs_per_doc;           // at least one pair per split
+    if (entries_per_doc < 1024) return 0;                        // the row-range kernel is fine: few entries per document
+    int splits = (4 * cus + n_d - 1) / n_d;                       // ~4 workgroups per CU (16-32 KiB of LDS each)
+    const long long by_work = entries_per_doc / 256;              // at least 256 (pair, token) entries per split
+    if (splits > by_work) splits = (int)by_work;
     if (splits > 64) splits = 64;
     return splits < 1 ? 1 : splits;
 }
@@ -444,7 +444,8 @@ void launch_dd_dense(const char *Q, const int32_t *d_off, int max_doc_rows, cons
     const int lds = 2 * max_doc_rows * 128 * (int)sizeof(float);  // <= 64 KiB
     hipLaunchKernelGGL(msim::maxsim_bwd_dd_dense_kernel<DT>, dim3(a.n_d, splits, (dim + 127) / 128), dim3(256), lds, st, Q, d_off,
                        pairs, order_by_doc, g, argmax, partial, a, dim, max_doc_rows, splits);
-    hipLaunchKernelGGL(msim::maxsim_bwd_dd_sum_kernel, dim3(a.n_d), dim3(256), 0, st, partial, d_off, dD, a.n_d, dim, max_doc_rows, splits);
+    hipLaunchKernelGGL(msim::maxsim_bwd_dd_sum_kernel, dim3(a.n_d, (max_doc_rows * dim + 255) / 256), dim3(256), 0, st, partial, d_off, dD,
+                       a.n_d, dim, max_doc_rows, splits);
 }
 
 template <bool F16>

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dd_kernel(const char *__restri
 // [B, 32, 128]), where a document of 32 rows collects B x 780 (pair, token) entries and the launch above has n_d workgroups to
 // spread them over (32 workgroups walking 25 000 entries each, every step a dependent gather: 2.4 ms of a 2.6 ms loss step
 // against 0.7 ms for the reference's einsum autograd).  Here EVERY entry hits the one row range, so there is nothing to
-// compact: workgroup (document c, split z) takes an even share of c's pair list; thread t owns column t & 127 and the tokens of
+// compact: workgroup (document c, split z) takes an even share of c's flattened (pair, token) entries; thread t owns column t & 127 and the tokens of
 // parity t >> 7, eight tokens' loads in flight per thread, accumulating into its parity's LDS tile; the two tiles are summed
 // (parity 0 first) into the split's partial, and maxsim_bwd_dd_sum_kernel adds the splits in split order: a fixed summation
 // order, no float atomics.
@@ -243,22 +243,26 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dd_dense_kernel(const char *__
     auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
     const int s = lower_bound_wave(a.n_pairs, c, lane, doc_of);
     const int e = lower_bound_wave(a.n_pairs, c + 1, lane, doc_of);
-    const int cnt = e - s;
-    const int k_lo = s + (int)(((long long)cnt * z) / n_splits), k_hi = s + (int)(((long long)cnt * (z + 1)) / n_splits);
+    // split z takes an even share of the document's FLATTENED (pair, token) entries (pair-major): entries [e_lo, e_hi)
+    const long long n_ent = (long long)(e - s) * a.Lq;
+    const long long e_lo = (n_ent * z) / n_splits, e_hi = (n_ent * (z + 1)) / n_splits;
+    const int k_first = s + (int)(e_lo / a.Lq), i_first = (int)(e_lo % a.Lq);
+    const int k_last = e_hi > e_lo ? s + (int)((e_hi - 1) / a.Lq) : k_first - 1, i_last = e_hi > e_lo ? (int)((e_hi - 1) % a.Lq) + 1 : 0;
     float *my = &tile[half * max_rows][lc];
-    for (int k = k_lo; k < k_hi; ++k) {
+    for (int k = k_first; k <= k_last; ++k) {
         const int p = order_by_doc[k];
         const float gp = g[p];
         const int32_t *arg = argmax + (size_t)p * a.Lq;
         const char *qrow = Q + ((size_t)pairs[2 * p] * a.Lq * dim + col_c) * ES;
-        for (int i0 = half; i0 < a.Lq; i0 += 2 * kBwdDenseUnroll) {
+        const int i_begin = k == k_first ? i_first : 0, i_end = k == k_last ? i_last : a.Lq;
+        for (int i0 = i_begin + half; i0 < i_end; i0 += 2 * kBwdDenseUnroll) {
             int r[kBwdDenseUnroll];
             float qv[kBwdDenseUnroll];
 #pragma unroll
             for (int j = 0; j < kBwdDenseUnroll; ++j) {
                 const int i = i0 + 2 * j;
-                const bool ok = i < a.Lq;
-                const int ic = ok ? i : half;                                  // clamped: every load is a valid address
+                const bool ok = i < i_end;
+                const int ic = ok ? i : i_begin;                               // clamped: every load is a valid address
                 const int rj = arg[ic];
                 r[j] = (ok && rj >= 0 && rj < len) ? rj : -1;                  // arg < 0: the zero padding row won the max
                 qv[j] = load_elem<DT>(qrow + (size_t)ic * dim * ES);
@@ -275,18 +279,17 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dd_dense_kernel(const char *__
     }
 }
 
-// dD[c, r, :] = sum over the splits, in split order
+// dD[c, r, :] = sum over the splits, in split order; workgroup (c, y) owns elements 256 y .. 256 y + 255 of document c's rows
 __global__ __launch_bounds__(256) void maxsim_bwd_dd_sum_kernel(const float *__restrict__ partial, const int32_t *__restrict__ d_off,
                                                                 float *__restrict__ dD, int n_d, int dim, int max_rows, int n_splits) {
     const int c = blockIdx.x;
     const int len = d_off[c + 1] - d_off[c];
-    float *out = dD + (size_t)d_off[c] * dim;
-    for (int idx = threadIdx.x; idx < len * dim; idx += 256) {
-        const int r = idx / dim, col = idx - r * dim;
-        float acc = 0.0f;
-        for (int z = 0; z < n_splits; ++z) acc += partial[(((size_t)z * n_d + c) * max_rows + r) * dim + col];
-        out[idx] = acc;
-    }
+    const int idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= len * dim) return;
+    const int r = idx / dim, col = idx - r * dim;
+    float acc = 0.0f;
+    for (int z = 0; z < n_splits; ++z) acc += partial[(((size_t)z * n_d + c) * max_rows + r) * dim + col];
+    dD[(size_t)d_off[c] * dim + idx] = acc;
 }
 
 }  // namespace msim
