@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 def dtype_code(dtype) -> int:
@@ -98,6 +98,8 @@ def lib() -> ctypes.CDLL:
     L.msim_smooth_pairs_bwd.restype = i32
     L.msim_embed_head.argtypes = [i32, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp]
     L.msim_embed_head.restype = i32
+    L.msim_embed_head_row_map.argtypes = [vp, i32, vp, i32, i64, vp, vp]
+    L.msim_embed_head_row_map.restype = i32
     L.msim_embed_head_bwd.argtypes = [i32, vp, vp, vp, i64, i32, vp, vp]
     L.msim_embed_head_bwd.restype = i32
     L.msim_sim_matrix.argtypes = [i32, vp, i32, vp, i32, i32, vp, i64, u32, vp]

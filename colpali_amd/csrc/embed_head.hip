@@ -612,4 +612,31 @@ __global__ __launch_bounds__(256) void embed_head_bwd_rows_kernel(const uint16_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row map of the DENSE drop-in (colpali_amd.embedding_head): row m keeps its place, masked positions become zero rows
+//   row_map[m] = (attention_mask[m] != 0 && (extra == null || extra[m] != 0)) ? m : -2 - m        (-1 beyond M: tile padding)
+// -- `proj * attention_mask.unsqueeze(-1)` and the optional `proj * image_mask` of modeling_colpali.py:72-77 as ONE launch in front
+// of the head instead of two or three torch element-wise kernels (a 0.5-1 ms head call is short enough for their launch gaps to show).
+// Masks come in whatever dtype the model hands over: `kind` 0 = 1-byte (bool / uint8 / int8), 1 = int16, 2 = int32, 3 = int64,
+// 4 = fp32, 5 = bf16, 6 = fp16 (floating zeros of either sign are "masked").
+__device__ __forceinline__ bool mask_nonzero(const void *p, long long m, int kind) {
+    switch (kind) {
+        case 0: return static_cast<const uint8_t *>(p)[m] != 0;
+        case 1: return static_cast<const uint16_t *>(p)[m] != 0;
+        case 2: return static_cast<const uint32_t *>(p)[m] != 0;
+        case 3: return static_cast<const unsigned long long *>(p)[m] != 0;
+        case 4: return static_cast<const float *>(p)[m] != 0.0f;
+        default: return (static_cast<const uint16_t *>(p)[m] & 0x7fffu) != 0;      // bf16 / fp16: anything but +-0
+    }
+}
+
+__global__ __launch_bounds__(256) void head_row_map_kernel(const void *__restrict__ mask, int mask_kind, const void *__restrict__ extra,
+                                                        int extra_kind, long long M, long long M_padded, int32_t *__restrict__ row_map) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M_padded) return;
+    if (m >= M) { row_map[m] = -1; return; }
+    const bool keep = mask_nonzero(mask, m, mask_kind) && (extra == nullptr || mask_nonzero(extra, m, extra_kind));
+    row_map[m] = keep ? (int32_t)m : (int32_t)(-2 - m);
+}
+
 }  // namespace msim

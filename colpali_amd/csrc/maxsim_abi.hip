@@ -1159,6 +1159,20 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void 
 }
 
 // ---------------------------------------------------------------- embedding head (the producer of the corpus format)
+int msim_embed_head_row_map(const void *mask, int mask_kind, const void *extra, int extra_kind, int64_t M, int32_t *row_map, void *stream) {
+    if (M < 0) return fail(MSIM_EINVAL, "bad size (M=%lld)", (long long)M);
+    if (M == 0) return MSIM_OK;
+    if (!mask || !row_map) return fail(MSIM_EINVAL, "null pointer argument");
+    if (mask_kind < 0 || mask_kind > 6 || (extra && (extra_kind < 0 || extra_kind > 6))) return fail(MSIM_EINVAL, "unknown mask kind");
+    if (M > 0x7ffffffdLL) return fail(MSIM_EUNSUPPORTED, "too many rows for an int32 row map");
+    const long long padded = (M + msim::kHeadBM - 1) / msim::kHeadBM * msim::kHeadBM;
+    hipLaunchKernelGGL(msim::head_row_map_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
+                       mask_kind, extra, extra_kind, (long long)M, padded, row_map);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "head_row_map_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
 int msim_embed_head_bwd(int dtype, const void *proj, const void *grad_out, const int32_t *row_map, int64_t M, int n_out,
                         void *dproj, void *stream) {
     if (M < 0) return fail(MSIM_EINVAL, "bad size (M=%lld)", (long long)M);

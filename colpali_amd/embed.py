@@ -64,17 +64,33 @@ def _padded_map(n: int, device) -> torch.Tensor:
     return torch.full(((n + _TILE - 1) // _TILE * _TILE,), -1, dtype=torch.int32, device=device)
 
 
-_row_id_cache = _lib.StreamConstCache(8)
+_MASK_KINDS = {torch.bool: 0, torch.uint8: 0, torch.int8: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3, torch.float32: 4,
+               torch.bfloat16: 5, torch.float16: 6}
 
 
-def _row_ids(n: int, device):
-    """(arange(n), -2 - arange(n)) as int32 on `device`: the row-map values of kept / zeroed rows of the dense output
-    (read-only constants, cached per size, device and stream: building them costs more launches than the rest of the wrapper)."""
-    def make():
-        rows = torch.arange(n, dtype=torch.int32, device=device)
-        return rows, -2 - rows
+def _dense_row_map(attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor], M: int, device) -> torch.Tensor:
+    """int32 row map of the dense output (kept rows stay in place, masked positions become zero rows), tile padding included:
+    one launch of msim_embed_head_row_map whatever the masks' dtypes (modeling_colpali.py:72, :74-77)."""
+    def prep(t):
+        t = t.reshape(-1)
+        if t.dtype not in _MASK_KINDS:
+            t = t != 0
+        if t.device != torch.device(device) or not t.is_contiguous():
+            t = t.to(device).contiguous()
+        return t
 
-    return _row_id_cache.get(n, device, make)
+    mask = prep(attention_mask)
+    extra = None if extra_mask is None else prep(extra_mask)
+    if mask.numel() != M or (extra is not None and extra.numel() != M):
+        raise ValueError("attention_mask / extra_mask must have one entry per hidden-state position")
+    row_map = torch.empty(((M + _TILE - 1) // _TILE * _TILE,), dtype=torch.int32, device=device)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        rc = L.msim_embed_head_row_map(_lib.ptr(mask), _MASK_KINDS[mask.dtype], _lib.ptr(extra),
+                                       _MASK_KINDS[extra.dtype] if extra is not None else 0, M, _lib.ptr(row_map),
+                                       _lib.current_stream_handle(torch.device(device)))
+    _lib.check(rc, "msim_embed_head_row_map")
+    return row_map
 
 
 class _EmbeddingHeadFn(torch.autograd.Function):
@@ -123,15 +139,7 @@ def embedding_head(hidden_states: torch.Tensor, weight: torch.Tensor, bias: Opti
     result carries a graph node whose backward is `_EmbeddingHeadFn.backward` (never a silent detach)."""
     _check(hidden_states, weight, bias, attention_mask)
     B, S, _ = hidden_states.shape
-    keep = attention_mask.reshape(-1) != 0
-    if extra_mask is not None:
-        keep = keep & (extra_mask.reshape(-1) != 0)
-    rows, zero_rows = _row_ids(B * S, hidden_states.device)
-    if (B * S) % _TILE == 0:
-        row_map = torch.where(keep, rows, zero_rows)                     # two launches in front of the kernel, not seven
-    else:
-        row_map = _padded_map(B * S, hidden_states.device)
-        torch.where(keep, rows, zero_rows, out=row_map[: B * S])
+    row_map = _dense_row_map(attention_mask, extra_mask, B * S, hidden_states.device)
     if torch.is_grad_enabled() and (hidden_states.requires_grad or weight.requires_grad
                                     or (bias is not None and bias.requires_grad)):
         return _EmbeddingHeadFn.apply(hidden_states, weight, bias, row_map)

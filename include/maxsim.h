@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 14
+#define MSIM_ABI_VERSION 15
 
 /* error codes */
 #define MSIM_OK 0
@@ -211,6 +211,15 @@ int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C,
 int msim_embed_head(int dtype, const void *X, int64_t M, int H,
                     const void *W, const void *bias, int n_out,
                     const int32_t *row_map, void *out, int64_t ld_out, void *stream);
+
+/*
+ * Row map of the DENSE form of msim_embed_head (the model forward's own output layout): row m keeps its place,
+ *   row_map[m] = (mask[m] != 0 && (extra == NULL || extra[m] != 0)) ? m : -2 - m,    -1 for the tile padding m in [M, ceil(M / 256) * 256)
+ * i.e. `proj * attention_mask.unsqueeze(-1)` (modeling_colpali.py:72) and the optional `proj * image_mask` (:74-77) as one launch in
+ * front of the head.  mask / extra: [M] elements of `kind` 0 = 1-byte (bool / uint8 / int8), 1 = int16, 2 = int32, 3 = int64, 4 = fp32,
+ * 5 = bf16, 6 = fp16 (a floating zero of either sign counts as masked); row_map: int32 [ceil(M / 256) * 256].
+ */
+int msim_embed_head_row_map(const void *mask, int mask_kind, const void *extra, int extra_kind, int64_t M, int32_t *row_map, void *stream);
 
 /*
  * Backward of the norm / mask tail of the embedding head -- what torch autograd derives for
