@@ -251,6 +251,7 @@ def _embed_head_shape(amd, dev, B, S, H):
         torch.cuda.synchronize()
         out[name]["ms_back_to_back"] = a.elapsed_time(b) / 20
         out[name]["hbm_gbs_back_to_back"] = byts / out[name]["ms_back_to_back"] / 1e6
+        out[name]["frac_of_8TBs_back_to_back"] = out[name]["hbm_gbs_back_to_back"] / HBM_PEAK_GBS   # `ms` above also holds the host's launch latency
     out["workload"] = f"{B} pages x {S} tokens x hidden {H} bf16 -> [rows, 128] unit rows (algorithmic bytes = hidden read + rows written)"
     del hidden
     return out
