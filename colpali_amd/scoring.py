@@ -51,6 +51,9 @@ def _fwd_workspace(nbytes: int, device: torch.device) -> Optional[torch.Tensor]:
     return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
 
 
+_MAX_FWD_SCRATCH = 1 << 30        # bytes of msim_fwd scratch per launch (long queries: see maxsim_scores)
+
+
 def _ref_rounding_from_env() -> bool:
     """COLPALI_AMD_REF_ROUNDING=1: the drop-in `score_multi_vector` returns what the reference LITERALLY returns for 16-bit
     embeddings -- every similarity rounded to the input dtype before the max, the token sum rounded to it
@@ -86,13 +89,19 @@ def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: 
         out = torch.empty((n_q, n), dtype=torch.float32, device=queries.device)
     elif out.shape != (n_q, n) or out.dtype != torch.float32 or out.stride(1) != 1:
         raise ValueError("out must be fp32 [n_q, n] with unit inner stride")
-    ws = _fwd_workspace(L.msim_fwd_workspace_bytes(dt, n_q, Lq, n, dim), queries.device)
+    # long queries are scored in 128-token segments whose partial sums live in the workspace (n_q x segments x n x 4 bytes): keep
+    # that scratch bounded by scoring the queries in groups (rows of `out` are independent)
+    ws_bytes = L.msim_fwd_workspace_bytes(dt, n_q, Lq, n, dim)
+    group = n_q if ws_bytes <= _MAX_FWD_SCRATCH else max(1, int(n_q * _MAX_FWD_SCRATCH // ws_bytes))
+    flags = _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0
     with torch.cuda.device(queries.device):
-        rc = L.msim_fwd(dt, _lib.ptr(queries), n_q, Lq, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
-                        _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out), out.stride(0) if n_q > 1 else max(n, 1),
-                        _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0, _lib.ptr(ws),
-                        _lib.current_stream_handle(queries.device))
-    _lib.check(rc, "msim_fwd")
+        for q0 in range(0, n_q, group):
+            nq = min(group, n_q - q0)
+            ws = _fwd_workspace(L.msim_fwd_workspace_bytes(dt, nq, Lq, n, dim), queries.device)
+            rc = L.msim_fwd(dt, _lib.ptr(queries[q0:q0 + nq]), nq, Lq, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
+                            _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out[q0:q0 + nq]), out.stride(0) if n_q > 1 else max(n, 1),
+                            flags, _lib.ptr(ws), _lib.current_stream_handle(queries.device))
+            _lib.check(rc, "msim_fwd")
     return out
 
 

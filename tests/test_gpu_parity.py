@@ -394,3 +394,16 @@ def test_long_queries_score_as_segments_on_the_tuned_kernels(amd, n_q, lq, n_d, 
         ref = mo.score_multi_vector([x.float().numpy() for x in qs], [x.float().numpy() for x in ps], batch_size=7, mode="bf16ref")
         ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 7)
         assert np.all(np.abs(lit - ref) <= ulp) and np.mean(lit == ref) > 0.8
+
+
+def test_long_query_scratch_is_bounded_by_scoring_the_queries_in_groups(amd, monkeypatch):
+    from colpali_amd import scoring
+
+    qs, ps = _random_case(77, 9, 300, 120, 200)
+    dev = torch.device("cuda:0")
+    q, corpus = amd.pack_queries(qs, dev), amd.pack_passages(ps, dev)
+    whole = amd.maxsim_scores(q, corpus).cpu()
+    monkeypatch.setattr(scoring, "_MAX_FWD_SCRATCH", 4096 + 2 * 3 * 120 * 4)          # room for two queries' partial sums at a time
+    grouped = amd.maxsim_scores(q, corpus).cpu()
+    assert torch.equal(whole, grouped)
+    assert close(whole.numpy(), _oracle(qs, ps, 128))
