@@ -869,10 +869,10 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
         c.workspace = workspace;
         c.n_seg = n_seg;
         const bool f16 = dtype == MSIM_DTYPE_F16;
+        if (n_q > 65535) return fail(MSIM_EUNSUPPORTED, "too many long queries (%d) for one launch", n_q);
         if (int rc = f16 ? batch_dispatch<4, true>(c) : batch_dispatch<4, false>(c)) return rc;
         const dim3 grid((n_d + 255) / 256, n_q);
         const bool round_total = (flags & MSIM_FLAG_REF_ROUNDING) != 0;
-        if (n_q > 65535) return fail(MSIM_EUNSUPPORTED, "too many long queries (%d) for one launch", n_q);
         if (f16)
             hipLaunchKernelGGL(msim::segment_sum_kernel<true>, grid, dim3(256), 0, c.st, partial, (long long)n_d, n_seg, n_d, scores,
                                (long long)ld_scores, round_total);
