@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 def dtype_code(dtype) -> int:
@@ -100,6 +100,8 @@ def lib() -> ctypes.CDLL:
     L.msim_embed_head.restype = i32
     L.msim_embed_head_row_map.argtypes = [vp, i32, vp, i32, i64, vp, vp]
     L.msim_embed_head_row_map.restype = i32
+    L.msim_embed_head_writer_map.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.msim_embed_head_writer_map.restype = i32
     L.msim_embed_head_bwd.argtypes = [i32, vp, vp, vp, i64, i32, vp, vp]
     L.msim_embed_head_bwd.restype = i32
     L.msim_sim_matrix.argtypes = [i32, vp, i32, vp, i32, i32, vp, i64, u32, vp]

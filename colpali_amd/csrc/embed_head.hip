@@ -639,4 +639,71 @@ __global__ __launch_bounds__(256) void head_row_map_kernel(const void *__restric
     row_map[m] = keep ? (int32_t)m : (int32_t)(-2 - m);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row map of the PACKING form (colpali_amd.CorpusWriter.append): the kept positions of page b go to consecutive corpus rows
+//   row_map[b * S + s] = keep(b, s) ? rows_before + (kept positions of pages < b) + (kept positions of page b before s) : -1
+// -- what the host used to assemble from ten torch launches per batch (two cumsums, sums, a where, casts).  Two launches: the kept
+// positions per page, then one workgroup per page that adds up the counts of the pages in front of it and ranks its own positions
+// (wave ballots + a 4-entry LDS carry).  counts[b] (int64) goes back to the host at finish(); rows_after = rows_before + all counts.
+__global__ __launch_bounds__(256) void head_page_count_kernel(const void *__restrict__ mask, int mask_kind, const void *__restrict__ extra,
+                                                           int extra_kind, int S, long long *__restrict__ counts) {
+    __shared__ int wave_sum[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int n = 0;
+    for (int s0 = 0; s0 < S; s0 += 256) {
+        const int sidx = s0 + threadIdx.x;
+        const long long m = (long long)b * S + sidx;
+        const bool keep = sidx < S && mask_nonzero(mask, m, mask_kind) && (extra == nullptr || mask_nonzero(extra, m, extra_kind));
+        n += __popcll(__ballot(keep));
+    }
+    if (lane == 0) wave_sum[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = (long long)wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+__global__ __launch_bounds__(256) void head_writer_map_kernel(const void *__restrict__ mask, int mask_kind, const void *__restrict__ extra,
+                                                           int extra_kind, int B, int S, const long long *__restrict__ rows_before,
+                                                           const long long *__restrict__ counts, long long M_padded,
+                                                           int32_t *__restrict__ row_map, long long *__restrict__ rows_after) {
+    __shared__ long long part[256];
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (b == B) {                                         // the extra workgroup: tile padding of the map, and the new row count
+        for (long long m = (long long)B * S + threadIdx.x; m < M_padded; m += 256) row_map[m] = -1;
+        long long t = 0;
+        for (int p = threadIdx.x; p < B; p += 256) t += counts[p];
+        part[threadIdx.x] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tot = *rows_before;
+            for (int i = 0; i < 256; ++i) tot += part[i];
+            *rows_after = tot;
+        }
+        return;
+    }
+    long long t = 0;
+    for (int p = threadIdx.x; p < b; p += 256) t += counts[p];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    long long base = *rows_before;
+    for (int i = 0; i < 256; ++i) base += part[i];         // every thread adds the same 256 numbers in the same order
+    for (int s0 = 0; s0 < S; s0 += 256) {
+        const int sidx = s0 + threadIdx.x;
+        const long long m = (long long)b * S + sidx;
+        const bool keep = sidx < S && mask_nonzero(mask, m, mask_kind) && (extra == nullptr || mask_nonzero(extra, m, extra_kind));
+        const unsigned long long bal = __ballot(keep);
+        __syncthreads();                                    // wave_cnt of the previous round has been read
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            before += w < wave ? wave_cnt[w] : 0;
+            total += wave_cnt[w];
+        }
+        if (sidx < S) row_map[m] = keep ? (int32_t)(base + before) : -1;
+        base += total;
+    }
+}
+
 }  // namespace msim

@@ -1173,6 +1173,25 @@ int msim_embed_head_row_map(const void *mask, int mask_kind, const void *extra, 
     return MSIM_OK;
 }
 
+int msim_embed_head_writer_map(const void *mask, int mask_kind, const void *extra, int extra_kind, int B, int S, const int64_t *rows_before,
+                               int64_t *counts, int32_t *row_map, int64_t *rows_after, void *stream) {
+    if (B < 0 || S <= 0) return fail(MSIM_EINVAL, "bad size (B=%d S=%d)", B, S);
+    if (B == 0) return MSIM_OK;
+    if (!mask || !rows_before || !counts || !row_map || !rows_after) return fail(MSIM_EINVAL, "null pointer argument");
+    if (mask_kind < 0 || mask_kind > 6 || (extra && (extra_kind < 0 || extra_kind > 6))) return fail(MSIM_EINVAL, "unknown mask kind");
+    const long long M = (long long)B * S;
+    const long long padded = (M + msim::kHeadBM - 1) / msim::kHeadBM * msim::kHeadBM;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(msim::head_page_count_kernel, dim3(B), dim3(256), 0, st, mask, mask_kind, extra, extra_kind, S,
+                       reinterpret_cast<long long *>(counts));
+    hipLaunchKernelGGL(msim::head_writer_map_kernel, dim3(B + 1), dim3(256), 0, st, mask, mask_kind, extra, extra_kind, B, S,
+                       reinterpret_cast<const long long *>(rows_before), reinterpret_cast<const long long *>(counts), padded, row_map,
+                       reinterpret_cast<long long *>(rows_after));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "head_writer_map_kernel launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+
 int msim_embed_head_bwd(int dtype, const void *proj, const void *grad_out, const int32_t *row_map, int64_t M, int n_out,
                         void *dproj, void *stream) {
     if (M < 0) return fail(MSIM_EINVAL, "bad size (M=%lld)", (long long)M);

@@ -59,28 +59,25 @@ def _launch(hidden: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     _lib.check(rc, "msim_embed_head")
 
 
-def _padded_map(n: int, device) -> torch.Tensor:
-    """int32 row map with the tile padding the kernel may read (filled with -1 = drop)."""
-    return torch.full(((n + _TILE - 1) // _TILE * _TILE,), -1, dtype=torch.int32, device=device)
-
-
 _MASK_KINDS = {torch.bool: 0, torch.uint8: 0, torch.int8: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3, torch.float32: 4,
                torch.bfloat16: 5, torch.float16: 6}
+
+
+def _prep_mask(t: torch.Tensor, device) -> torch.Tensor:
+    """A mask as the kernels read it: flat, contiguous, on the device, of a dtype they know (anything else is compared with 0 first)."""
+    t = t.reshape(-1)
+    if t.dtype not in _MASK_KINDS:
+        t = t != 0
+    if t.device != torch.device(device) or not t.is_contiguous():
+        t = t.to(device).contiguous()
+    return t
 
 
 def _dense_row_map(attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor], M: int, device) -> torch.Tensor:
     """int32 row map of the dense output (kept rows stay in place, masked positions become zero rows), tile padding included:
     one launch of msim_embed_head_row_map whatever the masks' dtypes (modeling_colpali.py:72, :74-77)."""
-    def prep(t):
-        t = t.reshape(-1)
-        if t.dtype not in _MASK_KINDS:
-            t = t != 0
-        if t.device != torch.device(device) or not t.is_contiguous():
-            t = t.to(device).contiguous()
-        return t
-
-    mask = prep(attention_mask)
-    extra = None if extra_mask is None else prep(extra_mask)
+    mask = _prep_mask(attention_mask, device)
+    extra = None if extra_mask is None else _prep_mask(extra_mask, device)
     if mask.numel() != M or (extra is not None and extra.numel() != M):
         raise ValueError("attention_mask / extra_mask must have one entry per hidden-state position")
     row_map = torch.empty(((M + _TILE - 1) // _TILE * _TILE,), dtype=torch.int32, device=device)
@@ -165,7 +162,7 @@ class CorpusWriter:
         self.score_batch_size = score_batch_size
         self._rows_dev = torch.zeros((), dtype=torch.int64, device=self.device)   # exact count, stays on the device
         self._rows_upper = 0                                                       # host-side bound (no sync per append)
-        self._bases, self._counts, self._padded_lens = [], [], []
+        self._counts, self._padded_lens = [], []
 
     def append(self, hidden_states: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                attention_mask: torch.Tensor, extra_mask: Optional[torch.Tensor] = None) -> int:
@@ -189,19 +186,24 @@ class CorpusWriter:
                 raise RuntimeError(f"CorpusWriter capacity of {self.capacity} rows exceeded: {self._rows_upper} rows written, "
                                    f"the batch may add up to {B * S}")
         self._rows_upper += B * S
-        keep = attention_mask != 0
-        if extra_mask is not None:
-            keep = keep & (extra_mask.reshape(B, S) != 0)
-        counts = keep.sum(dim=1)                                                   # int64 [B]
-        ends = torch.cumsum(counts, 0) + self._rows_dev
-        bases = ends - counts
-        rank = torch.cumsum(keep, dim=1) - 1
-        dest = torch.where(keep, bases[:, None] + rank, -1).to(torch.int32)
-        row_map = _padded_map(B * S, self.device)
-        row_map[: B * S] = dest.reshape(-1)
+        # destination row of every kept position, the page counts and the new row total: two launches of msim_embed_head_writer_map
+        # (the host used to assemble them from ten torch launches per batch)
+        mask = _prep_mask(attention_mask, self.device)
+        extra = None if extra_mask is None else _prep_mask(extra_mask, self.device)
+        if mask.numel() != B * S or (extra is not None and extra.numel() != B * S):
+            raise ValueError("attention_mask / extra_mask must have one entry per hidden-state position")
+        counts = torch.empty((B,), dtype=torch.int64, device=self.device)
+        row_map = torch.empty(((B * S + _TILE - 1) // _TILE * _TILE,), dtype=torch.int32, device=self.device)
+        rows_after = torch.empty((), dtype=torch.int64, device=self.device)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            rc = L.msim_embed_head_writer_map(_lib.ptr(mask), _MASK_KINDS[mask.dtype], _lib.ptr(extra),
+                                              _MASK_KINDS[extra.dtype] if extra is not None else 0, B, S, _lib.ptr(self._rows_dev),
+                                              _lib.ptr(counts), _lib.ptr(row_map), _lib.ptr(rows_after),
+                                              _lib.current_stream_handle(self.device))
+        _lib.check(rc, "msim_embed_head_writer_map")
         _launch(hidden_states, weight, bias, row_map, self.blob)
-        self._rows_dev = ends[-1]
-        self._bases.append(bases)
+        self._rows_dev = rows_after
         self._counts.append(counts)
         self._padded_lens.append(torch.full((B,), S, dtype=torch.int64))
         return B

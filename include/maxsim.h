@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 15
+#define MSIM_ABI_VERSION 16
 
 /* error codes */
 #define MSIM_OK 0
@@ -220,6 +220,16 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H,
  * 5 = bf16, 6 = fp16 (a floating zero of either sign counts as masked); row_map: int32 [ceil(M / 256) * 256].
  */
 int msim_embed_head_row_map(const void *mask, int mask_kind, const void *extra, int extra_kind, int64_t M, int32_t *row_map, void *stream);
+
+/*
+ * Row map of the PACKING form of msim_embed_head (pages written back to back into the resident corpus, masked positions dropped:
+ * what replaces README.md:121-126 `torch.unbind(embeddings.to("cpu"))` + the scorer's per-block pad_sequence):
+ *   row_map[b * S + s] = keep(b, s) ? *rows_before + (kept positions of pages < b) + (kept positions of page b before s) : -1
+ *   counts[b] = kept positions of page b (int64, device);  *rows_after = *rows_before + sum of counts;  tile padding of the map = -1.
+ * mask / extra as in msim_embed_head_row_map, [B * S] elements; rows_before / rows_after: device int64 (may alias).
+ */
+int msim_embed_head_writer_map(const void *mask, int mask_kind, const void *extra, int extra_kind, int B, int S, const int64_t *rows_before,
+                               int64_t *counts, int32_t *row_map, int64_t *rows_after, void *stream);
 
 /*
  * Backward of the norm / mask tail of the embedding head -- what torch autograd derives for
