@@ -206,9 +206,9 @@ int launch_stream(const FwdCall &c) {
     return launch_stream_aux<QT, TPQ, F16, 2, true, ring_default>(c);     // nt stream, interleaved DMA issue
 }
 
-template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0>
+template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0, int MAXT = 4>
 int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING, AUX>;
+    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING, AUX, MAXT>;
     constexpr int lds = RING * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves) / 32 KiB (pair, ring of 4)
     constexpr int wg_per_cu = 8 / NW;
     static std::atomic<int> configured[kMaxDevices];
@@ -220,7 +220,7 @@ int launch_batch(const FwdCall &c) {
     a.n_d = c.n_d;
     a.flags = c.flags;
     a.n_seg = c.n_seg;
-    const int q_per_block = NW * (4 / TPQ);                         // at most; the kernel splits n_q evenly over the blocks
+    const int q_per_block = NW * (MAXT / TPQ);                      // at most; the kernel splits n_q evenly over the blocks
     a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
     const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
@@ -322,14 +322,29 @@ int batch_nw_override() {
 struct BatchPlan {
     int nw;          // waves per document stream
     int n_qblocks;   // query blocks (passes over a document range)
+    int maxt;        // token tiles a wave holds at most (4, or 5 for one-tile queries: maxsim_batch.hip MAXT)
 };
+// which sizes take the five-tiles-per-wave form (one-tile queries): bit 0: 9..10 tiles (pair form 5 + 4 / 5 + 5 instead of 3/2/2/2,
+// 3/3/2/2 on four waves: 10 queries -2.7 %, 9 a tie), bit 1: 17..20 (the 4-wave form, 5/4/4/4 .. 5/5/5/5, instead of the 8-wave form:
+// -7..10 %), bit 2: 36..40 (ONE pass of the 8-wave form instead of two: -2..2.5 %; 33..35 lose 9 % to the single 5-tile wave and keep two
+// passes), bit 3: blocks of 40 above that (no gain: not default).  profiles/r03_logs/ab_batch_t5.log; MSIM_BATCH_T5 overrides it in
+// measurement builds
+constexpr int kBatchT5Default = 1 | 2 | 4;
 BatchPlan batch_plan(int n_q, int tpq) {
     const int tiles = n_q * tpq;
+    static const int t5 = ab_env("MSIM_BATCH_T5", kBatchT5Default);
     int nw = tiles <= 8 ? 2 : (tiles <= 16 ? 4 : 8);
+    int maxt = 4;
+    if (tpq == 1) {
+        if ((t5 & 1) && tiles >= 9 && tiles <= 10) { nw = 2; maxt = 5; }
+        else if ((t5 & 2) && tiles >= 17 && tiles <= 20) { nw = 4; maxt = 5; }
+        else if ((t5 & 4) && tiles >= 36 && tiles <= 40) { nw = 8; maxt = 5; }
+        else if ((t5 & 8) && tiles > 40) { nw = 8; maxt = 5; }
+    }
     const int forced = batch_nw_override();
-    if (forced && (forced != 2 || tiles <= 8)) nw = forced;
-    const int q_per_block = nw * (4 / tpq);
-    return BatchPlan{nw, (n_q + q_per_block - 1) / q_per_block};
+    if (maxt == 4 && forced && (forced != 2 || tiles <= 8)) nw = forced;
+    const int q_per_block = nw * (maxt / tpq);
+    return BatchPlan{nw, (n_q + q_per_block - 1) / q_per_block, maxt};
 }
 
 template <int TPQ, bool F16>
@@ -359,12 +374,20 @@ int batch_dispatch(const FwdCall &c) {
         }
     }
 #endif
-    const int nw = batch_plan(c.n_q, TPQ).nw;
+    const BatchPlan plan = batch_plan(c.n_q, TPQ);
+    const int nw = plan.nw;
     // one query block = every corpus byte is read once by one workgroup: stream it past L2 / MALL (nt), like K1s does.
     // MSIM_BATCH_NT=0 switches that off for A/B measurements (tuning knob, not part of the ABI).
     static const bool nt_off = ab_env("MSIM_BATCH_NT", 1) == 0;
-    const int q_per_block = nw * (4 / TPQ);
+    const int q_per_block = nw * (plan.maxt / TPQ);
     const bool single_block = c.n_q <= q_per_block && !nt_off;
+    if constexpr (TPQ == 1) {
+        if (plan.maxt == 5) {
+            if (nw == 2) return launch_batch<1, F16, 2, 4, 2, 5>(c);
+            if (nw == 4) return launch_batch<1, F16, 4, 3, 2, 5>(c);
+            return single_block ? launch_batch<1, F16, 8, 3, 2, 5>(c) : launch_batch<1, F16, 8, 3, 0, 5>(c);
+        }
+    }
     if (nw == 2) return single_block ? launch_batch<TPQ, F16, 2, 4, 2>(c) : launch_batch<TPQ, F16, 2, 4, 0>(c);
     if (nw == 4) return single_block ? launch_batch<TPQ, F16, 4, 3, 2>(c) : launch_batch<TPQ, F16, 4, 3, 0>(c);
     return single_block ? launch_batch<TPQ, F16, 8, 3, 2>(c) : launch_batch<TPQ, F16, 8, 3, 0>(c);

@@ -78,7 +78,10 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 // RING: chunks in the shared LDS ring (4 for the pair form: 32 KiB per workgroup, 3 otherwise: 48 / 96 KiB).
 // AUX : cache policy of the LDS-DMA loads: 2 = nt (no L2 / MALL allocation) when ONE query block streams the corpus, i.e. every byte
 //       is read exactly once, as in K1s; 0 = default when several query blocks share a range through the XCD's L2.
-template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0>
+// MAXT: token tiles a wave holds at most: 4, or 5 (round 3; one-tile queries only): 160 B-operand registers, 128 of them pinned to
+//       AGPRs, still two waves per SIMD -- a block of NW waves then takes 5 NW queries: 9..10 queries fit the pair form 5 + 4 / 5 + 5
+//       (instead of 3/2/2/2, 3/3/2/2 on four waves), 17..20 the 4-wave form, 33..40 one pass of the 8-wave form.
+template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0, int MAXT = 4>
 __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
 
     // ---- this wave's queries: block-local query j lives in wave j % 8
     static_assert(TPQ >= 1 && TPQ <= 4, "a wave holds whole queries of at most 4 token tiles");
-    constexpr int QPW = 4 / TPQ;                           // queries per wave at most
+    static_assert(MAXT == 4 || (MAXT == 5 && TPQ == 1), "five tiles per wave: one-tile queries only");
+    constexpr int QPW = MAXT / TPQ;                        // queries per wave at most
     constexpr int NTMAX = QPW * TPQ;
     const int q_base = a.n_q / a.n_qblocks, q_extra = a.n_q % a.n_qblocks;
     const int qb0 = qblock * q_base + (qblock < q_extra ? qblock : q_extra);   // first query of this block
@@ -138,7 +142,12 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qt[t].f[h][ks]));
+            for (int ks = 0; ks < kKSteps16; ++ks) {
+                // five tiles: four of them live in AGPRs (MFMA srcB reads either file); left alone hipcc keeps 128 VGPRs and shuffles
+                // the rest through v_accvgpr copies inside the slab loop
+                if (MAXT > 4 && t >= 1) asm volatile("" : "+a"(qt[t].f[h][ks]));
+                else asm volatile("" : "+v"(qt[t].f[h][ks]));
+            }
 
     // ---- per-lane address constants (same slab image as K1s)
     const int l16 = lane & 15, l4 = lane >> 4;
@@ -312,7 +321,8 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         case 1: run(std::integral_constant<int, TPQ>{}); break;
         case 2: if constexpr (QPW >= 2) run(std::integral_constant<int, 2 * TPQ>{}); break;
         case 3: if constexpr (QPW >= 3) run(std::integral_constant<int, 3 * TPQ>{}); break;
-        default: if constexpr (QPW >= 4) run(std::integral_constant<int, 4 * TPQ>{}); break;
+        case 4: if constexpr (QPW >= 4) run(std::integral_constant<int, 4 * TPQ>{}); break;
+        default: if constexpr (QPW >= 5) run(std::integral_constant<int, 5 * TPQ>{}); break;
     }
 }
 

@@ -117,6 +117,10 @@ def _oracle(qs, ps, batch_size):
     (3, 64, 90, 260, 128),       # pair form, two-tile queries: 2 + 1 queries per wave
     (2, 96, 60, 200, 128),       # pair form, three-tile queries: one per wave
     (2, 128, 40, 150, 128),      # pair form, four-tile queries
+    (10, 32, 257, 700, 128),     # pair form with FIVE tiles per wave (round 3): 5 + 5
+    (9, 30, 120, 400, 16),       # 5 + 4, clamp0
+    (18, 32, 200, 300, 128),     # 4-wave form, five tiles per wave: 5/5/4/4
+    (38, 32, 150, 260, 128),     # 8-wave form, one block of 38: 5/5/5/5/5/5/4/4
     (13, 32, 300, 500, 128),     # K1b<1>: waves with 2 and with 1 tile in one block
     (20, 32, 100, 400, 128),     # K1b<1>: 3 / 2 tiles per wave
     (33, 32, 500, 300, 128),     # K1b<1>: two balanced query blocks (17 + 16)
@@ -167,7 +171,7 @@ def test_stream_and_batch_kernels_agree_bitwise_on_shared_queries(amd):
     for i in (0, 7, 39):
         one = amd.maxsim_scores(amd.pack_queries([padded[i]], dev), corpus).cpu()
         assert torch.equal(one[0], big[i])
-    for n in (6, 12):
+    for n in (6, 10, 12, 20, 38):                                   # pair form 3+3, FIVE tiles per wave (5+5; 5/5/5/5; 5/.../4), 4-wave form
         part = amd.maxsim_scores(amd.pack_queries(padded[:n], dev), corpus).cpu()
         assert torch.equal(part, big[:n])
 
