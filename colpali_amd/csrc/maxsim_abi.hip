@@ -324,11 +324,14 @@ struct BatchPlan {
     int n_qblocks;   // query blocks (passes over a document range)
     int maxt;        // token tiles a wave holds at most (4, or 5 for one-tile queries: maxsim_batch.hip MAXT)
 };
-// which sizes take the five-tiles-per-wave form (one-tile queries): bit 0: 9..10 tiles (pair form 5 + 4 / 5 + 5 instead of 3/2/2/2,
-// 3/3/2/2 on four waves: 10 queries -2.7 %, 9 a tie), bit 1: 17..20 (the 4-wave form, 5/4/4/4 .. 5/5/5/5, instead of the 8-wave form:
-// -7..10 %), bit 2: 36..40 (ONE pass of the 8-wave form instead of two: -2..2.5 %; 33..35 lose 9 % to the single 5-tile wave and keep two
-// passes), bit 3: blocks of 40 above that (no gain: not default).  profiles/r03_logs/ab_batch_t5.log; MSIM_BATCH_T5 overrides it in
-// measurement builds
+// Which sizes take the five-tiles-per-wave form (one-tile queries; profiles/r03_logs/ab_batch_t5.log, bit-identical scores):
+//   bit 0:  9..10 tiles: the pair form 5 + 4 / 5 + 5 instead of 3/2/2/2, 3/3/2/2 on four waves (10 queries -2.7 %, 9 a tie);
+//   bit 1: 17..20 tiles: the 4-wave form 5/4/4/4 .. 5/5/5/5 instead of one pass of the 8-wave form (-7..10 %);
+//   bit 2: more than 32 tiles: blocks of up to 40 on the 8-wave form WHEN THAT IS FEWER WAVE-SLAB STEPS: a block's pace is set by its
+//          heaviest wave, so a plan costs (query blocks) x (tiles of the heaviest wave), and the five-tile bodies run ~10 % behind the
+//          four-tile ones per step.  33..40 queries: ONE pass instead of two (-16 % at 33, -12 % at 36, -7 % at 40); 73..80: two blocks of
+//          <= 40 instead of three of <= 27 (-8 % at 80); everywhere else (64, 256, 1000 ...) the four-tile plan stays (+1..10 % otherwise).
+// MSIM_BATCH_T5 overrides the mask in measurement builds (bit 3 there: blocks of 40 for every size above 40).
 constexpr int kBatchT5Default = 1 | 2 | 4;
 BatchPlan batch_plan(int n_q, int tpq) {
     const int tiles = n_q * tpq;
@@ -338,8 +341,12 @@ BatchPlan batch_plan(int n_q, int tpq) {
     if (tpq == 1) {
         if ((t5 & 1) && tiles >= 9 && tiles <= 10) { nw = 2; maxt = 5; }
         else if ((t5 & 2) && tiles >= 17 && tiles <= 20) { nw = 4; maxt = 5; }
-        else if ((t5 & 4) && tiles >= 36 && tiles <= 40) { nw = 8; maxt = 5; }
         else if ((t5 & 8) && tiles > 40) { nw = 8; maxt = 5; }
+        else if ((t5 & 4) && tiles > 32 && tiles <= 80) {                 // measured territory only
+            const int b4 = (tiles + 31) / 32, b5 = (tiles + 39) / 40;
+            const int w4 = ((tiles + b4 - 1) / b4 + 7) / 8, w5 = ((tiles + b5 - 1) / b5 + 7) / 8;   // tiles of the heaviest wave
+            if (11 * b5 * w5 < 10 * b4 * w4) { nw = 8; maxt = 5; }
+        }
     }
     const int forced = batch_nw_override();
     if (maxt == 4 && forced && (forced != 2 || tiles <= 8)) nw = forced;

@@ -121,9 +121,11 @@ def _oracle(qs, ps, batch_size):
     (9, 30, 120, 400, 16),       # 5 + 4, clamp0
     (18, 32, 200, 300, 128),     # 4-wave form, five tiles per wave: 5/5/4/4
     (38, 32, 150, 260, 128),     # 8-wave form, one block of 38: 5/5/5/5/5/5/4/4
+    (33, 32, 120, 200, 128),     # one block of 33: a single five-tile wave
+    (77, 32, 90, 150, 128),      # two blocks of 39 + 38 on five-tile waves (instead of three of 26)
     (13, 32, 300, 500, 128),     # K1b<1>: waves with 2 and with 1 tile in one block
     (20, 32, 100, 400, 128),     # K1b<1>: 3 / 2 tiles per wave
-    (33, 32, 500, 300, 128),     # K1b<1>: two balanced query blocks (17 + 16)
+    (41, 32, 500, 300, 128),     # K1b<1>: two balanced query blocks (21 + 20)
     (70, 32, 150, 300, 128),     # K1b<1>: three blocks (24 + 23 + 23)
     (100, 32, 200, 1100, 5),     # many queries, long ragged documents, small reference blocks (clamp0 everywhere)
     (17, 64, 90, 260, 128),      # K1b<2>: two blocks of 9 + 8 two-tile queries

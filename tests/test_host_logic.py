@@ -313,9 +313,8 @@ def test_fwd_workspace_bytes_reports_scratch_exactly_when_several_query_blocks_s
 
     assert ws(1, 32) == 0 and ws(4, 32) == 0                       # K1s
     assert ws(8, 32) == 0 and ws(16, 32) == 0 and ws(32, 32) == 0  # one query block (pair / 4-wave / 8-wave form)
-    assert ws(17, 32) == 0 and ws(20, 32) == 0 and ws(38, 32) == 0 # one block: 4-wave / 8-wave form with five tiles per wave (round 3)
-    assert ws(33, 32) == 4096 and ws(41, 32) == 4096              # two blocks
-    assert ws(33, 32) == 4096 and ws(1000, 32) == 4096
+    assert ws(17, 32) == 0 and ws(20, 32) == 0 and ws(33, 32) == 0 and ws(40, 32) == 0   # ONE block: five tiles per wave (round 3)
+    assert ws(41, 32) == 4096 and ws(64, 32) == 4096 and ws(80, 32) == 4096 and ws(1000, 32) == 4096   # several blocks
     # three-tile queries: a wave holds ONE (4 / 3), so 5 queries (15 tiles, 4 waves) and 9..10 (8 waves) are two query blocks
     assert ws(5, 96) == 4096 and ws(9, 96) == 4096 and ws(10, 96) == 4096
     assert ws(4, 96) == 0 and ws(6, 96) == 0 and ws(8, 96) == 0    # 12 tiles on 4 waves, 18 / 24 tiles on 8 waves: one block
