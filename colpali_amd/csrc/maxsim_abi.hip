@@ -362,7 +362,7 @@ int batch_dispatch(const FwdCall &c) {
     // MSIM_BATCH8: 0 = K1b only, 1 = K1b8 from `MSIM_BATCH8_MIN` tiles up; MSIM_B8_VAR: maxsim_batch8.hip's VAR (A/B knobs;
     // one-tile bf16 queries only, to bound the build time of the measurement library)
     if constexpr (TPQ == 1 && !F16) {
-        static const int b8 = ab_env("MSIM_BATCH8", 1);
+        static const int b8 = ab_env("MSIM_BATCH8", 0);      // K1b8 only on request: a K1b A/B must not silently measure K1b8
         static const int b8_min = ab_env("MSIM_BATCH8_MIN", 21);
         static const int var = ab_env("MSIM_B8_VAR", 0);
         if (b8 && tiles >= b8_min) {

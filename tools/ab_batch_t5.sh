@@ -4,7 +4,7 @@
 # form, bit 3: blocks of 40 above.  The first run writes the reference scores; every later run is compared with them bit for bit.
 # the MSIM_* knobs exist in the measurement build only: `make -C colpali_amd/csrc ab` first
 export COLPALI_AMD_LIB=${COLPALI_AMD_LIB:-tools/_ab/libmaxsim_ab.so}
-export MSIM_BATCH8=0      # the measurement build sends 21+ tiles to K1b8 otherwise
+export MSIM_BATCH8=0      # K1b, not K1b8 (the default of the measurement build since; it was 1 when the first table was taken)
 export AB_DOCS=${AB_DOCS:-65536}
 SIZES=${AB_SIZES:-9,10,17,18,20,33,36,40,64,80,256,1000}
 first=1
