@@ -51,7 +51,7 @@ def parse_args():
                          "BASELINE config 4 over 8 GPUs")
     ap.add_argument("--doc-len", type=int, default=1024)
     ap.add_argument("--nq", type=int, default=4, help="queries per step (32 tokens each); 4 = BASELINE config 1's query batch")
-    ap.add_argument("--regimes", type=str, default="1,6,8,10,12,16,32,1000",
+    ap.add_argument("--regimes", type=str, default="1,6,8,10,12,16,20,32,40,1000",
                     help="other query-batch sizes measured after the headline and reported under 'regimes' ('' = none)")
     ap.add_argument("--q-len", type=int, default=32)
     ap.add_argument("--topk", type=int, default=10)
