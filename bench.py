@@ -51,8 +51,10 @@ def parse_args():
                          "BASELINE config 4 over 8 GPUs")
     ap.add_argument("--doc-len", type=int, default=1024)
     ap.add_argument("--nq", type=int, default=4, help="queries per step (32 tokens each); 4 = BASELINE config 1's query batch")
-    ap.add_argument("--regimes", type=str, default="1,6,8,10,12,16,20,32,40,1000",
-                    help="other query-batch sizes measured after the headline and reported under 'regimes' ('' = none)")
+    ap.add_argument("--regimes", type=str, default="1,6,8,10,12,16,20,32,40,1000,4x40,16x40,1000x20,1000x40,1000x48,1000xr12-48",
+                    help="other query batches measured after the headline and reported under 'regimes' ('' = none): N = N queries of "
+                         "--q-len tokens; NxL = N queries of L tokens; NxrA-B = N queries of ragged lengths U{A..B} (real query lengths: "
+                         "processing_utils.py:86 appends 10 augmentation tokens, SURVEY: Lq ~ 20-40)")
     ap.add_argument("--q-len", type=int, default=32)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +82,26 @@ def make_queries(n_q, q_len, device, seed):
     g = torch.Generator().manual_seed(seed)
     q = torch.nn.functional.normalize(torch.randn(n_q, q_len, 128, generator=g), dim=-1).to(torch.bfloat16)
     return q.to(device)
+
+
+def parse_regime(spec, default_len):
+    """'N' | 'NxL' | 'NxrA-B' -> (n_queries, [length of every query], label)."""
+    if "x" not in spec:
+        n = int(spec)
+        return n, [default_len] * n, str(default_len)
+    n, ln = spec.split("x", 1)
+    n = int(n)
+    if ln.startswith("r"):
+        lo, hi = (int(v) for v in ln[1:].split("-"))
+        g = torch.Generator().manual_seed(1000 + n + lo * 7 + hi)
+        return n, torch.randint(lo, hi + 1, (n,), generator=g).tolist(), f"U{{{lo}..{hi}}}"
+    return n, [int(ln)] * n, ln
+
+
+def make_query_list(lens, seed):
+    """Host list of [len_i, 128] unit-row bf16 queries -- the drop-in's own input form (ragged lengths are the normal case)."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16) for n in lens]
 
 
 def cpu_baseline(q_len, doc_len):
@@ -314,7 +336,7 @@ def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
     """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list, the last
     step's score matrix, the last step's (top scores, top ids))."""
     dev = q.device
-    scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=dev)
+    scores = torch.empty((len(q), len(corpus)), dtype=torch.float32, device=dev)
 
     def step(ev=None):
         if ev is not None:
@@ -357,7 +379,7 @@ def power_sample(amd, q, corpus, seconds=1.2):
     smi = "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return None
-    scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=q.device)
+    scores = torch.empty((len(q), len(corpus)), dtype=torch.float32, device=q.device)
     got, stop = [], threading.Event()
 
     def sampler():
@@ -377,7 +399,7 @@ def power_sample(amd, q, corpus, seconds=1.2):
     th.start()
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for _ in range(max(1, 32 // q.shape[0])):
+        for _ in range(max(1, 32 // len(q))):
             amd.maxsim_scores(q, corpus, out=scores)
         torch.cuda.synchronize()
     stop.set()
@@ -450,10 +472,13 @@ def pmc_traffic(n_q, n_docs, doc_len):
     return table.get(f"nq{n_q}_docs{n_docs}_len{doc_len}")
 
 
-def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg):
+def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg, q_tokens=None):
+    """`q_tokens`: REAL query tokens in the batch (ragged batches); FLOP and bytes count real tokens only -- padding an
+    implementation adds is never credited."""
     pairs = n_q * n_docs
-    alg_bytes = n_docs * doc_len * 256 + n_q * q_len * 256 + pairs * 4   # docs streamed once per launch
-    flops = 2.0 * n_q * q_len * n_docs * doc_len * 128
+    q_tokens = n_q * q_len if q_tokens is None else q_tokens
+    alg_bytes = n_docs * doc_len * 256 + q_tokens * 256 + pairs * 4   # docs streamed once per launch
+    flops = 2.0 * q_tokens * n_docs * doc_len * 128
     sec = kern_ms_avg * 1e-3
     gbs, tf = alg_bytes / sec / 1e9, flops / sec / 1e12
     hbm_bound_s, mfma_bound_s = alg_bytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS * 1e12)
@@ -741,12 +766,18 @@ def main():
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
-    for nq in [int(x) for x in args.regimes.split(",") if x]:
-        qq = make_queries(nq, args.q_len, dev, seed=5 + nq)
+    for spec in [x for x in args.regimes.split(",") if x]:
+        nq, lens, len_label = parse_regime(spec, args.q_len)
+        if "x" in spec:      # real query lengths: a host list of ragged / non-tile-sized queries, packed as the product packs them
+            qq = amd.pack_queries(make_query_list(lens, seed=5 + nq + sum(lens)), dev)
+        else:
+            qq = make_queries(nq, args.q_len, dev, seed=5 + nq)
         steps = max(3, min(args.steps, 2000 // max(nq, 1)))
         d, km, _, _ = run_regime(amd, qq, corpus, steps, 2, args.topk, world, rank, dist)
-        r = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(km) / len(km))
-        regimes.append({"n_queries": nq, "steps": steps, "pairs_per_s": nq * args.docs * world * steps / d,
+        r = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(km) / len(km), q_tokens=sum(lens))
+        regimes.append({"n_queries": nq, "q_len": len_label, "q_tokens": sum(lens), "steps": steps,
+                        "pairs_per_s": nq * args.docs * world * steps / d,
+                        "pairs_per_s_per_32_real_tokens": nq * args.docs * world * steps / d * (sum(lens) / (32.0 * nq)),
                         "ms_per_step": d / steps * 1e3, "kernel_ms": r["kernel_ms"], "bound": r["bound"],
                         "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"]})
         if ceil_m and r["bound"] == "mfma":
