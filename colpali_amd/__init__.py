@@ -11,7 +11,7 @@ Drop-in for the MaxSim hot path of illuin-tech/colpali:
 The compute lives in hand-written HIP kernels behind a C ABI (include/maxsim.h,
 colpali_amd/csrc/); this package is the thin host-side mirror of the reference interface.
 """
-from .corpus import PackedCorpus, block_clamp0, pack_passages, pack_queries
+from .corpus import PackedCorpus, PackedQueries, block_clamp0, pack_passages, pack_queries
 from . import loss
 from .embed import CorpusWriter, embedding_head
 from .loss import (ColbertLoss, ColbertModule, ColbertNegativeCELoss, ColbertPairwiseCELoss,
@@ -36,6 +36,7 @@ __all__ = [
     "ColbertPairwiseCELoss",
     "ColbertSigmoidLoss",
     "PackedCorpus",
+    "PackedQueries",
     "maxsim",
     "ShardedRetriever",
     "ExactMaxSimIndex",

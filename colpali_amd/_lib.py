@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 def dtype_code(dtype) -> int:
@@ -81,6 +81,16 @@ def lib() -> ctypes.CDLL:
     L.msim_fwd_workspace_bytes.restype = sz
     L.msim_fwd.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
     L.msim_fwd.restype = i32
+    L.msim_fwd_ragged_workspace_bytes.argtypes = [i32, vp, i32, i32, i32]
+    L.msim_fwd_ragged_workspace_bytes.restype = sz
+    L.msim_fwd_ragged.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
+    L.msim_fwd_ragged.restype = i32
+    L.msim_query_compact.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+    L.msim_query_compact.restype = i32
+    L.msim_host_count_nonzero_rows.argtypes = [vp, vp, i64, i64, vp, i32]
+    L.msim_host_count_nonzero_rows.restype = i32
+    L.msim_host_gather_nonzero_rows.argtypes = [vp, vp, vp, i64, vp, i64, i32]
+    L.msim_host_gather_nonzero_rows.restype = i32
     L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
     L.msim_pairs_argmax.restype = i32
     L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]

@@ -244,17 +244,167 @@ def pack_passages(ps: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch
                         lengths=lengths, id_base=id_base)
 
 
-def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device) -> torch.Tensor:
-    """[n_q, Lq, width] on the device, zero padded (rows beyond a query's length and columns beyond its width).
+@dataclass
+class PackedQueries:
+    """Queries in the FLAT layout the tuned kernels take (include/maxsim.h: msim_fwd_ragged): every query's real tokens back
+    to back, like the packed corpus.  Queries are ragged in real use (processing_utils.py:86 appends 10 augmentation tokens to
+    a question of any length) and a zero row -- the model's padded positions, modeling_colpali.py:72 -- adds exactly 0 to every
+    score, so neither padding to the batch maximum nor the zero rows inside a query are carried to the GPU's matrix cores."""
+    tokens: torch.Tensor               # bf16 | f16 [T, 128], on the GPU
+    offsets: torch.Tensor              # int32 [n_q + 1], on the GPU
+    offsets_host: torch.Tensor         # int32 [n_q + 1], on the host (the launch plan is made from it)
 
-    processing_utils.py:172 pads each 128-query block to its own longest query; a zero
-    query row scores exactly 0 against everything (its max is 0), so padding all queries
-    to the global maximum returns identical values.
+    def __len__(self) -> int:
+        return int(self.offsets_host.numel()) - 1
+
+    @property
+    def device(self) -> torch.device:
+        return self.tokens.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.tokens.dtype
+
+    @property
+    def lengths(self) -> torch.Tensor:
+        return (self.offsets_host[1:] - self.offsets_host[:-1]).to(torch.int64)
+
+    def select(self, lo: int, hi: int) -> "PackedQueries":
+        """Queries lo .. hi-1 (views of the same token matrix; offsets rebased)."""
+        base = int(self.offsets_host[lo])
+        oh = (self.offsets_host[lo:hi + 1] - base).contiguous()
+        return PackedQueries(tokens=self.tokens[base:int(self.offsets_host[hi])] if hi > lo else self.tokens[:0],
+                             offsets=oh.to(self.tokens.device, non_blocking=True), offsets_host=oh)
+
+
+MAX_FLAT_QUERY_TOKENS = 1024       # a query's tokens share one workgroup (maxsim_abi.hip: flat_plan); longer ones keep the box layout
+
+
+def _is_flat_shape(dtype: torch.dtype, dim: int) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and dim == EMBED_DIM
+
+
+def _flat_from_host_list(qs: Sequence[torch.Tensor], dim: int, device: torch.device, compact: bool) -> Optional["PackedQueries"]:
+    """Host list -> flat layout: native threads count and copy the rows that are not all-zero straight into the pinned staging
+    buffer, one asynchronous upload (no torch CPU op on the way: see pack_queries)."""
+    import numpy as np
+
+    L = _lib_mod.lib()
+    es = qs[0].element_size()
+    row_bytes = dim * es
+    keep = [q if q.is_contiguous() else q.contiguous() for q in qs]
+    n = len(keep)
+    srcs = np.asarray([q.data_ptr() for q in keep], dtype=np.uint64)
+    rows = np.asarray([int(q.shape[0]) for q in keep], dtype=np.int64)
+    if compact:
+        counts = np.zeros(n, dtype=np.int32)
+        rc = L.msim_host_count_nonzero_rows(srcs.ctypes.data, rows.ctypes.data, row_bytes, n, counts.ctypes.data, _COPY_THREADS)
+        if rc != 0:
+            raise RuntimeError(f"msim_host_count_nonzero_rows failed: {L.msim_last_error().decode()}")
+    else:
+        counts = rows.astype(np.int32)
+    if int(counts.max(initial=0)) > MAX_FLAT_QUERY_TOKENS:
+        return None
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    total = int(off[-1])
+    offsets_host = torch.from_numpy(off.astype(np.int32))
+    tokens = torch.empty((max(total, 1), dim), dtype=qs[0].dtype, device=device)
+    if total == 0:
+        tokens.zero_()
+    else:
+        st = _staging_q
+        with st.lock:
+            nbytes = total * row_bytes
+            if st.buf is None or st.buf.numel() < nbytes:
+                for ev in st.events:
+                    if ev is not None:
+                        ev.synchronize()
+                st.buf = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, pin_memory=True)
+                st.events = [None, None]
+            for ev in st.events:
+                if ev is not None:
+                    ev.synchronize()          # the previous upload has left the buffer
+            dst_row = np.ascontiguousarray(off[:-1])
+            if compact:
+                rc = L.msim_host_gather_nonzero_rows(st.buf.data_ptr(), srcs.ctypes.data, rows.ctypes.data, row_bytes,
+                                                     dst_row.ctypes.data, n, _COPY_THREADS)
+            else:
+                dst_off, nb = dst_row * row_bytes, rows * row_bytes
+                rc = L.msim_host_gather(st.buf.data_ptr(), srcs.ctypes.data, dst_off.ctypes.data, nb.ctypes.data, n, _COPY_THREADS)
+            if rc != 0:
+                raise RuntimeError(f"host query gather failed: {L.msim_last_error().decode()}")
+            tokens.view(torch.uint8).view(-1)[:nbytes].copy_(st.buf[:nbytes], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            st.events = [ev, None]
+    del keep
+    return PackedQueries(tokens=tokens, offsets=offsets_host.to(device, non_blocking=True), offsets_host=offsets_host)
+
+
+def _flat_from_device_box(box: torch.Tensor, compact: bool) -> Optional["PackedQueries"]:
+    """[n_q, Lq, 128] on the GPU -> flat layout.  With `compact` the zero rows are dropped by msim_query_compact; the per-query
+    counts come back to the host (one small D2H + synchronisation: the launch plan needs the lengths)."""
+    n_q, Lq, dim = box.shape
+    box = box.contiguous()
+    if not compact or n_q == 0 or Lq == 0:
+        if Lq > MAX_FLAT_QUERY_TOKENS:
+            return None
+        oh = (torch.arange(n_q + 1, dtype=torch.int64) * Lq).to(torch.int32)
+        tok = box.reshape(n_q * Lq, dim)
+        if tok.shape[0] == 0:
+            tok = torch.zeros((1, dim), dtype=box.dtype, device=box.device)
+        return PackedQueries(tokens=tok, offsets=oh.to(box.device, non_blocking=True), offsets_host=oh)
+    if Lq > 4096:
+        return None
+    L = _lib_mod.lib()
+    row_bytes = dim * box.element_size()
+    counts = torch.empty((n_q,), dtype=torch.int32, device=box.device)
+    with torch.cuda.device(box.device):
+        stream = _lib_mod.current_stream_handle(box.device)
+        _lib_mod.check(L.msim_query_compact(_lib_mod.ptr(box), n_q, Lq, row_bytes, None, _lib_mod.ptr(counts), None, stream),
+                       "msim_query_compact")
+        counts_h = counts.cpu()
+        if int(counts_h.max()) > MAX_FLAT_QUERY_TOKENS:
+            return None
+        oh = torch.zeros(n_q + 1, dtype=torch.int32)
+        torch.cumsum(counts_h, 0, out=oh[1:])
+        off = oh.to(box.device, non_blocking=True)
+        total = int(oh[-1])
+        tokens = torch.empty((max(total, 1), dim), dtype=box.dtype, device=box.device)
+        if total == 0:
+            tokens.zero_()
+        else:
+            _lib_mod.check(L.msim_query_compact(_lib_mod.ptr(box), n_q, Lq, row_bytes, _lib_mod.ptr(off), None, _lib_mod.ptr(tokens),
+                                                stream), "msim_query_compact")
+    return PackedQueries(tokens=tokens, offsets=off, offsets_host=oh)
+
+
+def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device, *, layout: str = "auto",
+                 compact: bool = True) -> Union[torch.Tensor, "PackedQueries"]:
+    """Queries for the device.
+
+    layout="flat" (what "auto" picks on the GPU for bf16 / f16 embeddings of width 128): a `PackedQueries` -- every query's
+    tokens back to back; with `compact` (default) rows that are entirely zero are dropped, which changes no score: a zero
+    query row scores exactly 0 against everything (its max is 0).
+    layout="box": [n_q, Lq, width], zero padded (rows beyond a query's length and columns beyond its width) -- every other
+    dtype / width, CPU tensors, and queries of more than 1024 tokens.  processing_utils.py:172 pads each 128-query block to
+    its own longest query; padding all queries to the global maximum returns identical values for the same reason.
     """
+    if layout not in ("auto", "flat", "box"):
+        raise ValueError("layout must be 'auto', 'flat' or 'box'")
+    device = torch.device(device)
     if isinstance(qs, torch.Tensor):
         if qs.dim() != 3:
             raise ValueError("a query tensor must be 3-D (n_queries, max_len, dim)")
         _check_embeddings(qs, "queries")
+        if layout != "box" and device.type == "cuda" and _is_flat_shape(qs.dtype, qs.shape[2]):
+            flat = _flat_from_device_box(qs.to(device, non_blocking=True), compact)
+            if flat is not None:
+                return flat
+        if layout == "flat":
+            raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 on the GPU, at most "
+                                      f"{MAX_FLAT_QUERY_TOKENS} tokens per query")
         return _widen(qs.to(device, non_blocking=True)).contiguous()
     if len(qs) == 0:
         raise ValueError("No queries provided")
@@ -266,12 +416,23 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
             raise RuntimeError(f"expected queries of one dtype, got {qs[0].dtype} and {q.dtype}")
         if q.shape[1] != qs[0].shape[1]:
             raise RuntimeError(f"expected queries of one embedding width, got {qs[0].shape[1]} and {q.shape[1]}")
-    device = torch.device(device)
+    dim = int(qs[0].shape[1])
+    if layout != "box" and device.type == "cuda" and _is_flat_shape(qs[0].dtype, dim):
+        if all(q.device.type == "cpu" for q in qs):
+            flat = _flat_from_host_list(qs, dim, device, compact)
+        else:
+            l_max = max(int(q.shape[0]) for q in qs)
+            box = torch.nn.utils.rnn.pad_sequence([q.to(device) for q in qs], batch_first=True, padding_value=0) if l_max else None
+            flat = _flat_from_device_box(box, True) if box is not None else None
+        if flat is not None:
+            return flat
+    if layout == "flat":
+        raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 on the GPU, at most "
+                                  f"{MAX_FLAT_QUERY_TOKENS} tokens per query")
     if device.type == "cuda" and all(q.device.type == "cpu" for q in qs):
         # no torch CPU op on the way: pad_sequence's parallel loop costs tens of ms on a 128-thread host when it runs
         # between other multi-threaded work (measured 24 ms for 100 x 32 x 128), a memset + one memcpy per query costs 0.1
         l_max = max(int(q.shape[0]) for q in qs)
-        dim = int(qs[0].shape[1])
         if l_max == 0:
             padded = torch.zeros((len(qs), 0, dim), dtype=qs[0].dtype, device=device)
         else:

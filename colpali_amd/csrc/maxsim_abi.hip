@@ -15,9 +15,6 @@
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
-#ifdef MSIM_AB
-#include "maxsim_batch8.hip"   // K1b8: measured, not shipped (make ab; profiles/r03_logs/ab_batch8*.log)
-#endif
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
 #include "maxsim_bwd.hip"
@@ -45,12 +42,13 @@ int fail(int code, const char *fmt, ...) {
 // an integer A/B knob from the environment -- measurement builds only (maxsim_common.hpp: kAbBuild); the shipped library returns
 // the default without looking
 int ab_env(const char *name, int dflt) {
-    if constexpr (msim::kAbBuild) {
-        const char *e = getenv(name);
-        return e ? atoi(e) : dflt;
-    }
+#if defined(MSIM_AB) || defined(MSIM_TRACE)
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
     (void)name;
     return dflt;
+#endif
 }
 
 struct DeviceInfo {
@@ -131,7 +129,7 @@ int check_common(const void *Q, const void *D, const int32_t *d_off, int dtype, 
 }
 
 struct FwdCall {
-    const uint16_t *Q, *D;
+    const uint16_t *Q, *D;       // Q: the [n_q, Lq, 128] box (uniform queries: also a flat token matrix) or the flat token matrix (q_off)
     const int32_t *d_off;
     const uint8_t *clamp0;
     float *scores;
@@ -141,12 +139,30 @@ struct FwdCall {
     const DeviceInfo *di;
     hipStream_t st;
     void *workspace = nullptr;   // msim_fwd_workspace_bytes() bytes or null
-    int n_seg = 1;               // > 1: n_q counts 128-token segments of n_q / n_seg long queries (BatchArgs::n_seg)
+    // the flat token layout (maxsim_common.hpp)
+    const int32_t *q_off = nullptr;        // device: token offsets [n_q + 1]; null = uniform queries of Lq tokens
+    const int32_t *q_off_host = nullptr;   // the same numbers on the host: the plan below is made from them
+    int seg = 0, n_seg = 1;                // uniform long queries: n_q counts PIECES of `seg` tokens (FlatQ::n_seg)
 };
 
 constexpr size_t kFwdWorkspaceBytes = 4096;   // K1b's convoy counters: n_ranges * n_qblocks <= 8 * 64 ints
 
-constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup (launch_stream picks 2 for 3-4 tiles)
+constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup (launch_stream picks 2 for 5-8 units)
+
+// host mirror of msim::flat_qoff
+struct HostQ {
+    const int32_t *off;
+    int Lq, seg, n_seg;
+    int at(int i) const {
+        if (off) return off[i];
+        if (n_seg <= 1) return i * Lq;
+        const int r = i / n_seg, s = i - r * n_seg;
+        const int o = s * seg;
+        return r * Lq + (o < Lq ? o : Lq);
+    }
+};
+HostQ host_q(const FwdCall &c) { return HostQ{c.q_off_host, c.Lq, c.seg, c.n_seg}; }
+msim::FlatQ flat_q(const FwdCall &c) { return msim::FlatQ{c.q_off, c.Lq, c.seg, c.n_seg}; }
 
 // Cache policy of K1s's document stream: every byte is read once by one CU, so the LDS-DMA loads carry `nt`
 // (do not allocate in L2 / MALL).  Measured on MI355X, 16 GiB shard: 6.31 -> 7.02 TB/s at 1 query, 6.08 -> 6.45 TB/s
@@ -156,16 +172,16 @@ int stream_nt() {
     return v;
 }
 
-template <int QT, int TPQ, bool F16, int AUX, bool IL, int RING = kStreamRing, bool TILEMAJOR = false>
+template <int NU, bool F16, int AUX, bool IL, int RING = kStreamRing>
 int launch_stream_aux(const FwdCall &c) {
-    auto kern = msim::maxsim_stream_kernel<QT, TPQ, RING, F16, AUX, IL, TILEMAJOR>;
-    constexpr int lds = 4 * RING * msim::kSlabBytes;
+    auto kern = msim::maxsim_stream_kernel<NU, RING, F16, AUX, IL>;
+    constexpr int lds = 4 * (RING * msim::kSlabBytes + msim::kStreamTokBytes);
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     msim::StreamArgs a;
     a.ld = c.ld;
+    a.fq = flat_q(c);
     a.n_q = c.n_q;
-    a.Lq = c.Lq;
     a.n_d = c.n_d;
     a.flags = c.flags;
     const int wg_needed = (c.n_d + 3) / 4;
@@ -173,7 +189,7 @@ int launch_stream_aux(const FwdCall &c) {
     hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, c.st, c.Q, c.D, c.d_off,
                        c.clamp0, c.scores, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_stream_kernel<%d,%d> launch: %s", QT, TPQ, hipGetErrorString(e));
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_stream_kernel<%d> launch: %s", NU, hipGetErrorString(e));
     return MSIM_OK;
 }
 
@@ -185,126 +201,99 @@ int stream_il() {
     return v;
 }
 
-template <int QT, int TPQ, bool F16>
+template <int NU, bool F16>
 int launch_stream(const FwdCall &c) {
-    // 3-4 token tiles: a 2-slab ring (64 KiB per workgroup) lets TWO workgroups share a CU -- two waves per SIMD, one covering the
-    // other's DMA issue / operand reads / max folds: 4 queries 6.51-6.55 -> 6.82 TB/s (85 % of spec); 1-2 tiles are at the stream
-    // ceiling either way, 5+ tiles need more than 256 registers per wave (one wave per SIMD) and keep the deeper ring.
+    // 5-8 units (3-4 token tiles of 32): a 2-slab ring (72 KiB per workgroup) lets TWO workgroups share a CU -- two waves per SIMD,
+    // one covering the other's DMA issue / operand reads / max folds: 4 queries 6.51-6.55 -> 6.82 TB/s (85 % of spec); up to 4 units
+    // are at the stream ceiling either way and keep the deeper ring.
     // MSIM_STREAM_RING=2|4 forces one of them (tuning knob, not part of the ABI).
-    constexpr int ring_default = (QT == 3 || QT == 4) ? 2 : kStreamRing;
-    if constexpr (msim::kAbBuild) {
+    constexpr int ring_default = NU >= 5 ? 2 : kStreamRing;
+#ifdef MSIM_AB
+    {
         static const int ring_env = ab_env("MSIM_STREAM_RING", 0);
         const int ring = ring_env ? ring_env : ring_default;
-        static const bool tile_major = ab_env("MSIM_STREAM_TILEMAJOR", 0) != 0;
-        if constexpr (QT == 4 && TPQ == 1 && !F16) {
-            if (ring == 2 && tile_major) return launch_stream_aux<QT, TPQ, F16, 2, true, 2, true>(c);
+        if (ring == 2) return launch_stream_aux<NU, F16, 2, true, 2>(c);
+        if (stream_il() && stream_nt()) return launch_stream_aux<NU, F16, 2, true>(c);
+        return stream_nt() ? launch_stream_aux<NU, F16, 2, false>(c) : launch_stream_aux<NU, F16, 0, false>(c);
+    }
+#endif
+    return launch_stream_aux<NU, F16, 2, true, ring_default>(c);     // nt stream, interleaved DMA issue
+}
+
+// ---- the plan of one tuned forward call, made on the host from the queries' lengths -- ONE definition, shared by the dispatch and
+// by msim_fwd_workspace_bytes (which must report scratch exactly when the launch would use it: round-2 advisor finding).
+//   * up to 8 queries / 8 units (128 tokens) in total: K1s, every wave holds all units (HBM-bound regime, one pass over the corpus,
+//     no barriers at all);
+//   * more: K1b, whose query blocks hold WHOLE queries -- at most nw * maxu units of tokens and nw * 8 queries (one 8-lane group of the
+//     workgroup per query in the reduction).  One block if the batch fits one of the six shapes
+//         units <= 16: pair (2 waves) | <= 20: pair, ten units per wave | <= 32: 4 waves | <= 40: 4 waves x 10 | <= 64: 8 waves | <= 80: 8 x 10
+//     (the measured ladder of rounds 2-3 in 16-token units: profiles/r02_logs/ab_ridge.log, r03_logs/ab_batch_t5.log,
+//     ab_batch8_final.log), else several blocks on the 8-wave form, filled greedily in query order and then re-cut evenly; eight or
+//     ten units per wave by cost: a block's pace is set by its heaviest wave, so a plan costs (blocks) x (units of the heaviest
+//     wave), and the ten-unit bodies run ~10 % behind the eight-unit ones per step.
+struct FlatPlan {
+    bool stream = false;
+    int nu = 0;                   // K1s: units per wave
+    int nw = 0, maxu = 0;         // K1b
+    std::vector<int> blk_q0;      // K1b: first query of every block, + n_q
+    int n_blocks() const { return (int)blk_q0.size() - 1; }
+};
+
+// greedy fill in query order under (token, query) capacities; false if one query alone exceeds a block
+bool fill_blocks(const HostQ &hq, int n_q, int nw, int maxu, std::vector<int> &blk) {
+    const int cap_tok = nw * maxu * msim::kUnitTok, cap_q = nw * 8;
+    blk.clear();
+    blk.push_back(0);
+    int cur_tok = 0, cur_q = 0;
+    for (int i = 0; i < n_q; ++i) {
+        const int len = hq.at(i + 1) - hq.at(i);
+        if (len > cap_tok) return false;
+        if (cur_q == cap_q || cur_tok + len > cap_tok) {
+            blk.push_back(i);
+            cur_tok = 0;
+            cur_q = 0;
         }
-        if (ring == 2) return launch_stream_aux<QT, TPQ, F16, 2, true, 2>(c);
-        if (stream_il() && stream_nt()) return launch_stream_aux<QT, TPQ, F16, 2, true>(c);
-        return stream_nt() ? launch_stream_aux<QT, TPQ, F16, 2, false>(c) : launch_stream_aux<QT, TPQ, F16, 0, false>(c);
+        cur_tok += len;
+        ++cur_q;
     }
-    return launch_stream_aux<QT, TPQ, F16, 2, true, ring_default>(c);     // nt stream, interleaved DMA issue
+    blk.push_back(n_q);
+    return true;
 }
 
-template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0, int MAXT = 4>
-int launch_batch(const FwdCall &c) {
-    auto kern = msim::maxsim_batch_kernel<TPQ, F16, NW, RING, AUX, MAXT>;
-    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes;   // 96 KiB (8 waves) / 48 KiB (4 waves) / 32 KiB (pair, ring of 4)
-    constexpr int wg_per_cu = 8 / NW;
-    static std::atomic<int> configured[kMaxDevices];
-    if (int rc = allow_lds(kern, lds, configured)) return rc;
-    msim::BatchArgs a{};
-    a.ld = c.ld;
-    a.n_q = c.n_q;
-    a.Lq = c.Lq;
-    a.n_d = c.n_d;
-    a.flags = c.flags;
-    a.n_seg = c.n_seg;
-    const int q_per_block = NW * (MAXT / TPQ);                      // at most; the kernel splits n_q evenly over the blocks
-    a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
-    // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
-    const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
-    int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
-    // Two workgroups share a CU in the 4-wave form, and the matrix pipe serves the OLDER wave first: of two workgroups that start
-    // together one finishes after ~2/3 of the launch and the other runs its last third alone, one wave per SIMD, which cannot fill
-    // the pipe (tools/trace_batch.py: workgroup 0 busy for 68 % of the launch; SQ_WAVE_CYCLES: 83 % occupancy).  With 8 x more, smaller
-    // ranges than resident workgroups a finished workgroup is replaced at once and the lone phase shrinks to the last range: +3-5 %
-    // at 9..16 queries (profiles/r02_logs/ab_batch_over.log; the pair form, 5..8 queries, does not gain and keeps one range per
-    // resident workgroup).  Only when one query block streams the corpus (no L2 sharing between blocks to preserve), and never down
-    // to ranges of fewer than ~16 documents.
-    static const int over_env = ab_env("MSIM_BATCH_OVER", NW == 4 ? 8 : 1);
-    if (NW < 8 && a.n_qblocks == 1 && over_env > 1) {
-        int over = over_env;
-        while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
-        sub *= over;
+// the same number of blocks, cut evenly by tokens (a block's pace is its heaviest wave: 31 + 32 + 31 + ... beats 32 + 32 + ... + 8);
+// kept only if every block still fits
+void balance_blocks(const HostQ &hq, int n_q, int nw, int maxu, std::vector<int> &blk) {
+    const int nb = (int)blk.size() - 1;
+    if (nb <= 1) return;
+    const int cap_tok = nw * maxu * msim::kUnitTok, cap_q = nw * 8;
+    const long long base = hq.at(0), total = (long long)hq.at(n_q) - base;
+    std::vector<int> cut(1, 0);
+    int q = 0;
+    for (int b = 1; b < nb; ++b) {
+        const long long want = (total * b + nb - 1) / nb;         // tokens in front of block b
+        while (q < n_q && (long long)hq.at(q) - base < want) ++q;
+        if (q <= cut.back()) q = cut.back() + 1;
+        if (q >= n_q) return;
+        cut.push_back(q);
     }
-    a.n_ranges = 8 * sub;
-    const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
-    // convoy (maxsim_batch.hip): only when several query blocks share a range AND all of them are resident at once
-    a.convoy = nullptr;
-    static const bool convoy_off = ab_env("MSIM_BATCH_CONVOY", 1) == 0;
-    if (c.workspace && !convoy_off && a.n_qblocks > 1 && a.n_qblocks <= cus_per_xcd && a.n_qblocks <= 64 &&
-        (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
-        a.convoy = static_cast<int *>(c.workspace);
-        if (hipMemsetAsync(a.convoy, 0, (size_t)a.n_ranges * a.n_qblocks * sizeof(int), c.st) != hipSuccess)
-            return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
-    }
-    a.trace = nullptr;
-    if constexpr (msim::kTraceBuild) {                       // `make trace` only: device address of 8 x 8 uint64 (tools/trace_batch.py)
-        if (const char *tp = getenv("MSIM_BATCH_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
-    }
-    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", TPQ, NW, hipGetErrorString(e));
-    return MSIM_OK;
+    cut.push_back(n_q);
+    for (int b = 0; b < nb; ++b)
+        if (hq.at(cut[b + 1]) - hq.at(cut[b]) > cap_tok || cut[b + 1] - cut[b] > cap_q) return;
+    blk.swap(cut);
 }
 
-#ifdef MSIM_AB
-// K1b8 (maxsim_batch8.hip): one 512-register wave per SIMD, up to 8 token tiles per wave, NW waves per document stream
-template <int TPQ, bool F16, int NW, int RING, int AUX, int VAR = 0>
-int launch_batch8(const FwdCall &c) {
-    auto kern = msim::maxsim_batch8_kernel<TPQ, F16, NW, RING, AUX, VAR>;
-    constexpr int lds = RING * NW * msim::kSlabBytes;               // 96 KiB (4 waves, ring 3) / 64 KiB (2 waves, ring 4)
-    constexpr int wg_per_cu = 4 / NW;
-    static std::atomic<int> configured[kMaxDevices];
-    if (int rc = allow_lds(kern, lds, configured)) return rc;
-    msim::BatchArgs a{};
-    a.ld = c.ld;
-    a.n_q = c.n_q;
-    a.Lq = c.Lq;
-    a.n_d = c.n_d;
-    a.flags = c.flags;
-    const int q_per_block = NW * (8 / TPQ);
-    a.n_qblocks = (c.n_q + q_per_block - 1) / q_per_block;
-    const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
-    int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
-    static const int over_env = ab_env("MSIM_BATCH8_OVER", 1);
-    if (a.n_qblocks == 1 && over_env > 1) {
-        int over = over_env;
-        while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
-        sub *= over;
+int heaviest_wave_units(const HostQ &hq, const std::vector<int> &blk, int nw) {
+    int worst = 0;
+    for (size_t b = 0; b + 1 < blk.size(); ++b) {
+        const int units = (hq.at(blk[b + 1]) - hq.at(blk[b]) + msim::kUnitTok - 1) / msim::kUnitTok;
+        const int w = (units + nw - 1) / nw;
+        if (w > worst) worst = w;
     }
-    a.n_ranges = 8 * sub;
-    const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
-    a.convoy = nullptr;
-    static const bool convoy_off = ab_env("MSIM_BATCH_CONVOY", 1) == 0;
-    if (c.workspace && !convoy_off && a.n_qblocks > 1 && a.n_qblocks <= cus_per_xcd && a.n_qblocks <= 64 &&
-        (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
-        a.convoy = static_cast<int *>(c.workspace);
-        if (hipMemsetAsync(a.convoy, 0, (size_t)a.n_ranges * a.n_qblocks * sizeof(int), c.st) != hipSuccess)
-            return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
-    }
-    a.trace = nullptr;
-    hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch8_kernel<%d,%d> launch: %s", TPQ, NW, hipGetErrorString(e));
-    return MSIM_OK;
+    return worst;
 }
-
-#endif   // MSIM_AB
 
 // MSIM_BATCH_NW=2|4|8 forces the number of waves that share a document stream in K1b (tuning knob for A/B measurements, not
-// part of the ABI; 2 is only legal up to 8 token tiles).
+// part of the ABI)
 int batch_nw_override() {
     static const int v = [] {
         const int x = ab_env("MSIM_BATCH_NW", 0);
@@ -313,116 +302,160 @@ int batch_nw_override() {
     return v;
 }
 
-// The shape K1b runs a problem in -- ONE definition, shared by the dispatch below and by msim_fwd_workspace_bytes (which must
-// report scratch exactly when launch_batch would use it: round-2 advisor finding).
-// 5..8 token tiles: the pair form; 9..16: two 4-wave workgroups per CU cover each other's chunk barriers; above: one
-// 8-wave workgroup per CU (profiles/r02_logs/ab_ridge.log: 16 queries 6.57 ms with 4 waves vs 7.01 with 8, 24 queries
-// 9.97 vs 9.73).  17..20 tiles used to go to the 4-wave form, which holds 16: TWO passes over the corpus -- 17 queries 8.79 ms,
-// 20 queries 8.93 against 7.00 / 7.52 in one pass of the 8-wave form (profiles/r03_logs/ab_batch8_final.log)
-struct BatchPlan {
-    int nw;          // waves per document stream
-    int n_qblocks;   // query blocks (passes over a document range)
-    int maxt;        // token tiles a wave holds at most (4, or 5 for one-tile queries: maxsim_batch.hip MAXT)
-};
-// Which sizes take the five-tiles-per-wave form (one-tile queries; profiles/r03_logs/ab_batch_t5.log, bit-identical scores):
-//   bit 0:  9..10 tiles: the pair form 5 + 4 / 5 + 5 instead of 3/2/2/2, 3/3/2/2 on four waves (10 queries -2.7 %, 9 a tie);
-//   bit 1: 17..20 tiles: the 4-wave form 5/4/4/4 .. 5/5/5/5 instead of one pass of the 8-wave form (-7..10 %);
-//   bit 2: more than 32 tiles: blocks of up to 40 on the 8-wave form WHEN THAT IS FEWER WAVE-SLAB STEPS: a block's pace is set by its
-//          heaviest wave, so a plan costs (query blocks) x (tiles of the heaviest wave), and the five-tile bodies run ~10 % behind the
-//          four-tile ones per step.  33..40 queries: ONE pass instead of two (-16 % at 33, -12 % at 36, -7 % at 40); 73..80: two blocks of
-//          <= 40 instead of three of <= 27 (-8 % at 80); everywhere else (64, 256, 1000 ...) the four-tile plan stays (+1..10 % otherwise).
-// MSIM_BATCH_T5 overrides the mask in measurement builds (bit 3 there: blocks of 40 for every size above 40).
-constexpr int kBatchT5Default = 1 | 2 | 4;
-BatchPlan batch_plan(int n_q, int tpq) {
-    const int tiles = n_q * tpq;
-    static const int t5 = ab_env("MSIM_BATCH_T5", kBatchT5Default);
-    int nw = tiles <= 8 ? 2 : (tiles <= 16 ? 4 : 8);
-    int maxt = 4;
-    if (tpq == 1) {
-        if ((t5 & 1) && tiles >= 9 && tiles <= 10) { nw = 2; maxt = 5; }
-        else if ((t5 & 2) && tiles >= 17 && tiles <= 20) { nw = 4; maxt = 5; }
-        else if ((t5 & 8) && tiles > 40) { nw = 8; maxt = 5; }
-        else if ((t5 & 4) && tiles > 32 && tiles <= 80) {                 // measured territory only
-            const int b4 = (tiles + 31) / 32, b5 = (tiles + 39) / 40;
-            const int w4 = ((tiles + b4 - 1) / b4 + 7) / 8, w5 = ((tiles + b5 - 1) / b5 + 7) / 8;   // tiles of the heaviest wave
-            if (11 * b5 * w5 < 10 * b4 * w4) { nw = 8; maxt = 5; }
+int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
+    const long long tokens = (long long)hq.at(n_q) - hq.at(0);
+    if (tokens < 0) return fail(MSIM_EINVAL, "query token offsets are not non-decreasing");
+    const long long units = (tokens + msim::kUnitTok - 1) / msim::kUnitTok;
+    p = FlatPlan{};
+    if (n_q <= 8 && units <= 8) {
+        p.stream = true;
+        p.nu = units > 0 ? (int)units : 1;
+        return MSIM_OK;
+    }
+    static const int shapes[6][2] = {{2, 8}, {2, 10}, {4, 8}, {4, 10}, {8, 8}, {8, 10}};
+    const int forced = batch_nw_override();
+    for (const auto &sh : shapes) {
+        if (forced && sh[0] != forced) continue;
+        if (units > sh[0] * sh[1] || n_q > sh[0] * 8) continue;
+        if (!fill_blocks(hq, n_q, sh[0], sh[1], p.blk_q0) || p.n_blocks() != 1) continue;
+        p.nw = sh[0];
+        p.maxu = sh[1];
+        return MSIM_OK;
+    }
+    std::vector<int> b8, b10;
+    if (!fill_blocks(hq, n_q, 8, 8, b8)) {
+        if (!fill_blocks(hq, n_q, 8, 10, b10))
+            return fail(MSIM_EUNSUPPORTED, "a query of more than %d tokens does not fit one query block", 8 * 10 * msim::kUnitTok);
+        balance_blocks(hq, n_q, 8, 10, b10);
+        p.nw = 8;
+        p.maxu = 10;
+        p.blk_q0.swap(b10);
+        return MSIM_OK;
+    }
+    balance_blocks(hq, n_q, 8, 8, b8);
+    p.nw = 8;
+    p.maxu = 8;
+    if (fill_blocks(hq, n_q, 8, 10, b10)) {
+        balance_blocks(hq, n_q, 8, 10, b10);
+        const long long c8 = (long long)(b8.size() - 1) * heaviest_wave_units(hq, b8, 8);
+        const long long c10 = (long long)(b10.size() - 1) * heaviest_wave_units(hq, b10, 8);
+        if (11 * c10 < 10 * c8) {
+            p.maxu = 10;
+            p.blk_q0.swap(b10);
+            return MSIM_OK;
         }
     }
-    const int forced = batch_nw_override();
-    if (maxt == 4 && forced && (forced != 2 || tiles <= 8)) nw = forced;
-    const int q_per_block = nw * (maxt / tpq);
-    return BatchPlan{nw, (n_q + q_per_block - 1) / q_per_block, maxt};
+    p.blk_q0.swap(b8);
+    return MSIM_OK;
 }
 
-template <int TPQ, bool F16>
-int batch_dispatch(const FwdCall &c) {
-    const int tiles = c.n_q * TPQ;
-    (void)tiles;
-#ifdef MSIM_AB
-    // MSIM_BATCH8: 0 = K1b only, 1 = K1b8 from `MSIM_BATCH8_MIN` tiles up; MSIM_B8_VAR: maxsim_batch8.hip's VAR (A/B knobs;
-    // one-tile bf16 queries only, to bound the build time of the measurement library)
-    if constexpr (TPQ == 1 && !F16) {
-        static const int b8 = ab_env("MSIM_BATCH8", 0);      // K1b8 only on request: a K1b A/B must not silently measure K1b8
-        static const int b8_min = ab_env("MSIM_BATCH8_MIN", 21);
-        static const int var = ab_env("MSIM_B8_VAR", 0);
-        if (b8 && tiles >= b8_min) {
-            if (tiles <= 16) return (var & 1) ? launch_batch8<1, false, 2, 4, 2, 1>(c) : launch_batch8<1, false, 2, 4, 2, 0>(c);
-            if (tiles <= 32) return (var & 1) ? launch_batch8<1, false, 4, 3, 2, 1>(c) : launch_batch8<1, false, 4, 3, 2, 0>(c);
-            switch (var) {
-                case 1: return launch_batch8<1, false, 4, 3, 0, 1>(c);
-                case 2: return launch_batch8<1, false, 4, 3, 0, 2>(c);
-                case 3: return launch_batch8<1, false, 4, 3, 0, 3>(c);
-                case 4: return launch_batch8<1, false, 4, 3, 0, 4>(c);
-                case 7: return launch_batch8<1, false, 4, 3, 0, 7>(c);
-                case 8: return launch_batch8<1, false, 4, 3, 0, 8>(c);
-                case 9: return launch_batch8<1, false, 4, 3, 0, 9>(c);
-                default: return launch_batch8<1, false, 4, 3, 0, 0>(c);
+template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
+int launch_batch(const FwdCall &c, const FlatPlan &plan) {
+    auto kern = msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
+    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes + NW * MAXU * msim::kUnitTok * 16 + NW * 8 * 8;   // ring + the per-token max table + the queries' token ranges
+    constexpr int wg_per_cu = 8 / NW;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
+    const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * wg_per_cu;   // resident workgroups per XCD
+    static const int over_env = ab_env("MSIM_BATCH_OVER", NW == 4 ? 8 : 1);
+    static const bool convoy_off = ab_env("MSIM_BATCH_CONVOY", 1) == 0;
+    const int total_blocks = plan.n_blocks();
+    for (int b0 = 0; b0 < total_blocks; b0 += msim::kMaxQBlocks) {       // the block table travels in the kernel arguments
+        msim::BatchArgs a{};
+        a.ld = c.ld;
+        a.fq = flat_q(c);
+        a.n_d = c.n_d;
+        a.flags = c.flags;
+        a.n_qblocks = total_blocks - b0 < msim::kMaxQBlocks ? total_blocks - b0 : msim::kMaxQBlocks;
+        for (int b = 0; b <= a.n_qblocks; ++b) a.blk_q0[b] = plan.blk_q0[b0 + b];
+        // Ranges per XCD.  An XCD's workgroups are handed out in blockIdx order, range-major: (range 0, all query blocks), (range 1, ...),
+        // so the slots of one XCD are a queue its CUs drain.  One block: one range per resident workgroup.  Several blocks: the number
+        // of slots (blocks x ranges) should fill whole rounds of the XCD's resident workgroups -- 40 blocks on 32 CUs in ONE range each
+        // are two rounds, the second a quarter full (round 4, 1000 queries x 40 tokens: 1125 ms; four ranges = 160 slots = five full
+        // rounds); 20 blocks in one range leave 12 of 32 CUs idle.  Smallest number of ranges whose last round is >= 97 % full, else
+        // the fullest; never ranges of fewer than ~64 documents.
+        int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
+        if (a.n_qblocks > 1) {
+            double best = 0.0;
+            int best_sub = 1;
+            for (int s = 1; s <= 32; ++s) {
+                if (s > 1 && (long long)8 * s * 64 > c.n_d) break;
+                const long long slots_x = (long long)a.n_qblocks * s;
+                const long long rounds = (slots_x + cus_per_xcd - 1) / cus_per_xcd;
+                const double eff = (double)slots_x / (double)(rounds * cus_per_xcd);
+                if (eff > best + 1e-9) {
+                    best = eff;
+                    best_sub = s;
+                }
+                if (eff >= 0.97) break;
             }
+            sub = best_sub;
         }
-    }
+        // Two workgroups share a CU in the 4-wave form, and the matrix pipe serves the OLDER wave first: of two workgroups that start
+        // together one finishes after ~2/3 of the launch and the other runs its last third alone, one wave per SIMD, which cannot fill
+        // the pipe (tools/trace_batch.py: workgroup 0 busy for 68 % of the launch; SQ_WAVE_CYCLES: 83 % occupancy).  With 8 x more, smaller
+        // ranges than resident workgroups a finished workgroup is replaced at once and the lone phase shrinks to the last range: +3-5 %
+        // at 9..16 queries (profiles/r02_logs/ab_batch_over.log; the pair form does not gain and keeps one range per resident
+        // workgroup).  Only when one query block streams the corpus (no L2 sharing between blocks to preserve), and never down
+        // to ranges of fewer than ~16 documents.
+        if (NW < 8 && a.n_qblocks == 1 && over_env > 1) {
+            int over = over_env;
+            while (over > 1 && (long long)8 * sub * over * 16 > c.n_d) over >>= 1;
+            sub *= over;
+        }
+        a.n_ranges = 8 * sub;
+        const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
+        // convoy (maxsim_batch.hip): only when several query blocks share a range AND all of them are resident at once
+        a.convoy = nullptr;
+        if (c.workspace && !convoy_off && a.n_qblocks > 1 && (long long)a.n_qblocks * sub <= cus_per_xcd && a.n_qblocks <= 64 &&
+            (size_t)a.n_ranges * a.n_qblocks * sizeof(int) <= kFwdWorkspaceBytes) {
+            a.convoy = static_cast<int *>(c.workspace);
+            if (hipMemsetAsync(a.convoy, 0, (size_t)a.n_ranges * a.n_qblocks * sizeof(int), c.st) != hipSuccess)
+                return fail(MSIM_ELAUNCH, "hipMemsetAsync(convoy counters) failed");
+        }
+        a.trace = nullptr;
+#ifdef MSIM_TRACE
+        if (const char *tp = getenv("MSIM_BATCH_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
 #endif
-    const BatchPlan plan = batch_plan(c.n_q, TPQ);
-    const int nw = plan.nw;
-    // one query block = every corpus byte is read once by one workgroup: stream it past L2 / MALL (nt), like K1s does.
-    // MSIM_BATCH_NT=0 switches that off for A/B measurements (tuning knob, not part of the ABI).
-    static const bool nt_off = ab_env("MSIM_BATCH_NT", 1) == 0;
-    const int q_per_block = nw * (plan.maxt / TPQ);
-    const bool single_block = c.n_q <= q_per_block && !nt_off;
-    if constexpr (TPQ == 1) {
-        if (plan.maxt == 5) {
-            if (nw == 2) return launch_batch<1, F16, 2, 4, 2, 5>(c);
-            if (nw == 4) return launch_batch<1, F16, 4, 3, 2, 5>(c);
-            return single_block ? launch_batch<1, F16, 8, 3, 2, 5>(c) : launch_batch<1, F16, 8, 3, 0, 5>(c);
-        }
+        hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", NW, MAXU, hipGetErrorString(e));
     }
-    if (nw == 2) return single_block ? launch_batch<TPQ, F16, 2, 4, 2>(c) : launch_batch<TPQ, F16, 2, 4, 0>(c);
-    if (nw == 4) return single_block ? launch_batch<TPQ, F16, 4, 3, 2>(c) : launch_batch<TPQ, F16, 4, 3, 0>(c);
-    return single_block ? launch_batch<TPQ, F16, 8, 3, 2>(c) : launch_batch<TPQ, F16, 8, 3, 0>(c);
+    return MSIM_OK;
 }
 
 template <bool F16>
 int fwd_dispatch(const FwdCall &c) {
-    const int tpq = (c.Lq + msim::kTokTile - 1) / msim::kTokTile;
-    const int n_q = c.n_q;
-    // up to 4 token tiles in total every wave of K1s holds all of them (HBM-bound regime, one pass over the corpus, no
-    // barriers at all); above that the tiles are spread over the 2 / 4 / 8 waves that share a document stream in K1b
-    if (n_q * tpq > 4) {
-        if (tpq == 1) return batch_dispatch<1, F16>(c);
-        if (tpq == 2) return batch_dispatch<2, F16>(c);
-        if (tpq == 3) return batch_dispatch<3, F16>(c);
-        return batch_dispatch<4, F16>(c);
+    thread_local FlatPlan plan;
+    if (int rc = flat_plan(host_q(c), c.n_q, plan)) return rc;
+    if (plan.stream) {
+        switch (plan.nu) {
+            case 1: return launch_stream<1, F16>(c);
+            case 2: return launch_stream<2, F16>(c);
+            case 3: return launch_stream<3, F16>(c);
+            case 4: return launch_stream<4, F16>(c);
+            case 5: return launch_stream<5, F16>(c);
+            case 6: return launch_stream<6, F16>(c);
+            case 7: return launch_stream<7, F16>(c);
+            default: return launch_stream<8, F16>(c);
+        }
     }
-    switch (n_q * 10 + tpq) {
-        case 11: return launch_stream<1, 1, F16>(c);
-        case 21: return launch_stream<2, 1, F16>(c);
-        case 31: return launch_stream<3, 1, F16>(c);
-        case 41: return launch_stream<4, 1, F16>(c);
-        case 12: return launch_stream<2, 2, F16>(c);
-        case 22: return launch_stream<4, 2, F16>(c);
-        case 13: return launch_stream<3, 3, F16>(c);
-        case 14: return launch_stream<4, 4, F16>(c);
-        default: return fail(MSIM_EUNSUPPORTED, "no kernel for %d queries x %d token tiles", n_q, tpq);
-    }
+    // one query block = every corpus byte is read once by one workgroup: stream it past L2 / MALL (nt), like K1s does.
+    // MSIM_BATCH_NT=0 switches that off for A/B measurements (tuning knob, not part of the ABI).
+    static const bool nt_off = ab_env("MSIM_BATCH_NT", 1) == 0;
+    const bool single = plan.n_blocks() == 1 && !nt_off;
+    if (plan.nw == 2) return plan.maxu == 10 ? launch_batch<F16, 2, 4, 2, 10>(c, plan) : launch_batch<F16, 2, 4, 2, 8>(c, plan);
+    if (plan.nw == 4) return plan.maxu == 10 ? launch_batch<F16, 4, 3, 2, 10>(c, plan) : launch_batch<F16, 4, 3, 2, 8>(c, plan);
+    if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10>(c, plan) : launch_batch<F16, 8, 3, 0, 10>(c, plan);
+    return single ? launch_batch<F16, 8, 3, 2, 8>(c, plan) : launch_batch<F16, 8, 3, 0, 8>(c, plan);
+}
+
+// scratch of a tuned forward call: K1b's convoy counters, needed once several query blocks stream a document range
+size_t flat_workspace_bytes(const HostQ &hq, int n_q) {
+    thread_local FlatPlan plan;
+    if (flat_plan(hq, n_q, plan) != MSIM_OK) return 0;
+    return (!plan.stream && plan.n_blocks() > 1) ? kFwdWorkspaceBytes : 0;
 }
 
 template <int TPQ, bool F16>
@@ -771,7 +804,7 @@ int launch_stream_panels(const FwdCall &c) {
     constexpr int lds = 4 * msim::kPanelRing * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
-    msim::StreamArgs a;
+    msim::PanelStreamArgs a;
     a.ld = c.ld;
     a.n_q = c.n_q;
     a.Lq = c.Lq;
@@ -792,7 +825,7 @@ int launch_batch_panels(const FwdCall &c) {
     constexpr int lds = msim::kPanelStages * kPanels320 * msim::kSlabBytes;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
-    msim::BatchArgs a{};
+    msim::PanelBatchArgs a{};
     a.ld = c.ld;
     a.n_q = c.n_q;
     a.Lq = c.Lq;
@@ -842,12 +875,51 @@ size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim) {
     // document range (bf16 / fp16, width 128).  Passing NULL instead only switches the convoy off; a non-null workspace must hold
     // at least the bytes reported here (4096 whenever it is non-zero).
     if (n_q <= 0 || n_d <= 0 || Lq <= 0) return 0;
-    if (is_long_tuned(dtype, dim, Lq))                                              // segments on K1b: counters + the partial sums
+    if (is_long_tuned(dtype, dim, Lq))                                              // pieces on K1b: counters + the partial sums
         return kFwdWorkspaceBytes + (size_t)n_q * long_segments(Lq) * n_d * sizeof(float);
     if (!is_tuned(dtype, dim, Lq)) return 0;
-    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
-    if ((long long)n_q * tpq <= 4) return 0;                                        // K1s: no scratch
-    return batch_plan(n_q, tpq).n_qblocks > 1 ? kFwdWorkspaceBytes : 0;             // exactly launch_batch's condition
+    return flat_workspace_bytes(HostQ{nullptr, Lq, 0, 1}, n_q);                     // exactly launch_batch's condition
+}
+
+size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim) {
+    if (n_q <= 0 || n_d <= 0 || !q_off_host) return 0;
+    if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || dim != msim::kDim) return 0;
+    return flat_workspace_bytes(HostQ{q_off_host, 0, 0, 1}, n_q);
+}
+
+int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32_t *q_off_host, int n_q, const void *D,
+                    const int32_t *d_off, const uint8_t *d_clamp0, int n_d, int dim, float *scores, int64_t ld_scores,
+                    uint32_t flags, void *workspace, void *stream) {
+    if (n_q < 0 || n_d < 0) return fail(MSIM_EINVAL, "negative size (n_q=%d n_d=%d)", n_q, n_d);
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!scores || !Qt || !D || !d_off || !q_off || !q_off_host) return fail(MSIM_EINVAL, "null pointer argument");
+    if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || dim != msim::kDim)
+        return fail(MSIM_EUNSUPPORTED, "msim_fwd_ragged takes bfloat16 / float16 embeddings of width %d (dtype code %d, dim %d): "
+                    "pad the queries to one length and call msim_fwd", msim::kDim, dtype, dim);
+    if ((reinterpret_cast<uintptr_t>(Qt) | reinterpret_cast<uintptr_t>(D)) & 15) return fail(MSIM_EINVAL, "Qt and D must be 16-byte aligned");
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
+    if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
+    if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
+    if (q_off_host[0] != 0) return fail(MSIM_EINVAL, "q_off[0] must be 0");
+    for (int i = 0; i < n_q; ++i)
+        if (q_off_host[i + 1] < q_off_host[i]) return fail(MSIM_EINVAL, "q_off must be non-decreasing (query %d)", i);
+    FwdCall c;
+    if (int rc = device_info(&c.di)) return rc;
+    c.Q = static_cast<const uint16_t *>(Qt);
+    c.D = static_cast<const uint16_t *>(D);
+    c.d_off = d_off;
+    c.clamp0 = d_clamp0;
+    c.scores = scores;
+    c.ld = ld_scores;
+    c.n_q = n_q;
+    c.Lq = 0;
+    c.n_d = n_d;
+    c.flags = flags;
+    c.st = static_cast<hipStream_t>(stream);
+    c.workspace = workspace;
+    c.q_off = q_off;
+    c.q_off_host = q_off_host;
+    return dtype == MSIM_DTYPE_F16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c);
 }
 
 int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
@@ -877,9 +949,11 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
             return dtype == MSIM_DTYPE_F16 ? panels_dispatch<true>(c) : panels_dispatch<false>(c);
         }
     }
+    // long queries in the tuned dtype / width (pages as queries, image-to-image retrieval, the trainer's symmetric direction): 128-token
+    // PIECES on K1b -- MaxSim is a sum over query tokens, and in the flat token layout a piece is nothing but another pair of token
+    // offsets -- partial token sums into the scratch, added in piece order: 3-4 x the generic kernels' rate on a large corpus.
+    // The piece rows are reduced 65 535 queries at a time (grid.y of segment_sum_kernel).
     if (is_long_tuned(dtype, dim, Lq) && workspace != nullptr && (long long)n_q * long_segments(Lq) <= 0x7fffffff / 8) {
-        // long queries (pages as queries, image-to-image retrieval, the trainer's symmetric direction): 128-token segments on K1b,
-        // partial token sums into the scratch, added in segment order -- 3-4 x the generic kernels' rate on a large corpus
         if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
         const int n_seg = long_segments(Lq);
         float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + kFwdWorkspaceBytes);
@@ -897,18 +971,23 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
         c.flags = flags | msim::kFlagPartial;
         c.st = static_cast<hipStream_t>(stream);
         c.workspace = workspace;
+        c.seg = kLongSegRows;
         c.n_seg = n_seg;
         const bool f16 = dtype == MSIM_DTYPE_F16;
-        if (n_q > 65535) return fail(MSIM_EUNSUPPORTED, "too many long queries (%d) for one launch", n_q);
-        if (int rc = f16 ? batch_dispatch<4, true>(c) : batch_dispatch<4, false>(c)) return rc;
-        const dim3 grid((n_d + 255) / 256, n_q);
+        if (int rc = f16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c)) return rc;
         const bool round_total = (flags & MSIM_FLAG_REF_ROUNDING) != 0;
-        if (f16)
-            hipLaunchKernelGGL(msim::segment_sum_kernel<true>, grid, dim3(256), 0, c.st, partial, (long long)n_d, n_seg, n_d, scores,
-                               (long long)ld_scores, round_total);
-        else
-            hipLaunchKernelGGL(msim::segment_sum_kernel<false>, grid, dim3(256), 0, c.st, partial, (long long)n_d, n_seg, n_d, scores,
-                               (long long)ld_scores, round_total);
+        for (int q0 = 0; q0 < n_q; q0 += 65535) {
+            const int nq = n_q - q0 < 65535 ? n_q - q0 : 65535;
+            const dim3 grid((n_d + 255) / 256, nq);
+            const float *part = partial + (size_t)q0 * n_seg * n_d;
+            float *out = scores + (size_t)q0 * ld_scores;
+            if (f16)
+                hipLaunchKernelGGL(msim::segment_sum_kernel<true>, grid, dim3(256), 0, c.st, part, (long long)n_d, n_seg, n_d, out,
+                                   (long long)ld_scores, round_total);
+            else
+                hipLaunchKernelGGL(msim::segment_sum_kernel<false>, grid, dim3(256), 0, c.st, part, (long long)n_d, n_seg, n_d, out,
+                                   (long long)ld_scores, round_total);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(MSIM_ELAUNCH, "segment_sum_kernel launch: %s", hipGetErrorString(e));
         return MSIM_OK;
@@ -1477,6 +1556,99 @@ int msim_host_gather(void *dst, const void *const *src, const int64_t *dst_off, 
         }
     }
     for (auto &t : pool) t.join();
+    return MSIM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+inline bool row_is_zero(const char *p, int64_t row_bytes) {
+    int64_t i = 0;
+    uint64_t acc = 0;
+    for (; i + 8 <= row_bytes; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        acc |= v;
+    }
+    for (; i < row_bytes; ++i) acc |= (unsigned char)p[i];
+    return acc == 0;
+}
+
+template <class F>
+void host_parallel(int64_t n, int n_threads, int64_t work_bytes, F &&body) {
+    int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    if (work_bytes < (int64_t)(4 << 20) * nt) nt = (int)(work_bytes >> 22) < 1 ? 1 : (int)(work_bytes >> 22);
+    if (nt <= 1 || n < 2) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nt);
+    const int64_t per = (n + nt - 1) / nt;
+    for (int64_t lo = 0; lo < n; lo += per) pool.emplace_back(body, lo, lo + per < n ? lo + per : n);
+    for (auto &t : pool) t.join();
+}
+}  // namespace
+
+extern "C" {
+
+int msim_host_count_nonzero_rows(const void *const *src, const int64_t *rows, int64_t row_bytes, int64_t n, int32_t *counts,
+                                 int n_threads) {
+    if (n < 0 || row_bytes <= 0) return fail(MSIM_EINVAL, "bad size");
+    if (n == 0) return MSIM_OK;
+    if (!src || !rows || !counts) return fail(MSIM_EINVAL, "null pointer argument");
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] > 0x7fffffff || (rows[i] > 0 && !src[i])) return fail(MSIM_EINVAL, "bad buffer %lld", (long long)i);
+        total += rows[i] * row_bytes;
+    }
+    host_parallel(n, n_threads, total, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const char *p = static_cast<const char *>(src[i]);
+            int32_t c = 0;
+            for (int64_t r = 0; r < rows[i]; ++r) c += row_is_zero(p + r * row_bytes, row_bytes) ? 0 : 1;
+            counts[i] = c;
+        }
+    });
+    return MSIM_OK;
+}
+
+int msim_host_gather_nonzero_rows(void *dst, const void *const *src, const int64_t *rows, int64_t row_bytes, const int64_t *dst_row,
+                                  int64_t n, int n_threads) {
+    if (n < 0 || row_bytes <= 0) return fail(MSIM_EINVAL, "bad size");
+    if (n == 0) return MSIM_OK;
+    if (!dst || !src || !rows || !dst_row) return fail(MSIM_EINVAL, "null pointer argument");
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (rows[i] < 0 || dst_row[i] < 0 || (rows[i] > 0 && !src[i])) return fail(MSIM_EINVAL, "bad buffer %lld", (long long)i);
+        total += rows[i] * row_bytes;
+    }
+    char *d = static_cast<char *>(dst);
+    host_parallel(n, n_threads, total, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const char *p = static_cast<const char *>(src[i]);
+            char *o = d + dst_row[i] * row_bytes;
+            for (int64_t r = 0; r < rows[i]; ++r) {
+                if (row_is_zero(p + r * row_bytes, row_bytes)) continue;
+                memcpy(o, p + r * row_bytes, (size_t)row_bytes);
+                o += row_bytes;
+            }
+        }
+    });
+    return MSIM_OK;
+}
+
+int msim_query_compact(const void *box, int n_q, int Lq, int row_bytes, const int32_t *q_off, int32_t *counts, void *out,
+                       void *stream) {
+    if (n_q < 0 || Lq < 0 || row_bytes <= 0 || (row_bytes & 15)) return fail(MSIM_EINVAL, "bad size (row bytes must be a multiple of 16)");
+    if (n_q == 0 || Lq == 0) return MSIM_OK;
+    if (!box || (!counts && !(q_off && out))) return fail(MSIM_EINVAL, "null pointer argument");
+    if (Lq > msim::kCompactMaxRows) return fail(MSIM_EUNSUPPORTED, "query boxes of more than %d rows are not compacted", msim::kCompactMaxRows);
+    if (reinterpret_cast<uintptr_t>(box) & 15 || reinterpret_cast<uintptr_t>(out) & 15) return fail(MSIM_EINVAL, "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(msim::query_compact_kernel, dim3(n_q), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char *>(box), Lq, row_bytes, q_off, counts, static_cast<char *>(out));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "query_compact_kernel launch: %s", hipGetErrorString(e));
     return MSIM_OK;
 }
 

@@ -38,16 +38,19 @@ constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;    // 32 KiB
 constexpr int kBatchRing = 3;
 constexpr int kBatchLds = kBatchRing * kChunkBytes;      // 96 KiB
 
+constexpr int kMaxQBlocks = 256;     // query blocks per launch (the table travels in the kernel arguments; msim_fwd loops beyond that)
+
 struct BatchArgs {
     long long ld;        // leading dimension of scores
-    int n_q, Lq, n_d;
-    int n_seg;           // > 1: the n_q "queries" are 128-token SEGMENTS of n_q / n_seg real queries of Lq tokens each (segment s of query r
-                         // = rows 128 s .. of it; the last one may be shorter); scores row = the segment's index (msim_fwd sums the segments)
-    int n_qblocks;       // query blocks: block b holds n_q / n_qblocks (+1 for the first n_q % n_qblocks) queries, <= 8 * (4 / TPQ)
+    FlatQ fq;            // where the queries sit in the flat token matrix
+    int n_d;
+    int n_qblocks;       // query blocks: block b holds the WHOLE queries blk_q0[b] .. blk_q0[b+1]-1 -- at most NW * MAXU * 16 tokens and
+                         // NW * 8 queries (host plan: maxsim_abi.hip flat_plan); its 16-token units are dealt to the waves round-robin
     int n_ranges;        // document ranges (multiple of 8: XCD x owns ranges x*sub .. x*sub+sub-1)
     unsigned flags;
     int *convoy;         // [n_ranges, n_qblocks] progress counters (zeroed before the launch) or null: see the convoy below
     unsigned long long *trace;   // debug (MSIM_BATCH_TRACE_PTR): per wave of workgroup 0, s_memtime ticks per phase of the chunk loop; null in production
+    int blk_q0[kMaxQBlocks + 1];
 };
 
 // Convoy: the workgroups of one XCD that stream the SAME document range for different query blocks share that stream through
@@ -70,19 +73,17 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
     return lo;
 }
 
-// TPQ: token tiles (32 tokens) per query, 1..4.  A wave holds whole queries: up to 4 / TPQ of them (NTMAX = TPQ * (4 / TPQ)
-// token tiles); how many it really holds is a run-time, wave-uniform number that selects the compiled loop body.
 // NW : waves per workgroup.  8 = one workgroup per CU, 128-row chunks (the MFMA-bound end: fewest query blocks per corpus pass);
-//      4 = two workgroups per CU with 64-row chunks and half the queries each: while one sits at its chunk barrier the other
-//      computes (+5 % at 9..16 queries, -2..-4 % from 64 queries up, where the doubled number of query blocks costs more).
+//      4 = two workgroups per CU with 64-row chunks and half the tokens each: while one sits at its chunk barrier the other
+//      computes (+5 % at 9..16 queries of 32 tokens, -2..-4 % from 64 up, where the doubled number of query blocks costs more);
+//      2 = the pair form, four pairs per CU.
 // RING: chunks in the shared LDS ring (4 for the pair form: 32 KiB per workgroup, 3 otherwise: 48 / 96 KiB).
 // AUX : cache policy of the LDS-DMA loads: 2 = nt (no L2 / MALL allocation) when ONE query block streams the corpus, i.e. every byte
 //       is read exactly once, as in K1s; 0 = default when several query blocks share a range through the XCD's L2.
-// MAXT: token tiles a wave holds at most: 4, or 5 (round 3; one-tile queries only): 160 B-operand registers, 128 of them pinned to
-//       AGPRs, still two waves per SIMD -- a block of NW waves then takes 5 NW queries: 9..10 queries fit the pair form 5 + 4 / 5 + 5
-//       (instead of 3/2/2/2, 3/3/2/2 on four waves), 17..20 the 4-wave form, 33..40 one pass of the 8-wave form.
-template <int TPQ, bool F16, int NW, int RING = 3, int AUX = 0, int MAXT = 4>
-__global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Q,
+// MAXU: 16-token units a wave holds at most: 8, or 10 (round 3's five-tile form): 160 B-operand registers, 128 of them pinned to
+//       AGPRs, still two waves per SIMD.  How many it really holds is a run-time, wave-uniform number that selects the compiled body.
+template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
+__global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Qt,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
                                                                const uint8_t *__restrict__ clamp0,
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *const tokmax = smem + kBatchRing * kChunkBytes;   // per-token max table of the workgroup: NW * MAXU units x 16 tokens x 16 B
 
     // ---- which (query block, document range) is this workgroup?
     const int sub = a.n_ranges >> 3;                       // ranges per XCD
@@ -116,38 +118,40 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     bool convoy_on = my_prog != nullptr;
     int g_chunk = 0;                                        // chunks consumed by this workgroup (wave-uniform)
 
-    // ---- this wave's queries: block-local query j lives in wave j % 8
-    static_assert(TPQ >= 1 && TPQ <= 4, "a wave holds whole queries of at most 4 token tiles");
-    static_assert(MAXT == 4 || (MAXT == 5 && TPQ == 1), "five tiles per wave: one-tile queries only");
-    constexpr int QPW = MAXT / TPQ;                        // queries per wave at most
-    constexpr int NTMAX = QPW * TPQ;
-    const int q_base = a.n_q / a.n_qblocks, q_extra = a.n_q % a.n_qblocks;
-    const int qb0 = qblock * q_base + (qblock < q_extra ? qblock : q_extra);   // first query of this block
-    const int qb_n = q_base + (qblock < q_extra ? 1 : 0);                       // queries in this block (<= 8 * QPW)
-    const int my_q = wave < qb_n ? (qb_n - 1 - wave) / kB1Waves + 1 : 0;     // queries of this wave (wave-uniform)
-    QueryTile qt[NTMAX];
+    // ---- this block's tokens; block-local unit u lives in wave u % NW (slot u / NW)
+    static_assert(MAXU == 8 || MAXU == 10, "a wave holds up to 8 units (10: the AGPR form)");
+    const int qb0 = a.blk_q0[qblock];                                       // first query of this block
+    const int qb_n = a.blk_q0[qblock + 1] - qb0;                            // queries in this block (<= 8 * NW)
+    const int tok0 = flat_qoff(a.fq, qb0);
+    const int n_tok = flat_qoff(a.fq, qb0 + qb_n) - tok0;                   // tokens in this block (<= 16 * NW * MAXU)
+    const int n_units = (n_tok + kUnitTok - 1) / kUnitTok;
+    const int my_nu = wave < n_units ? (n_units - 1 - wave) / kB1Waves + 1 : 0;   // units of this wave (wave-uniform)
+    QueryUnit qu[MAXU];
 #pragma unroll
-    for (int t = 0; t < NTMAX; ++t) {
-        const bool live = t / TPQ < my_q;
-        const int q = live ? qb0 + wave + kB1Waves * (t / TPQ) : 0;
-        const int n_seg = a.n_seg > 1 ? a.n_seg : 1;
-        const int seg_rows = n_seg > 1 ? TPQ * kTokTile : a.Lq;           // long queries: segments of TPQ = 4 tiles
-        const int qr = q / n_seg, sg = q - qr * n_seg;
-        const int valid = a.Lq - sg * seg_rows < seg_rows ? a.Lq - sg * seg_rows : seg_rows;
-        load_query_tile(qt[t], Q + ((size_t)qr * a.Lq + (size_t)sg * seg_rows) * kDim, (t % TPQ) * kTokTile, valid, lane, live);
+    for (int t = 0; t < MAXU; ++t)
+        load_query_unit(qu[t], Qt + (size_t)tok0 * kDim, (wave + kB1Waves * t) * kUnitTok, n_tok, lane, t < my_nu);
+    // the reduction after every document: 8 lanes per query, query j of the block in lanes 8j .. 8j+7 of the workgroup
+    // (the token range of the query waits in LDS next to the table, written by the lanes that read it back: the slab loop of the
+    // ten-unit form has no two registers to spare)
+    int *const rtab = reinterpret_cast<int *>(tokmax + kB1Waves * MAXU * kUnitTok * 16);
+    {
+        const int rq = threadIdx.x >> 3;
+        if (rq < qb_n) {
+            const int s = flat_qoff(a.fq, qb0 + rq) - tok0, e = flat_qoff(a.fq, qb0 + rq + 1) - tok0;
+            rtab[2 * rq] = s;
+            rtab[2 * rq + 1] = e;
+        }
     }
     wait_vmcnt<0>();
 #pragma unroll
-    for (int t = 0; t < NTMAX; ++t)
+    for (int t = 0; t < MAXU; ++t)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int ks = 0; ks < kKSteps16; ++ks) {
-                // five tiles: four of them live in AGPRs (MFMA srcB reads either file); left alone hipcc keeps 128 VGPRs and shuffles
-                // the rest through v_accvgpr copies inside the slab loop
-                if (MAXT > 4 && t >= 1) asm volatile("" : "+a"(qt[t].f[h][ks]));
-                else asm volatile("" : "+v"(qt[t].f[h][ks]));
-            }
+        for (int ks = 0; ks < kKSteps16; ++ks) {
+            // ten units: eight of them live in AGPRs (MFMA srcB reads either file); left alone hipcc keeps 128 VGPRs and shuffles
+            // the rest through v_accvgpr copies inside the slab loop
+            if (MAXU > 8 && t >= 2) asm volatile("" : "+a"(qu[t].f[ks]));
+            else asm volatile("" : "+v"(qu[t].f[ks]));
+        }
 
     // ---- per-lane address constants (same slab image as K1s)
     const int l16 = lane & 15, l4 = lane >> 4;
@@ -198,23 +202,56 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     for (int i = 0; i < kBatchRing - 1; ++i) produce();
 
     const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
+    const bool round_total = ref_bf16 && !(a.flags & kFlagPartial);
     int c_slot = 0;
     // MSIM_TRACE builds only (make trace -> tools/_ab/libmaxsim_trace.so): even a never-taken tracing branch in the chunk loop costs
     // the product kernel ~5 % (registers and schedule), so the stamps are compiled out of the shipped library
     const bool tracing = kTraceBuild && a.trace != nullptr && blockIdx.x == 0;
     unsigned long long tr[7] = {0, 0, 0, 0, 0, 0, 0};     // vmcnt, convoy, barrier, DMA issue, slabs, document epilogue, chunks
 
-    // the walk over [d_lo, d_hi) for a wave that holds NT token tiles (NT = 0: it only feeds the ring and keeps the barriers)
-    auto run = [&](auto nt_c) {
-    constexpr int NT = decltype(nt_c)::value;
-    constexpr bool wave_has_queries = NT > 0;
-    constexpr int NTA = NT > 0 ? NT : 1;                   // array extents (no zero-length arrays)
+    // ---- the token sums of the document whose maxima are in the table (all waves have passed a barrier since they were written)
+    auto reduce_doc = [&](int doc, bool clamp) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));        // opaque: nothing derived from it (row pointers, table addresses) is hoisted into registers that
+        const int rq = tid >> 3, ri = tid & 7;   // stay live across the slab loop (the ten-unit form spills otherwise)
+        if (rq < qb_n) {
+            float tot = reduce_query_tokens<F16>(tokmax, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
+            if (round_total) tot = round_to_input<F16>(tot);
+            if (ri == 0) scores[(size_t)(qb0 + rq) * a.ld + doc] = tot;
+        }
+    };
+    // a barrier that also orders this wave's table writes (ds_write retires out of sight of s_barrier)
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // the walk over [d_lo, d_hi) for a wave that holds NU units (NU = 0: it only feeds the ring, keeps the barriers and reduces)
+    auto run = [&](auto nu_c) {
+    constexpr int NU = decltype(nu_c)::value;
+    constexpr bool wave_has_units = NU > 0;
+    constexpr int NUA = NU > 0 ? NU : 1;                   // array extents (no zero-length arrays)
+    int pend_doc = -1;                                      // document whose maxima wait in the table (wave-uniform, the same in all waves)
+    bool pend_clamp = false;
     for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nchunk = (len + kChunkRows - 1) / kChunkRows;
-        float m[NTA][2];
+        bool clamp = false;
+        if (clamp0 != nullptr) {
+            const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
+            clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+        }
+        if (nchunk == 0) {          // a document without rows never enters the ring: every token's max is over nothing (-inf, or 0 under clamp0)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int rq = tid >> 3;
+            if (rq < qb_n && (tid & 7) == 0)
+                scores[(size_t)(qb0 + rq) * a.ld + c_idx] = (rtab[2 * rq + 1] > rtab[2 * rq] && !clamp) ? -INFINITY : 0.0f;
+            continue;
+        }
+        float m[NUA];
 #pragma unroll
-        for (int t = 0; t < NTA; ++t) m[t][0] = m[t][1] = -INFINITY;
+        for (int t = 0; t < NUA; ++t) m[t] = -INFINITY;
         auto slab = [&](int src_lds, auto tail, int rows_left) {   // src_lds: LDS byte address of the slab (wave-uniform)
             constexpr bool kTail = decltype(tail)::value;
             bf16x8 af[2][kKSteps16];
@@ -222,21 +259,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int ks = 0; ks < kKSteps16; ++ks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[g][ks]);
-#pragma unroll
-            for (int t = 0; t < NTA; ++t) {
-                TileAcc acc;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) acc.a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < kKSteps16; ++ks)
-#pragma unroll
-                    for (int hg = 0; hg < 4; ++hg)              // four independent accumulator chains per tile, round-robin
-                        acc.a[hg >> 1][hg & 1] = mfma16<F16>(af[hg & 1][ks], qt[t].f[hg >> 1][ks], acc.a[hg >> 1][hg & 1]);
-                if constexpr (kTail) tile_mask_tail(acc, rows_left, lane);   // rows past the document end do not exist
-                tile_fold(m[t], acc);
-            }
+            slab_units<F16, NUA, kTail, false>(m, af, qu, rows_left, lane, [](int) {});
         };
 
         for (int ch = 0; ch < nchunk; ++ch) {
@@ -258,15 +281,16 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             }
             ++g_chunk;
             const unsigned long long t2 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done reading the previous chunk
+            lds_barrier();                  // everyone's share landed; everyone is done reading the previous chunk (and has written its maxima)
             const unsigned long long t3 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             produce();                      // refill the buffer that was read in the previous iteration
             const unsigned long long t4 = tracing ? __builtin_amdgcn_s_memtime() : 0;
+            if (ch == 0 && pend_doc >= 0) reduce_doc(pend_doc, pend_clamp);   // the previous document's token sums, behind its barrier
 
             const int cbuf = c_slot * kChunkBytes;
             c_slot = (c_slot + 1 == kBatchRing) ? 0 : c_slot + 1;
             const int rows_in_chunk = len - ch * kChunkRows;   // >= 1
-            if constexpr (wave_has_queries) {
+            if constexpr (wave_has_units) {
                 const int n_full = rows_in_chunk >= kChunkRows ? kChunkSlabs : rows_in_chunk / kSlabRows;
 #pragma unroll 1
                 for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
@@ -274,10 +298,10 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
                 if (n_full < kChunkSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem);
             }
             if (tracing) {
-                if constexpr (wave_has_queries) {   // the MFMAs have been issued, not retired: the running maxima must be readable
+                if constexpr (wave_has_units) {     // the MFMAs have been issued, not retired: the running maxima must be readable
                     float sink = 0.f;
 #pragma unroll
-                    for (int t = 0; t < NTA; ++t) sink += m[t][0] + m[t][1];
+                    for (int t = 0; t < NUA; ++t) sink += m[t];
                     asm volatile("" ::"v"(sink));
                 }
                 const unsigned long long t5 = __builtin_amdgcn_s_memtime();
@@ -285,28 +309,20 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
             }
         }
         const unsigned long long te0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-        // ---- document epilogue (per wave, its own queries)
-        if constexpr (wave_has_queries) {
-            bool clamp = false;
-            if (clamp0 != nullptr) {
-                const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
-                clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
-            }
-            float tile_sum[NTA];
+        // ---- document epilogue: this wave's maxima into the workgroup's table; the sums are taken behind the next barrier.  ONE table:
+        // a one-chunk document has no barrier between the previous document's sums and these writes, so it gets one
+        if (nchunk == 1) lds_barrier();
+        if constexpr (wave_has_units) {
 #pragma unroll
-            for (int t = 0; t < NTA; ++t) tile_sum[t] = tile_finish<F16>(m[t], clamp, ref_bf16);
-            if (lane == 0) {
-#pragma unroll
-                for (int qq = 0; qq < NTA / TPQ; ++qq) {
-                    float tot = 0.0f;
-#pragma unroll
-                    for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[qq * TPQ + tt];
-                    if (ref_bf16 && !(a.flags & kFlagPartial)) tot = round_to_input<F16>(tot);
-                    scores[(size_t)(qb0 + wave + kB1Waves * qq) * a.ld + c_idx] = tot;
-                }
-            }
+            for (int t = 0; t < NUA; ++t) store_token_max(tokmax, wave + kB1Waves * t, m[t], lane);
         }
+        pend_doc = c_idx;
+        pend_clamp = clamp;
         if (tracing) tr[5] += __builtin_amdgcn_s_memtime() - te0;
+    }
+    if (pend_doc >= 0) {
+        lds_barrier();
+        reduce_doc(pend_doc, pend_clamp);
     }
     if (tracing && lane == 0) {
 #pragma unroll
@@ -316,13 +332,18 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         __hip_atomic_store(my_prog + qblock, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };   // run
 
-    switch (my_q) {                                        // wave-uniform; every body executes the same barriers
+    switch (my_nu) {                                       // wave-uniform; every body executes the same barriers
         case 0: run(std::integral_constant<int, 0>{}); break;
-        case 1: run(std::integral_constant<int, TPQ>{}); break;
-        case 2: if constexpr (QPW >= 2) run(std::integral_constant<int, 2 * TPQ>{}); break;
-        case 3: if constexpr (QPW >= 3) run(std::integral_constant<int, 3 * TPQ>{}); break;
-        case 4: if constexpr (QPW >= 4) run(std::integral_constant<int, 4 * TPQ>{}); break;
-        default: if constexpr (QPW >= 5) run(std::integral_constant<int, 5 * TPQ>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 5: run(std::integral_constant<int, 5>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}); break;
+        case 7: run(std::integral_constant<int, 7>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 9: if constexpr (MAXU >= 9) run(std::integral_constant<int, 9>{}); break;
+        default: if constexpr (MAXU >= 10) run(std::integral_constant<int, 10>{}); break;
     }
 }
 
@@ -340,6 +361,44 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restric
     for (int s = 0; s < n_seg; ++s) acc += p[(size_t)s * ld_part];
     if (round_total) acc = round_to_input<F16>(acc);
     scores[(size_t)q * ld + c] = acc;
+}
+
+
+// Zero rows of a [n_q, Lq, dim] query box add exactly 0 to every score (the model multiplies padded positions by the attention mask:
+// modeling_colpali.py:72, modeling_colqwen2.py:69): the flat layout drops them.  One workgroup per query.  counts != null: the number
+// of rows that are not all-zero goes to counts[q].  out != null: those rows are copied, in order, to rows q_off[q] .. of `out`.
+constexpr int kCompactMaxRows = 4096;
+__global__ __launch_bounds__(256) void query_compact_kernel(const char *__restrict__ box, int Lq, int row_bytes,
+                                                            const int32_t *__restrict__ q_off, int32_t *__restrict__ counts,
+                                                            char *__restrict__ out) {
+    __shared__ int pos[kCompactMaxRows + 1];
+    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char *src = box + (size_t)q * Lq * row_bytes;
+    const int pieces = row_bytes >> 4;
+    for (int r = wave; r < Lq; r += 4) {
+        uint32_t acc = 0;
+        for (int p = lane; p < pieces; p += 64) {
+            const i32x4 v = *reinterpret_cast<const i32x4 *>(src + (size_t)r * row_bytes + (p << 4));
+            acc |= (uint32_t)(v[0] | v[1] | v[2] | v[3]);
+        }
+        const bool nz = __ballot(acc != 0) != 0;
+        if (lane == 0) pos[r + 1] = nz ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pos[0] = 0;
+        for (int r = 0; r < Lq; ++r) pos[r + 1] += pos[r];
+        if (counts) counts[q] = pos[Lq];
+    }
+    __syncthreads();
+    if (out == nullptr) return;
+    char *dst = out + (size_t)q_off[q] * row_bytes;
+    for (int r = wave; r < Lq; r += 4) {
+        if (pos[r + 1] == pos[r]) continue;
+        for (int p = lane; p < pieces; p += 64)
+            *reinterpret_cast<i32x4 *>(dst + (size_t)pos[r] * row_bytes + (p << 4)) =
+                *reinterpret_cast<const i32x4 *>(src + (size_t)r * row_bytes + (p << 4));
+    }
 }
 
 }  // namespace msim

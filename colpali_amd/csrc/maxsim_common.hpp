@@ -207,4 +207,139 @@ __device__ __forceinline__ float tile_finish(const float (&m)[2], bool clamp, bo
     return s;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the FLAT token layout of the scorers K1s / K1b.  Queries are ragged in real use (processing_utils.py:86 appends 10
+// augmentation tokens to a question of any length; the model's zero padding rows add exactly 0) -- a [n_q, Lq_max, 128] box spends
+// MFMA work on every padding row.  The kernels therefore see ONE token matrix Qt [T, 128] (every query's real tokens back to back,
+// like the packed corpus) plus the token offsets q_off [n_q + 1], and the unit of MFMA work is 16 consecutive tokens of that matrix
+// (the N of v_mfma_f32_16x16x32), whatever query they belong to.  The per-token maxima of a document go through LDS, where
+// 8 lanes per query add their query's tokens in an order that depends on nothing but the query's length.
+constexpr int kUnitTok = 16;               // query tokens per unit = MFMA N
+
+struct QueryUnit {                         // B operands of one 16-token unit: [k-step], 16 VGPRs
+    bf16x8 f[kKSteps16];
+};
+struct UnitAcc {                           // D of one (unit, slab): [row group], 8 VGPRs
+    f32x4 a[2];
+};
+
+// how a kernel finds its queries in the flat token matrix
+struct FlatQ {
+    const int32_t *q_off;   // [n_q + 1] token offsets, or null: uniform queries of Lq tokens each
+    int Lq;                 // uniform length (q_off == null)
+    int seg, n_seg;         // n_seg > 1 (uniform only): "query" p is PIECE p % n_seg (seg tokens, the last one shorter) of query p / n_seg
+};
+__device__ __forceinline__ int flat_qoff(const FlatQ &f, int i) {
+    if (f.q_off) return f.q_off[i];
+    if (f.n_seg <= 1) return i * f.Lq;
+    const int r = i / f.n_seg, s = i - r * f.n_seg;
+    const int o = s * f.seg;
+    return r * f.Lq + (o < f.Lq ? o : f.Lq);
+}
+
+// B fragments of tokens tok0 .. tok0+15 of the token matrix Qt; tokens >= n_tok (and a dead unit) are zero rows
+__device__ __forceinline__ void load_query_unit(QueryUnit &q, const uint16_t *__restrict__ Qt, int tok0, int n_tok, int lane, bool live) {
+    const int row = tok0 + (lane & 15);
+    const bool valid = live && row < n_tok;
+    const uint16_t *p = Qt + (size_t)(valid ? row : 0) * kDim + (lane >> 4) * 8;
+#pragma unroll
+    for (int ks = 0; ks < kKSteps16; ++ks) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+        q.f[ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+__device__ __forceinline__ void unit_mask_tail(UnitAcc &acc, int rows_left, int lane) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * g + 4 * (lane >> 4) + r >= rows_left) acc.a[g][r] = -INFINITY;
+}
+
+// running max of token (lane & 15) of the unit over this lane's document rows: 4 v_max3 per unit and slab
+__device__ __forceinline__ void unit_fold(float &m, const UnitAcc &acc) {
+    m = max3(m, acc.a[0][0], acc.a[0][1]);
+    m = max3(m, acc.a[0][2], acc.a[0][3]);
+    m = max3(m, acc.a[1][0], acc.a[1][1]);
+    m = max3(m, acc.a[1][2], acc.a[1][3]);
+}
+
+// One 32-row slab (its 8 operand fragments `af` already in registers) against NU resident units.  Units are taken two at a time
+// (a "group" = the 32-token tile of rounds 1-3): 16 MFMAs on four independent accumulator chains, round-robin; an odd last unit runs
+// 8 MFMAs on two chains.  LATE: the 16 -> 1 max fold of a group is written behind the MFMAs of the NEXT group -- a VALU read of an
+// accumulator needs 12 wait states after the MFMA that writes it, and straight-line code lets hipcc spend them on MFMAs instead of
+// s_nop (K1s); K1b folds at once (two waves per SIMD cover it, and fewer live registers matter more there).
+// `hook(mf)` runs in front of MFMA number mf (K1s issues its LDS-DMA pieces there).
+template <bool F16, int NU, bool kTail, bool LATE, class Hook>
+__device__ __forceinline__ void slab_units(float (&m)[NU], const bf16x8 (&af)[2][kKSteps16], const QueryUnit *qu, int rows_left,
+                                           int lane, Hook &&hook) {
+    constexpr int NG = (NU + 1) / 2;
+    UnitAcc prev[2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n = NU - 2 * g >= 2 ? 2 : 1;      // units in this group (compile-time after unrolling)
+        UnitAcc acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[u].a[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < 2 * n) {
+                    hook((2 * g * kKSteps16 + ks * n) * 2 + j);
+                    acc[j >> 1].a[j & 1] = mfma16<F16>(af[j & 1][ks], qu[2 * g + (j >> 1)].f[ks], acc[j >> 1].a[j & 1]);
+                }
+            }
+        if constexpr (kTail) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u < n) unit_mask_tail(acc[u], rows_left, lane);
+        }
+        if constexpr (LATE) {
+            if (g > 0) {
+                unit_fold(m[2 * g - 2], prev[0]);
+                unit_fold(m[2 * g - 1], prev[1]);
+            }
+            prev[0] = acc[0];
+            prev[1] = acc[1];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u < n) unit_fold(m[2 * g + u], acc[u]);
+        }
+    }
+    if constexpr (LATE) {
+        unit_fold(m[2 * NG - 2], prev[0]);
+        if constexpr (NU % 2 == 0) unit_fold(m[2 * NG - 1], prev[1]);
+    }
+}
+
+// End of a document: the running maxima of this lane's units go to the per-token table in LDS -- token t of the table owns 4 floats,
+// one per lane group (the four row quarters of a slab); a full-wave ds_write_b32 hits 64 different banks.
+__device__ __forceinline__ void store_token_max(char *tokmax, int unit_in_table, float m, int lane) {
+    *reinterpret_cast<float *>(tokmax + ((unit_in_table * kUnitTok + (lane & 15)) << 4) + ((lane >> 4) << 2)) = m;
+}
+
+// sum over the tokens [s, e) of the table: lane i of the query's 8 lanes adds tokens s+i, s+i+8, ... in that order, then the 8 lanes
+// are folded xor 4, 2, 1 -- a pure function of the token values and e - s, the same in every kernel and for every batch composition
+template <bool F16>
+__device__ __forceinline__ float reduce_query_tokens(const char *tokmax, int s, int e, int i, bool clamp, bool ref_round) {
+    float acc = 0.0f;
+    for (int t = s + i; t < e; t += 8) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tokmax + (t << 4));
+        float x = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (clamp) x = fmaxf(x, 0.0f);
+        if (ref_round) x = round_to_input<F16>(x);
+        acc += x;
+    }
+    acc += __shfl_xor(acc, 4);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 1);
+    return acc;
+}
+
 }  // namespace msim

@@ -22,6 +22,20 @@
 
 namespace msim {
 
+// the panel kernels keep the [n_q, Lq, dim] query box of rounds 1-3 (whole queries of 32-token tiles per wave)
+struct PanelStreamArgs {
+    long long ld;   // leading dimension of scores
+    int n_q, Lq, n_d;
+    unsigned flags;
+};
+struct PanelBatchArgs {
+    long long ld;
+    int n_q, Lq, n_d;
+    int n_qblocks;       // query blocks: block b holds n_q / n_qblocks (+1 for the first n_q % n_qblocks) queries
+    int n_ranges;        // document ranges (multiple of 8: XCD x owns ranges x*sub .. x*sub+sub-1)
+    unsigned flags;
+};
+
 constexpr int kPanelBytes = 256;             // one panel of a row
 constexpr int kPanelRing = 4;                // K1sP: panel-slabs per wave-private ring
 constexpr int kPanelStages = 4;              // K1bP: stages in the shared ring
@@ -40,7 +54,7 @@ template <int QT, int TPQ, int PANELS, int KS_LAST, bool F16, int AUX>
 __global__ __launch_bounds__(256) void maxsim_stream_panels_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                                    const int32_t *__restrict__ d_off,
                                                                    const uint8_t *__restrict__ clamp0,
-                                                                   float *__restrict__ scores, StreamArgs a) {
+                                                                   float *__restrict__ scores, PanelStreamArgs a) {
     constexpr int KT = (PANELS - 1) * 8 + KS_LAST;      // k-steps of 16 elements
     constexpr int DIM = KT * 16;
     constexpr int ROW_BYTES = DIM * 2;
@@ -203,7 +217,7 @@ template <int NT, int TPQ, int PANELS, int KS_LAST, bool F16>
 __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                                       const int32_t *__restrict__ d_off,
                                                                       const uint8_t *__restrict__ clamp0,
-                                                                      float *__restrict__ scores, BatchArgs a) {
+                                                                      float *__restrict__ scores, PanelBatchArgs a) {
     constexpr int KT = (PANELS - 1) * 8 + KS_LAST;
     constexpr int DIM = KT * 16;
     constexpr int ROW_BYTES = DIM * 2;

@@ -7,8 +7,9 @@
 //       einsum("bnd,csd->bcns", Q, D).max(dim=3)[0].sum(dim=2)
 //
 // Structure (one wave = one independent pipeline, no workgroup barriers at all):
-//   * the query token tiles live in registers for the whole kernel as the MFMA
-//     B operand (32 VGPRs per 32-token tile);
+//   * the queries' tokens -- ONE flat token matrix, every query's real tokens back to back
+//     (maxsim_common.hpp: the flat layout) -- live in registers for the whole kernel as the MFMA
+//     B operand (16 VGPRs per 16-token unit, at most 8 units);
 //   * each wave walks its own documents; a document is streamed in 32-patch
 //     slabs (8 KiB) into a wave-private LDS ring (RING slabs: 4, or 2 for 3-4 token tiles
 //     so that two workgroups share a CU -- see launch_stream in maxsim_abi.hip) by LDS-DMA
@@ -20,8 +21,9 @@
 //   * swapped product mfma_f32_16x16x32_bf16(D_slab rows, Q^T) (maxsim_common.hpp: the
 //     16x16x32 tiling -- half the accumulator traffic of 32x32x16, which is what counts
 //     on a chip that clocks to its power budget): the C layout puts one query token per
-//     lane column, so the max over patches is 8 v_max3 per 32-token tile and slab in
-//     registers; two lane-group exchanges and a butterfly sum per document finish the score.
+//     lane column, so the max over patches is 4 v_max3 per 16-token unit and slab in
+//     registers; per document the maxima pass through a wave-private LDS table where 8 lanes
+//     per query add that query's tokens (whatever units they sit in) and one lane stores.
 #pragma once
 #include <type_traits>
 
@@ -31,31 +33,32 @@ namespace msim {
 
 struct StreamArgs {
     long long ld;   // leading dimension of scores
-    int n_q, Lq, n_d;
+    FlatQ fq;       // where the queries sit in the flat token matrix
+    int n_q;        // queries (<= 8: one 8-lane group of every wave per query)
+    int n_d;
     unsigned flags;
 };
 
 constexpr unsigned kFlagRefBf16 = 1u;
-constexpr unsigned kFlagPartial = 2u;     // internal (long queries scored in 128-token segments): the token sum is a PARTIAL sum, not rounded here
+constexpr unsigned kFlagPartial = 2u;     // internal (long queries scored in 128-token pieces): the token sum is a PARTIAL sum, not rounded here
+
+constexpr int kStreamTokBytes = 8 * kUnitTok * 16;   // wave-private per-token max table: 8 units x 16 tokens x 4 lane groups x 4 B = 2 KiB
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// QT  : token tiles (of 32 tokens) held by every wave = n_q * TPQ
-// TPQ : token tiles per query = ceil(Lq / 32)
+// NU  : 16-token units of the flat token matrix held by every wave (1..8) = ceil(total tokens / 16)
 // RING: slabs in the wave-private LDS ring
 // F16 : embeddings are IEEE half instead of bfloat16
 // AUX : cache-policy bits of the LDS-DMA loads (0 = default, 2 = nt: streamed once, do not keep in L2 / MALL)
 // IL  : issue the 8 LDS-DMA pieces of the next slab BETWEEN the MFMAs of the current one instead of in a block in
-//       front of them (the matrix pipe idles while a block of DMA instructions issues; one piece per QT MFMAs hides)
-// At most 4 token tiles: launch bounds ask for two waves per SIMD (<= 256 registers), which the 2-slab ring needs to put two
-// workgroups on a CU; without the bound hipcc gives every tile an accumulator of its own and lands at 290 registers.
-// TILEMAJOR: scheduling barriers between the token tiles keep the instruction stream tile by tile (8 MFMAs of one tile, the fold of
-// the previous one among them) instead of letting hipcc run all tiles' MFMAs k-step by k-step and fold everything at the end.
-template <int QT, int TPQ, int RING, bool F16, int AUX = 0, bool IL = false, bool TILEMAJOR = false>
-__global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *__restrict__ Q,       // [n_q, Lq, 128] bf16
+//       front of them (the matrix pipe idles while a block of DMA instructions issues; one piece per NU MFMAs hides)
+// At most 8 units (4 token tiles of 32): launch bounds ask for two waves per SIMD (<= 256 registers), which the 2-slab ring needs to
+// put two workgroups on a CU; without the bound hipcc gives every unit an accumulator of its own and lands at 290 registers.
+template <int NU, int RING, bool F16, int AUX = 0, bool IL = false>
+__global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *__restrict__ Qt,      // [T, 128] flat query tokens
                                                             const uint16_t *__restrict__ D,       // [rows, 128] bf16
                                                             const int32_t *__restrict__ d_off,    // [n_d + 1]
                                                             const uint8_t *__restrict__ clamp0,   // [n_d] or null
@@ -65,23 +68,27 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *ring = smem + wave * (RING * kSlabBytes);
+    char *tokmax = smem + 4 * (RING * kSlabBytes) + wave * kStreamTokBytes;
     const int gw = blockIdx.x * 4 + wave;  // global wave id: this wave owns documents gw, gw+GW, ...
     const int GW = gridDim.x * 4;
 
-    // ---- query fragments: B operands, resident for the whole kernel (32 VGPRs per 32-token tile)
-    QueryTile qt[QT];
+    // ---- query fragments: B operands, resident for the whole kernel (16 VGPRs per 16-token unit)
+    const int n_tok = flat_qoff(a.fq, a.n_q);
+    QueryUnit qu[NU];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) load_query_tile(qt[t], Q + (size_t)(t / TPQ) * a.Lq * kDim, (t % TPQ) * kTokTile, a.Lq, lane, true);
+    for (int u = 0; u < NU; ++u) load_query_unit(qu[u], Qt, u * kUnitTok, n_tok, lane, true);
+    // this lane's query (8 lanes per query) and its token range in the table
+    const int rq = lane >> 3, ri = lane & 7;
+    const bool r_live = rq < a.n_q;
+    const int r_s = r_live ? flat_qoff(a.fq, rq) : 0, r_e = r_live ? flat_qoff(a.fq, rq + 1) : 0;
 
     // the query loads are ordinary VMEM loads: retire them before the LDS-DMA stream starts so that the
     // compiler's own vmcnt waits for them never drain the ring later on
     wait_vmcnt<0>();
 #pragma unroll
-    for (int t = 0; t < QT; ++t)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qt[t].f[h][ks]));
+        for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qu[u].f[ks]));
 
     // ---- per-lane address constants
     // LDS-DMA source: wave-instruction i of a slab fills LDS rows 4i..4i+3 linearly; lane (l4 = lane>>4,
@@ -165,16 +172,14 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
     int c_slot = 0;
     for (int c_idx = gw; c_idx < a.n_d; c_idx += GW) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
-        float m[QT][2];
+        float m[NU];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) m[t][0] = m[t][1] = -INFINITY;
+        for (int u = 0; u < NU; ++u) m[u] = -INFINITY;
 
-        // one slab: request the next one (IL: its 8 pieces go out between the MFMAs), fetch the 8 operand fragments once, then per
-        // token tile 8 MFMAs with the 16 -> 1 max fold of the PREVIOUS tile underneath them.  The fold is written one tile late on
-        // purpose: a VALU read of an accumulator needs 12 wait states after the MFMA that writes it (the compiler inserts them), and
-        // straight-line code lets it spend them on the next tile's MFMAs instead of on s_nop.  kTail (rows past the document end
-        // masked to -inf) is a compile-time variant so that the full-slab body has no branch in it.
-        auto slab = [&](auto tail_c, int s, int rows_left) {
+        // one slab: request the next one (IL: its 8 pieces go out between the MFMAs), fetch the 8 operand fragments once, then the
+        // MFMAs of all units (maxsim_common.hpp: slab_units, folds one group late).  kTail (rows past the document end masked to
+        // -inf) is a compile-time variant so that the full-slab body has no branch in it.
+        auto slab = [&](auto tail_c, int rows_left) {
             constexpr bool kTail = decltype(tail_c)::value;
             // next slab to request (its slot is the one consumed in the previous iteration: free again)
             bool nx_live = false;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
                 nx_soff = nx_live ? p_row * kRowBytes : 0;
                 nx_rsrc = nx_live ? p_rsrc : null_rsrc;
             } else {
-                // the slot consumed in the previous iteration is free again: refill it, then wait for slab s
+                // the slot consumed in the previous iteration is free again: refill it, then wait for this slab
                 const bool issued = produce();
                 if (issued)
                     wait_vmcnt<8 * (RING - 1)>();
@@ -204,43 +209,23 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
                 for (int ks = 0; ks < kKSteps16; ++ks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[g][ks]);
             c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
 
-            TileAcc prev;
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                TileAcc acc;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) acc.a[h][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < kKSteps16; ++ks)
-#pragma unroll
-                    for (int hg = 0; hg < 4; ++hg) {           // four independent accumulator chains per tile, round-robin
-                        if constexpr (IL) {
-                            constexpr int kPer = 2 * QT;        // one DMA piece per 2 * QT MFMAs: 8 per slab
-                            const int mf = (t * kKSteps16 + ks) * 4 + hg;
-                            if (mf % kPer == 0) {
-                                const int i = mf / kPer;
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(nx_rsrc, MSIM_LDS(nx_dst + i * 1024), 16, src_off[i & 3],
-                                                                         nx_soff + i * 1024, 0, AUX);
-                            }
-                        }
-                        acc.a[hg >> 1][hg & 1] = mfma16<F16>(af[hg & 1][ks], qt[t].f[hg >> 1][ks], acc.a[hg >> 1][hg & 1]);
+            slab_units<F16, NU, kTail, true>(m, af, qu, rows_left, lane, [&](int mf) {
+                if constexpr (IL) {                 // one DMA piece per NU MFMAs: 8 per slab (a slab is 8 * NU MFMAs)
+                    if (mf % NU == 0) {
+                        const int i = mf / NU;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(nx_rsrc, MSIM_LDS(nx_dst + i * 1024), 16, src_off[i & 3],
+                                                                 nx_soff + i * 1024, 0, AUX);
                     }
-                if constexpr (kTail) tile_mask_tail(acc, rows_left, lane);
-                if (t > 0) tile_fold(m[t - 1], prev);
-                prev = acc;
-                if constexpr (TILEMAJOR) __builtin_amdgcn_sched_barrier(0);
-            }
-            tile_fold(m[QT - 1], prev);
+                }
+            });
             if constexpr (IL) advance(nx_live);                                  // the 8 pieces are out: advance the cursor
-            (void)s;
         };
         const int n_full = len / kSlabRows, rem = len - n_full * kSlabRows;
-        for (int s = 0; s < n_full; ++s) slab(std::false_type{}, s, kSlabRows);
-        if (rem > 0) slab(std::true_type{}, n_full, rem);
+        for (int s = 0; s < n_full; ++s) slab(std::false_type{}, kSlabRows);
+        if (rem > 0) slab(std::true_type{}, rem);
 
-        // ---- document epilogue: combine the two lane halves, clamp, sum over tokens, store
+        // ---- document epilogue: the per-token maxima go to the wave's table in LDS (no barrier: the table is wave-private and a
+        // wave's LDS operations complete in order), then 8 lanes per query add their query's tokens and one of them stores.
         // clamp0 is a byte array; fetch the aligned dword around the byte with an explicit scalar load
         // (a vector byte load would make the compiler wait vmcnt(0), i.e. drain the whole LDS-DMA ring)
         bool clamp = false;
@@ -248,18 +233,12 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
             const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
             clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
         }
-        float tile_sum[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) tile_sum[t] = tile_finish<F16>(m[t], clamp, ref_bf16);
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < QT / TPQ; ++q) {
-                float tot = 0.0f;
-#pragma unroll
-                for (int tt = 0; tt < TPQ; ++tt) tot += tile_sum[q * TPQ + tt];
-                if (ref_bf16) tot = round_to_input<F16>(tot);
-                scores[(size_t)q * a.ld + c_idx] = tot;
-            }
+        for (int u = 0; u < NU; ++u) store_token_max(tokmax, u, m[u], lane);
+        if (r_live) {
+            float tot = reduce_query_tokens<F16>(tokmax, r_s, r_e, ri, clamp, ref_bf16);
+            if (ref_bf16 && !(a.flags & kFlagPartial)) tot = round_to_input<F16>(tot);
+            if (ri == 0) scores[(size_t)rq * a.ld + c_idx] = tot;
         }
     }
 }

@@ -15,7 +15,7 @@ from typing import List, Optional, Union
 import torch
 
 from . import _lib
-from .corpus import PackedCorpus, _check_embeddings, _widen, pack_passages, pack_queries
+from .corpus import PackedCorpus, PackedQueries, _check_embeddings, _widen, pack_passages, pack_queries
 
 logger = logging.getLogger(__name__)
 
@@ -63,10 +63,12 @@ def _ref_rounding_from_env() -> bool:
     return os.environ.get("COLPALI_AMD_REF_ROUNDING", "0") not in ("", "0")
 
 
-def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: bool = False,
+def maxsim_scores(queries: Union[torch.Tensor, PackedQueries], corpus: PackedCorpus, *, ref_rounding: bool = False,
                   out: Optional[torch.Tensor] = None, ref_bf16: Optional[bool] = None) -> torch.Tensor:
-    """Device-level entry: [n_q, Lq, width] device tensor x packed corpus -> fp32 [n_q, n] on the device.
+    """Device-level entry: queries x packed corpus -> fp32 [n_q, n] on the device.
 
+    `queries`: a `PackedQueries` (the flat layout `pack_queries` returns on the GPU: ragged lengths, zero rows dropped ->
+    msim_fwd_ragged) or a contiguous [n_q, Lq, width] device tensor (every row is scored as it stands -> msim_fwd).
     Asynchronous on torch's current stream.  `ref_rounding=True` reproduces the rounding the reference
     applies when torch evaluates processing_utils.py:179 in the embeddings' own 16-bit dtype
     (`ref_bf16` is the older name of the same switch).
@@ -74,14 +76,16 @@ def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: 
     if ref_bf16 is not None:
         ref_rounding = ref_bf16
     L = _lib.lib()
-    if queries.dim() != 3 or not queries.is_contiguous():
-        raise ValueError("queries must be a contiguous [n_q, Lq, width] tensor")
+    flat = isinstance(queries, PackedQueries)
+    if not flat and (queries.dim() != 3 or not queries.is_contiguous()):
+        raise ValueError("queries must be a PackedQueries or a contiguous [n_q, Lq, width] tensor")
     if queries.dtype != corpus.blob.dtype:   # torch.einsum raises on mixed dtypes too
         raise RuntimeError(f"expected queries and passages of one dtype, got {queries.dtype} and {corpus.blob.dtype}")
     dt = _lib.dtype_code(queries.dtype)
     if queries.device != corpus.device:
         raise ValueError("queries and corpus live on different devices")
-    n_q, Lq, dim = queries.shape
+    n_q = len(queries)
+    dim = queries.tokens.shape[1] if flat else queries.shape[2]
     if dim != corpus.blob.shape[1]:
         raise RuntimeError(f"queries have embedding width {dim}, the corpus {corpus.blob.shape[1]}")
     n = len(corpus)
@@ -89,17 +93,28 @@ def maxsim_scores(queries: torch.Tensor, corpus: PackedCorpus, *, ref_rounding: 
         out = torch.empty((n_q, n), dtype=torch.float32, device=queries.device)
     elif out.shape != (n_q, n) or out.dtype != torch.float32 or out.stride(1) != 1:
         raise ValueError("out must be fp32 [n_q, n] with unit inner stride")
-    # long queries are scored in 128-token segments whose partial sums live in the workspace (n_q x segments x n x 4 bytes): keep
+    flags = _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0
+    ld = out.stride(0) if n_q > 1 else max(n, 1)
+    if flat:
+        with torch.cuda.device(queries.device):
+            oh = queries.offsets_host
+            ws = _fwd_workspace(L.msim_fwd_ragged_workspace_bytes(dt, oh.data_ptr(), n_q, n, dim), queries.device)
+            rc = L.msim_fwd_ragged(dt, _lib.ptr(queries.tokens), _lib.ptr(queries.offsets), oh.data_ptr(), n_q, _lib.ptr(corpus.blob),
+                                   _lib.ptr(corpus.offsets), _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out), ld, flags, _lib.ptr(ws),
+                                   _lib.current_stream_handle(queries.device))
+            _lib.check(rc, "msim_fwd_ragged")
+        return out
+    Lq = queries.shape[1]
+    # long queries are scored in 128-token pieces whose partial sums live in the workspace (n_q x pieces x n x 4 bytes): keep
     # that scratch bounded by scoring the queries in groups (rows of `out` are independent)
     ws_bytes = L.msim_fwd_workspace_bytes(dt, n_q, Lq, n, dim)
     group = n_q if ws_bytes <= _MAX_FWD_SCRATCH else max(1, int(n_q * _MAX_FWD_SCRATCH // ws_bytes))
-    flags = _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0
     with torch.cuda.device(queries.device):
         for q0 in range(0, n_q, group):
             nq = min(group, n_q - q0)
             ws = _fwd_workspace(L.msim_fwd_workspace_bytes(dt, nq, Lq, n, dim), queries.device)
             rc = L.msim_fwd(dt, _lib.ptr(queries[q0:q0 + nq]), nq, Lq, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets),
-                            _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out[q0:q0 + nq]), out.stride(0) if n_q > 1 else max(n, 1),
+                            _lib.ptr(corpus.clamp0), n, dim, _lib.ptr(out[q0:q0 + nq]), ld,
                             flags, _lib.ptr(ws), _lib.current_stream_handle(queries.device))
             _lib.check(rc, "msim_fwd")
     return out

@@ -28,6 +28,14 @@
  *                                    (colpali_engine/utils/processing_utils.py:175-178,
  *                                     pad_sequence(..., padding_value=0))
  *   Q        bf16|f16|f32 [n_q, Lq, dim]     queries (same dtype as D), zero rows = padding (they add 0)
+ *
+ * Flat query layout (msim_fwd_ragged; bf16 / f16, dim 128) -- queries are ragged in real use
+ * (colpali_engine/utils/processing_utils.py:86 appends 10 augmentation tokens to a question of any length; a batch is
+ * padded to its longest member, colpali_engine/collators/visual_retriever_collator.py:82-85) and a zero row adds exactly
+ * 0 to every score, so the kernels take the real tokens only:
+ *   Qt       bf16|f16 [T, 128]       every query's tokens back to back
+ *   q_off    int32 [n_q + 1]         query q owns tokens q_off[q] .. q_off[q+1]-1 (on the device AND on the host: the
+ *                                    launch plan -- which whole queries share a workgroup -- is made on the host)
  */
 #ifndef COLPALI_AMD_MAXSIM_H
 #define COLPALI_AMD_MAXSIM_H
@@ -39,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 16
+#define MSIM_ABI_VERSION 17
 
 /* error codes */
 #define MSIM_OK 0
@@ -93,6 +101,40 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq,
                   int n_d, int dim,
                   float *scores, int64_t ld_scores,
                   uint32_t flags, void *workspace, void *stream);
+
+/*
+ * The same scores for RAGGED queries in the flat layout: scores[q, c] = sum over the tokens i of query q of
+ * max_{j in doc c} <Qt[q_off[q] + i, :], D[j, :]>.  A query's score is a pure function of its own tokens and the
+ * document (the token sum runs in an order fixed by the query's length alone), so it does not depend on the batch it is
+ * scored in, on the kernel shape the plan picks, or on whether msim_fwd or msim_fwd_ragged computed it (for queries of up
+ * to 128 tokens).  bf16 / f16 embeddings of width 128 only (MSIM_EUNSUPPORTED otherwise: pad the queries to one length and
+ * call msim_fwd); a query may hold 0 .. 1280 tokens.  `q_off` is the device copy, `q_off_host` the host copy of the same
+ * n_q + 1 numbers (read during the call only).  Workspace as msim_fwd's: msim_fwd_ragged_workspace_bytes() bytes or NULL.
+ * Replaces the same reference lines as msim_fwd (processing_utils.py:172-179 with its pad_sequence of the query block).
+ */
+size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim);
+int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32_t *q_off_host, int n_q,
+                    const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                    int n_d, int dim,
+                    float *scores, int64_t ld_scores,
+                    uint32_t flags, void *workspace, void *stream);
+
+/*
+ * Packing queries into the flat layout: rows that are entirely zero (the model's padded positions,
+ * modeling_colpali.py:72 / modeling_colqwen2.py:69; byte-wise test) are dropped, the others keep their order.
+ *   msim_query_compact        device: box [n_q, Lq, row_bytes] (row_bytes a multiple of 16, Lq <= 4096).  counts != NULL:
+ *                             counts[q] = rows of query q that are not all-zero.  out != NULL: those rows are copied to rows
+ *                             q_off[q] .. of `out`.  (Call once for the counts, build q_off, call again to copy.)
+ *   msim_host_count_nonzero_rows / msim_host_gather_nonzero_rows
+ *                             host (native threads; synchronous): the same for a list of host buffers src[i] of rows[i] rows --
+ *                             counts, then the copy of source i's non-zero rows to row dst_row[i] .. of `dst` (pinned staging).
+ */
+int msim_query_compact(const void *box, int n_q, int Lq, int row_bytes, const int32_t *q_off, int32_t *counts, void *out,
+                       void *stream);
+int msim_host_count_nonzero_rows(const void *const *src, const int64_t *rows, int64_t row_bytes, int64_t n, int32_t *counts,
+                                 int n_threads);
+int msim_host_gather_nonzero_rows(void *dst, const void *const *src, const int64_t *rows, int64_t row_bytes,
+                                  const int64_t *dst_row, int64_t n, int n_threads);
 
 /*
  * MaxSim for an explicit list of (query, document) pairs, optionally reporting for every

@@ -284,16 +284,24 @@ def test_generic_many_documents_and_literal_rounding(amd):
 
 
 def test_generic_and_tuned_kernels_agree(amd):
-    # a 128-wide bf16 query scored by the tuned kernels (Lq <= 128: 16x16x32 MFMA tiles, 32 k per step) and, zero-padded to 160
-    # tokens, by the generic kernel (32x32x16 tiles, 16 k per step): the same exact products summed in a different order inside
-    # the matrix unit -- equal to fp32 summation-order noise, not bit for bit
+    # a 128-wide bf16 query scored by the tuned kernels (16x16x32 MFMA tiles, 32 k per step) and, as a zero-padded box of 160
+    # tokens handed to msim_fwd WITHOUT scratch, by the generic kernel K1g (32x32x16 tiles, 16 k per step): the same exact products
+    # summed in a different order inside the matrix unit -- equal to fp32 summation-order noise, not bit for bit
+    from colpali_amd import _lib
+
     qs, ps = _random_case(21, 3, 32, 200, 500)
     dev = torch.device("cuda:0")
     corpus = amd.pack_passages(ps, dev)
     tuned = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()
-    long_q = [torch.cat([q, q.new_zeros(160 - q.shape[0], 128)]) for q in qs]
-    generic = amd.maxsim_scores(amd.pack_queries(long_q, dev), corpus).cpu()
+    box = amd.pack_queries([torch.cat([q, q.new_zeros(160 - q.shape[0], 128)]) for q in qs], dev, layout="box")
+    assert box.shape == (3, 160, 128)
+    generic = torch.empty((3, len(ps)), dtype=torch.float32, device=dev)
+    rc = _lib.lib().msim_fwd(0, _lib.ptr(box), 3, 160, _lib.ptr(corpus.blob), _lib.ptr(corpus.offsets), _lib.ptr(corpus.clamp0),
+                             len(ps), 128, _lib.ptr(generic), len(ps), 0, None, _lib.current_stream_handle(dev))   # NULL scratch: K1g
+    _lib.check(rc, "msim_fwd")
+    generic = generic.cpu()
     assert float(((tuned - generic).abs() / generic.abs().clamp_min(1.0)).max()) < 2e-6
+    assert not torch.equal(tuned, generic)          # a different kernel really ran
 
 
 def test_transpose_detecting_asymmetric_inputs_fp32(amd):
@@ -386,7 +394,7 @@ def test_long_queries_score_as_segments_on_the_tuned_kernels(amd, n_q, lq, n_d, 
     got = amd.score_multi_vector(qs, ps, batch_size=7, device="cuda:0").numpy()                    # blocks of 7: clamp0 flags everywhere
     assert close(got, want)
     dev = torch.device("cuda:0")
-    q, corpus = amd.pack_queries(qs, dev), amd.pack_passages(ps, dev, batch_size=7)
+    q, corpus = amd.pack_queries(qs, dev, layout="box"), amd.pack_passages(ps, dev, batch_size=7)   # the box entry: pieces on K1b
     L = _lib.lib()
     assert L.msim_fwd_workspace_bytes(_lib.dtype_code(dtype), n_q, q.shape[1], n_d, 128) == 4096 + n_q * ((q.shape[1] + 127) // 128) * n_d * 4
     generic = torch.empty((n_q, n_d), dtype=torch.float32, device=dev)
@@ -407,7 +415,7 @@ def test_long_query_scratch_is_bounded_by_scoring_the_queries_in_groups(amd, mon
 
     qs, ps = _random_case(77, 9, 300, 120, 200)
     dev = torch.device("cuda:0")
-    q, corpus = amd.pack_queries(qs, dev), amd.pack_passages(ps, dev)
+    q, corpus = amd.pack_queries(qs, dev, layout="box"), amd.pack_passages(ps, dev)
     whole = amd.maxsim_scores(q, corpus).cpu()
     monkeypatch.setattr(scoring, "_MAX_FWD_SCRATCH", 4096 + 2 * 3 * 120 * 4)          # room for two queries' partial sums at a time
     grouped = amd.maxsim_scores(q, corpus).cpu()

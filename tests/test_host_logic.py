@@ -311,14 +311,28 @@ def test_fwd_workspace_bytes_reports_scratch_exactly_when_several_query_blocks_s
     def ws(n_q, lq, dtype=0, dim=128):
         return L.msim_fwd_workspace_bytes(dtype, n_q, lq, 1000, dim)
 
+    # the plan (maxsim_abi.hip: flat_plan) works in 16-token units of the flat token matrix: one query block holds up to
+    # 256 / 320 / 512 / 640 / 1024 / 1280 tokens (pair, pair x 10 units, 4 waves, 4 x 10, 8 waves, 8 x 10) and 16 / 32 / 64 queries
     assert ws(1, 32) == 0 and ws(4, 32) == 0                       # K1s
     assert ws(8, 32) == 0 and ws(16, 32) == 0 and ws(32, 32) == 0  # one query block (pair / 4-wave / 8-wave form)
-    assert ws(17, 32) == 0 and ws(20, 32) == 0 and ws(33, 32) == 0 and ws(40, 32) == 0   # ONE block: five tiles per wave (round 3)
+    assert ws(17, 32) == 0 and ws(20, 32) == 0 and ws(33, 32) == 0 and ws(40, 32) == 0   # ONE block: ten units per wave (round 3's five tiles)
     assert ws(41, 32) == 4096 and ws(64, 32) == 4096 and ws(80, 32) == 4096 and ws(1000, 32) == 4096   # several blocks
-    # three-tile queries: a wave holds ONE (4 / 3), so 5 queries (15 tiles, 4 waves) and 9..10 (8 waves) are two query blocks
-    assert ws(5, 96) == 4096 and ws(9, 96) == 4096 and ws(10, 96) == 4096
-    assert ws(4, 96) == 0 and ws(6, 96) == 0 and ws(8, 96) == 0    # 12 tiles on 4 waves, 18 / 24 tiles on 8 waves: one block
-    assert ws(17, 64) == 4096 and ws(16, 64) == 0 and ws(8, 64) == 0   # two-tile queries: 16 per 8-wave block
+    # 96-token queries are 6 units each, wherever they sit: 5 / 9 / 10 / 13 of them still fit one block (round 3: a wave held whole
+    # queries of 32-token tiles, and 5 of them were already two blocks)
+    assert ws(5, 96) == 0 and ws(9, 96) == 0 and ws(10, 96) == 0 and ws(13, 96) == 0 and ws(14, 96) == 4096
+    assert ws(17, 64) == 0 and ws(20, 64) == 0 and ws(21, 64) == 4096
+    assert ws(20, 40) == 0 and ws(32, 40) == 0 and ws(33, 40) == 4096      # real query lengths: 32 x 40 tokens = 1280 = one 8 x 10 block
+    assert ws(65, 8) == 4096 and ws(64, 8) == 0                            # the 64-queries-per-block limit (8 lanes per query in the reduction)
+    # ragged queries: the same plan from the host copy of the token offsets
+    import numpy as np
+
+    def wsr(lens, dtype=0, dim=128):
+        off = np.zeros(len(lens) + 1, dtype=np.int32)
+        np.cumsum(np.asarray(lens, dtype=np.int32), out=off[1:])
+        return L.msim_fwd_ragged_workspace_bytes(dtype, off.ctypes.data, len(lens), 1000, dim)
+
+    assert wsr([12, 40, 33]) == 0 and wsr([40] * 32) == 0 and wsr([40] * 32 + [1]) == 4096 and wsr([0] * 64 + [5]) == 4096
+    assert wsr([32] * 100, dtype=2) == 0 and wsr([32] * 100, dim=320) == 0      # not the flat path's shapes
     assert ws(100, 32, dtype=2) == 0 and ws(100, 32, dim=320) == 0 and ws(100, 200, dtype=2) == 0   # generic / panel kernels: none
     # queries longer than 128 tokens (16-bit, width 128): 128-token segments on K1b -- counters + n_q x segments x n_d partial sums
     assert ws(100, 200) == 4096 + 100 * 2 * 1000 * 4 and ws(1, 780) == 4096 + 7 * 1000 * 4 and ws(3, 129, dtype=1) == 4096 + 3 * 2 * 1000 * 4
