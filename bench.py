@@ -496,8 +496,12 @@ def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg, q_tokens=None):
 
 def stream_ceiling(amd, corpus):
     """The machine's own ceiling for K1s' document stream: the same LDS-DMA loads of the same resident shard with no MFMA, no
-    max/sum and no output (msim_probe_stream, include/maxsim.h).  GB/s of the shard bytes; HIP events on the launch stream."""
-    L = amd._lib.lib()
+    max/sum and no output (msim_probe_stream, include/maxsim_probe.h: tools/probe/libmaxsim_probe.so, not the product library).  GB/s of the shard bytes; HIP events on the launch stream."""
+    from tools import probe
+
+    L = probe.lib()
+    if L is None:
+        return None
     rows = int(corpus.blob.shape[0]) // 256 * 256
     sink = torch.zeros(4, dtype=torch.float32, device=corpus.blob.device)
     st = torch.cuda.current_stream()
@@ -509,7 +513,7 @@ def stream_ceiling(amd, corpus):
         b.record(st)
         torch.cuda.synchronize()
         if rc != 0:
-            raise RuntimeError(f"msim_probe_stream failed: {L.msim_last_error().decode()}")
+            raise RuntimeError(f"msim_probe_stream failed: {L.msim_probe_last_error().decode()}")
         if i >= 2:
             ms.append(a.elapsed_time(b))
     t = sorted(ms)[len(ms) // 2]
@@ -561,14 +565,16 @@ def topk_parity(amd, q, corpus, scores, top_s, top_i, k, n_queries=2, n_random=1
 
 
 def mfma_ceiling(amd, corpus):
-    """The machine's own matrix-core ceiling under its power budget (msim_probe_mfma, include/maxsim.h): back-to-back
+    """The machine's own matrix-core ceiling under its power budget (msim_probe_mfma, include/maxsim_probe.h: tools/probe/libmaxsim_probe.so, not the product library): back-to-back
     v_mfma_f32_16x16x32_bf16 on rows of the resident shard (the operand values the scorer multiplies), two waves per SIMD, no HBM
     traffic.  `kernel_mix` = with K1b's operand path (A fragments re-read from LDS) and its max folds; `registers_only` = nothing
     but MFMAs.  MI355X clocks to its power budget: on real operand values the chip does not reach the 2.5 PFLOP/s of
     1024 SIMDs x 1024 FLOP/clk x 2.4 GHz (on zeros it nearly does), so this is what an MFMA-bound kernel can be held against."""
-    L = amd._lib.lib()
+    from tools import probe
+
+    L = probe.lib()
     rows = int(corpus.blob.shape[0])
-    if rows < 256 * 8 * 5 * 32:
+    if L is None or rows < 256 * 8 * 5 * 32:
         return None
     sink = torch.zeros(4, dtype=torch.float32, device=corpus.blob.device)
     st = torch.cuda.current_stream()
@@ -584,7 +590,7 @@ def mfma_ceiling(amd, corpus):
             b.record(st)
             torch.cuda.synchronize()
             if rc != 0:
-                raise RuntimeError(f"msim_probe_mfma failed: {L.msim_last_error().decode()}")
+                raise RuntimeError(f"msim_probe_mfma failed: {L.msim_probe_last_error().decode()}")
             if i >= 2:
                 ms.append(a.elapsed_time(b))
         out[name + "_tflops"] = flop / sorted(ms)[len(ms) // 2] / 1e9
@@ -706,8 +712,8 @@ def main():
         out["launched_by"] = "bench.py (self-spawned torch.distributed.run)" if os.environ.get("BENCH_SELF_LAUNCHED") else "external launcher"
         if out["rccl_ranks"] != args.gpus:
             raise SystemExit(f"process group spans {out['rccl_ranks']} ranks, --gpus {args.gpus} requested")
-    if corpus.blob.shape[1] == 128:
-        ceil_ = stream_ceiling(amd, corpus)
+    ceil_ = stream_ceiling(amd, corpus) if corpus.blob.shape[1] == 128 else None
+    if ceil_:
         out["roofline"]["stream_ceiling_gbs"] = ceil_["gbs"]
         out["roofline"]["stream_ceiling_what"] = ceil_["what"]
         if out["roofline"]["bound"] == "hbm":
@@ -716,7 +722,7 @@ def main():
     if ceil_m:
         out["mfma_ceiling"] = ceil_m
         if out["roofline"]["bound"] == "mfma":
-            out["roofline"]["frac_of_mfma_ceiling"] = out["roofline"]["achieved"] / ceil_m["kernel_mix_tflops"]
+            out["roofline"]["ratio_to_registers_only_probe"] = out["roofline"]["achieved"] / ceil_m["registers_only_tflops"]
     if not args.no_parity:
         # every rank checks its own shard (the CPU oracle as the checker); the verdicts are combined below
         local_top = amd.topk(scores, args.topk, corpus.id_base)
@@ -781,7 +787,7 @@ def main():
                         "ms_per_step": d / steps * 1e3, "kernel_ms": r["kernel_ms"], "bound": r["bound"],
                         "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"]})
         if ceil_m and r["bound"] == "mfma":
-            regimes[-1]["frac_of_mfma_ceiling"] = r["mfma_tflops"] / ceil_m["kernel_mix_tflops"]
+            regimes[-1]["ratio_to_registers_only_probe"] = r["mfma_tflops"] / ceil_m["registers_only_tflops"]
         if world == 1 and os.environ.get("BENCH_POWER_SAMPLE", "1") != "0":
             ps = power_sample(amd, qq, corpus)
             if ps:

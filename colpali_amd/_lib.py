@@ -81,6 +81,11 @@ def lib() -> ctypes.CDLL:
     L.msim_fwd_workspace_bytes.restype = sz
     L.msim_fwd.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
     L.msim_fwd.restype = i32
+    L.msim_fwd_host.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, u32, i32]
+    L.msim_fwd_host.restype = i32
+    L.msim_host_last_error.restype = ctypes.c_char_p
+    L.msim_sim_matrix_host.argtypes = [i32, vp, i32, vp, i32, i32, vp, i64, u32, i32]
+    L.msim_sim_matrix_host.restype = i32
     L.msim_fwd_ragged_workspace_bytes.argtypes = [i32, vp, i32, i32, i32]
     L.msim_fwd_ragged_workspace_bytes.restype = sz
     L.msim_fwd_ragged.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]
@@ -120,16 +125,12 @@ def lib() -> ctypes.CDLL:
     L.msim_pool_cluster.restype = i32
     L.msim_pool_reduce.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.msim_pool_reduce.restype = i32
-    L.msim_probe_stream.argtypes = [i32, vp, i64, i32, vp, vp]
-    L.msim_probe_stream.restype = i32
     L.msim_loss_epilogue_workspace_bytes.argtypes = [i32]
     L.msim_loss_epilogue_workspace_bytes.restype = sz
     L.msim_loss_epilogue.argtypes = [i32, vp, i64, i32, i32, vp, i32, i32, i32, i32, f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]
     L.msim_loss_epilogue.restype = i32
     L.msim_host_gather.argtypes = [vp, vp, vp, vp, i64, i32]
     L.msim_host_gather.restype = i32
-    L.msim_probe_mfma.argtypes = [i32, vp, i64, i32, vp, vp]
-    L.msim_probe_mfma.restype = i32
     L.msim_topk_workspace_bytes.argtypes = [i32, i64, i32]
     L.msim_topk_workspace_bytes.restype = sz
     L.msim_topk_f32.argtypes = [vp, vp, i32, i64, i64, i32, i64, vp, vp, vp, vp]

@@ -37,11 +37,54 @@ def _require_gpu(device: Union[str, torch.device]) -> torch.device:
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError(
-            f"colpali_amd.score_multi_vector runs on an AMD Instinct MI355X only (requested device: {dev}). "
-            "There is deliberately no CPU fallback; use the reference scorer for CPU scoring.")
+            f"colpali_amd: this entry point runs on an AMD Instinct MI355X only (requested device: {dev}); "
+            "of the scorers, score_multi_vector alone has a host path (device='cpu').")
     if not torch.cuda.is_available():
         raise RuntimeError("colpali_amd: no ROCm GPU is visible to torch")
     return dev
+
+
+def _host_threads() -> int:
+    return max(1, min(int(os.environ.get("COLPALI_AMD_HOST_THREADS", "0")) or torch.get_num_threads(), 256))
+
+
+def _score_on_host(qs, ps, batch_size: int, ref_rounding: bool) -> torch.Tensor:
+    """`device="cpu"`: the library's own host-core scorer (msim_fwd_host, colpali_amd/csrc/maxsim_host.cpp) on host copies of the
+    same packed layout -- the reference computes on the device it is given (processing_utils.py:161, :172-179), so a CPU request
+    is served on the CPU.  No torch arithmetic, no oracle; a GPU request never comes here."""
+    import numpy as np
+
+    L = _lib.lib()
+    cpu = torch.device("cpu")
+    q = pack_queries([t.to(cpu) for t in qs] if not isinstance(qs, torch.Tensor) else qs.to(cpu), cpu, layout="box")
+    if isinstance(ps, torch.Tensor):
+        if ps.dim() != 3:
+            raise ValueError("a passage tensor must be 3-D (n_passages, max_len, dim)")
+        _check_embeddings(ps, "passages")
+        n, Lp, dim = ps.shape
+        blob = _widen(ps.to(cpu).reshape(n * Lp, dim)).contiguous()
+        lengths = np.full(n, Lp, dtype=np.int64)
+        clamp0 = None
+    else:
+        corpus = pack_passages([t.to(cpu) for t in ps], cpu, batch_size=batch_size)      # host blob, same clamp0 rule
+        blob, clamp0 = corpus.blob, corpus.clamp0
+        lengths = corpus.lengths.numpy()
+    if q.dtype != blob.dtype:
+        raise RuntimeError(f"expected queries and passages of one dtype, got {q.dtype} and {blob.dtype}")
+    if q.shape[2] != blob.shape[1]:
+        raise RuntimeError(f"queries have embedding width {q.shape[2]}, the corpus {blob.shape[1]}")
+    off = np.zeros(len(lengths) + 1, dtype=np.int32)
+    np.cumsum(lengths, out=off[1:])
+    n_q, Lq, dim = q.shape
+    out = torch.empty((n_q, len(lengths)), dtype=torch.float32)
+    rc = L.msim_fwd_host(_lib.dtype_code(q.dtype), q.data_ptr(), n_q, Lq, blob.data_ptr(), off.ctypes.data,
+                         clamp0.data_ptr() if clamp0 is not None else None, len(lengths), dim, out.data_ptr(),
+                         out.stride(0) if n_q > 1 else max(len(lengths), 1), _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0,
+                         _host_threads())
+    if rc != 0:
+        msg = L.msim_host_last_error().decode("utf-8", "replace")
+        raise (NotImplementedError if rc == -2 else ValueError if rc == -1 else RuntimeError)(f"msim_fwd_host: {msg}")
+    return out
 
 
 def _fwd_workspace(nbytes: int, device: torch.device) -> Optional[torch.Tensor]:
@@ -139,8 +182,12 @@ def score_multi_vector(
         raise ValueError("No queries provided")
     if len(ps) == 0:
         raise ValueError("No passages provided")
-    dev = _require_gpu(device)
     ref_rounding = _ref_rounding_from_env()
+    if torch.device(device).type == "cpu":
+        scores = _score_on_host(qs, ps, batch_size, ref_rounding)
+        assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+        return scores
+    dev = _require_gpu(device)
     q = pack_queries(qs, dev)
     cols = []
     for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
@@ -223,6 +270,22 @@ def score_single_vector(
         if len(ps) == 0:
             raise ValueError("No passages provided")
         qs, ps = torch.stack(qs), torch.stack(ps)
+    if torch.device(device).type == "cpu":      # the library's host-core path (msim_sim_matrix_host): a CPU request is served on the CPU
+        a, b = qs.to("cpu"), ps.to("cpu")
+        if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+            raise ValueError("expected [n_a, dim] and [n_b, dim]")
+        if a.dtype != b.dtype:
+            raise RuntimeError(f"expected both operands of one dtype, got {a.dtype} and {b.dtype}")
+        _check_embeddings(a, "similarity operand")
+        a, b = a.contiguous(), b.contiguous()
+        L = _lib.lib()
+        scores = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32)
+        rc = L.msim_sim_matrix_host(_lib.dtype_code(a.dtype), a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], a.shape[1],
+                                    scores.data_ptr(), max(b.shape[0], 1), 0, _host_threads())
+        if rc != 0:
+            raise RuntimeError(f"msim_sim_matrix_host: {L.msim_host_last_error().decode('utf-8', 'replace')}")
+        assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+        return scores
     dev = _require_gpu(device)
     scores = similarity_matrix(qs.to(dev), ps.to(dev))
     assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"

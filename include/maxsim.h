@@ -103,6 +103,26 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq,
                   uint32_t flags, void *workspace, void *stream);
 
 /*
+ * The same scores on the HOST cores: every pointer is host memory, the call is synchronous and runs on `n_threads` native
+ * threads (AVX-512 / AVX2 / baseline clones picked at load time).  This is what colpali_amd.score_multi_vector runs when the
+ * caller names device="cpu" -- or passes no device on a host without a GPU -- through the reference's signature
+ *   colpali_engine/utils/processing_utils.py:132-187 (the reference scores on whatever device it is given: :161, :172-179;
+ *   colpali_engine/utils/torch_utils.py:12-31 answers "cpu" when no accelerator is visible);
+ * it is never used on behalf of a GPU request.  fp32 products and sums of the exactly widened inputs (the kernels' truth tier:
+ * within 1e-5 of a float64 evaluation); MSIM_FLAG_REF_ROUNDING as in msim_fwd.  Any dim >= 1, any Lq >= 0; bf16 / f16 / f32.
+ * msim_host_last_error() gives its thread-local message.
+ */
+const char *msim_host_last_error(void);
+int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq,
+                  const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                  int n_d, int dim,
+                  float *scores, int64_t ld_scores,
+                  uint32_t flags, int n_threads);
+/* out[i, j] = <A_i, B_j> on the host cores (score_single_vector with device="cpu": processing_utils.py:103-130) */
+int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n_b, int dim,
+                         float *out, int64_t ld_out, uint32_t flags, int n_threads);
+
+/*
  * The same scores for RAGGED queries in the flat layout: scores[q, c] = sum over the tokens i of query q of
  * max_{j in doc c} <Qt[q_off[q] + i, :], D[j, :]>.  A query's score is a pure function of its own tokens and the
  * document (the token sum runs in an order fixed by the query's length alone), so it does not depend on the batch it is
@@ -327,44 +347,6 @@ int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages
  * issued from python threads fight over the interpreter lock (70 ms stalls in a 10 ms call were measured).
  */
 int msim_host_gather(void *dst, const void *const *src, const int64_t *dst_off, const int64_t *nbytes, int64_t n, int n_threads);
-
-/*
- * Measurement aid (no reference counterpart): the streaming ceiling of this machine for the access patterns
- * of the kernels above.  Pulls the row-major 16-bit matrix X [rows, row_elems] through LDS once with the kernels'
- * own LDS-DMA instruction, cache policy and ring discipline and does nothing else; the caller times the launch
- * (bench.py reports bytes / time next to the 8 TB/s spec figure).
- *   MSIM_PROBE_ROWS256B    256-byte pieces of 32 rows per wave and ring slot; with row_elems = 128 these are whole
- *                          rows, i.e. msim_fwd's document stream
- *   MSIM_PROBE_PIECES128B  128-byte pieces of 32 rows per wave                   (msim_embed_head's hidden states)
- *   MSIM_PROBE_PIECES512B  512-byte pieces of 16 rows per wave                   (the best pattern found for wide rows)
- * rows must be a multiple of 256 and the row a multiple of the piece; sink = 4 bytes of device memory (never
- * written in practice: it only keeps the loads alive).
- */
-#define MSIM_PROBE_ROWS256B 0
-#define MSIM_PROBE_PIECES128B 1
-#define MSIM_PROBE_PIECES512B 2
-int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, float *sink, void *stream);
-
-/*
- * Measurement aid (no reference counterpart): the matrix-core ceiling of this machine under its own power budget for the
- * MaxSim kernels' MFMA (v_mfma_f32_32x32x16_bf16, two waves per SIMD, four 32-token tiles per wave) on the operand values
- * the scorer multiplies.  X = row-major [rows, 128] bf16 (unit-norm rows), rows >= 256 * 8 * 5 * 32 = 327 680; every wave
- * keeps 5 tiles of X in registers / LDS and issues `iters` x 32 MFMAs; no HBM traffic, no barrier.  The caller times the
- * launch: FLOP = 256 workgroups x 8 waves x iters x 32 x 32768.
- *   variant bit 0: A operand re-read from LDS per k-step (msim_fwd's operand path) instead of held in registers
- *   variant bit 1: the 16 -> 1 max fold of every accumulator tile runs next to the MFMAs
- *   variants 4..7: the same four mixes on v_mfma_f32_16x16x32_bf16, the tile shape msim_fwd's kernels use (variant - 4 = the bits
- *   above): 7 = their instruction mix (A fragments from LDS + max folds), 4 = MFMAs alone
- *   variants 8..11 (rows >= 256 * 16 * 3 * 32 = 393 216): the 16x16x32 mix with MORE waves per SIMD -- 8: 12 waves x 3 tiles, 9: 16 waves x
- *   2 tiles (both A from LDS + folds), 10 / 11: the same two shapes with everything in registers.  FLOP = 256 x 12 x iters x 48 x 16384
- *   (8, 10) resp. 256 x 16 x iters x 32 x 16384 (9, 11).
- *   variants 12..23 (round 3, iters even): msim_fwd's EXACT slab body (8 fragment reads per 32-row slab, then per token tile 16
- *   v_mfma_f32_16x16x32 + 8 v_max3) under other register plans -- 12: the shipped plan (8 waves x 4 tiles), 16: the same with the
- *   fragments in registers, 17: 4 waves x 4 tiles; 13 / 15: ONE 512-register wave per SIMD x 8 / 6 tiles (B operands in AGPRs),
- *   14: 13 with the fragments in registers, 18 / 19: 13 / 15 with the next slab's fragments prefetched, 20 / 21 / 22: + the fold
- *   of tile t-1 under tile t (21: interleave pinned), 23: 14 with deferred folds.  FLOP = 256 x waves x iters x tiles x 16 x 16384.
- */
-int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *sink, void *stream);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -107,8 +107,12 @@ def test_every_other_entry_point_is_graph_capturable(amd):
 
 
 def test_probe_stream_runs_and_validates_arguments(amd):
-    """msim_probe_stream (measurement aid): every variant launches on a conforming matrix; bad shapes are refused."""
-    L = amd._lib.lib()
+    """msim_probe_stream (measurement aid, tools/probe/libmaxsim_probe.so -- not the product library): every variant launches on a
+    conforming matrix; bad shapes are refused."""
+    from tools import probe
+
+    L = probe.lib()
+    assert L is not None, "tools/probe/libmaxsim_probe.so is not built (__graft_entry__.build())"
     dev = torch.device("cuda:0")
     sink = torch.zeros(4, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -301,15 +305,19 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
 
 
 def test_probe_mfma_runs_and_validates_arguments(amd):
-    """msim_probe_mfma (measurement aid): every variant launches and leaves the sink untouched; bad arguments are refused."""
-    L = amd._lib.lib()
+    """msim_probe_mfma (measurement aid, tools/probe/libmaxsim_probe.so): every variant launches and leaves the sink untouched; bad
+    arguments are refused."""
+    from tools import probe
+
+    L = probe.lib()
+    assert L is not None, "tools/probe/libmaxsim_probe.so is not built (__graft_entry__.build())"
     dev = torch.device("cuda:0")
     rows, rows_small = 256 * 16 * 3 * 32, 256 * 8 * 5 * 32
     x = torch.nn.functional.normalize(torch.randn((rows, 128), device=dev), dim=-1).to(torch.bfloat16)
     sink = torch.zeros(4, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for variant in range(25):               # 12..24: K1b's exact slab body under the round-3 register plans (probe_mfma.hip)
-        assert L.msim_probe_mfma(variant, x.data_ptr(), rows, 50, sink.data_ptr(), st) == 0, L.msim_last_error()
+        assert L.msim_probe_mfma(variant, x.data_ptr(), rows, 50, sink.data_ptr(), st) == 0, L.msim_probe_last_error()
     torch.cuda.synchronize()
     assert float(sink.abs().sum()) == 0.0
     assert L.msim_probe_mfma(25, x.data_ptr(), rows, 50, sink.data_ptr(), st) != 0

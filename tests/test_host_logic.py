@@ -33,6 +33,29 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     lib.msim_abi_version.restype = ctypes.c_int
     m = re.search(r"#define MSIM_ABI_VERSION (\d+)", header)
     assert lib.msim_abi_version() == int(m.group(1))
+    # ... and exports nothing else: the entry points ARE the header (measurement aids live in tools/probe/, include/maxsim_probe.h)
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", colpali_amd._lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-2:-1] == ["T"] and ln.split()[-1].startswith("msim_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    assert not any("probe" in s for s in exported)
+
+
+def test_probe_library_is_separate_from_the_product():
+    """bench.py's ceilings come from tools/probe/libmaxsim_probe.so (include/maxsim_probe.h); it exports what that header declares."""
+    from tools import probe
+
+    header = open(os.path.join(ROOT, "include", "maxsim_probe.h")).read()
+    declared = set(re.findall(r"\b(msim_[a-z0-9_]+)\s*\(", header))
+    assert declared == {"msim_probe_last_error", "msim_probe_stream", "msim_probe_mfma"}
+    if not os.path.exists(probe.LIB_PATH):
+        pytest.skip("tools/probe/libmaxsim_probe.so not built")
+    lib = ctypes.CDLL(probe.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name)
+    src = "".join(open(os.path.join(ROOT, "colpali_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "colpali_amd")) if f.endswith(".py"))
+    assert "probe" not in src            # the package never loads it
 
 
 def test_abi_rejects_bad_arguments_without_touching_a_gpu():
@@ -110,13 +133,18 @@ def test_generic_widths_are_zero_padded_to_32_byte_rows():
     assert colpali_amd._lib.kernel_width(30, torch.float32) == 32
 
 
-def test_empty_inputs_and_cpu_device_errors_mirror_or_fail_loudly():
+def test_empty_inputs_raise_like_the_reference_and_a_gpu_request_is_never_served_elsewhere():
     with pytest.raises(ValueError, match="No queries provided"):
         colpali_amd.score_multi_vector([], [bf(2)])
     with pytest.raises(ValueError, match="No passages provided"):
         colpali_amd.score_multi_vector([bf(2)], [])
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        colpali_amd.score_multi_vector([bf(2)], [bf(2)], device="cpu")
+    # device="cpu" is the caller's choice and is served by the library's host path (tests/test_host_path.py); a GPU request on a host
+    # without a GPU fails loudly -- it is never quietly computed somewhere else
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no ROCm GPU"):
+            colpali_amd.score_multi_vector([bf(2)], [bf(2)], device="cuda:0")
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        colpali_amd.similarity_matrix(bf(2), bf(2))
 
 
 def test_all_empty_passage_block_raises_like_the_reference():

@@ -7,7 +7,8 @@ import torch
 import bench, colpali_amd as amd
 
 dev = torch.device("cuda:0")
-L = amd._lib.lib()
+from tools import probe
+L = probe.lib()          # tools/probe/libmaxsim_probe.so (include/maxsim_probe.h): make -C tools/probe
 rows = 256 * 16 * 4 * 32          # >= 256 x 8 x (5 + 1) x 32 for the five-tile plan
 g = torch.Generator(device=dev).manual_seed(1)
 X = torch.nn.functional.normalize(torch.randn((rows, 128), generator=g, device=dev), dim=-1).to(torch.bfloat16)
@@ -32,7 +33,7 @@ for data, name in ((X, "random unit rows"), (Z, "zeros")):
                 rc = L.msim_probe_mfma(variant, data.data_ptr(), rows, iters, sink.data_ptr(), st.cuda_stream)
                 b.record(st)
                 torch.cuda.synchronize()
-                assert rc == 0, L.msim_last_error()
+                assert rc == 0, L.msim_probe_last_error()
                 if i >= 1:
                     ms.append(a.elapsed_time(b))
             t = sorted(ms)[len(ms) // 2]

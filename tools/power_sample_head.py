@@ -9,6 +9,8 @@ import colpali_amd as amd
 dev = torch.device("cuda:0")
 SMI = "/opt/rocm/bin/rocm-smi"
 L = amd._lib.lib()
+from tools import probe
+P = probe.lib()          # tools/probe/libmaxsim_probe.so (include/maxsim_probe.h)
 
 
 def sample():
@@ -64,7 +66,7 @@ for B, S, H in ((1000, 1030, 2048), (1000, 779, 1536), (256, 1030, 3584)):
     rows = B * S // 256 * 256
     st = torch.cuda.current_stream().cuda_stream
     run(f"K3 fused head, hidden {H} ({B} x {S} rows)", lambda: amd.embedding_head(hidden, weight, bias, mask), B * S * H * 2 + B * S * 256)
-    run(f"  its bare access pattern (probe, 128-B pieces), hidden {H}", lambda: L.msim_probe_stream(1, hidden.data_ptr(), rows, H, sink.data_ptr(), st),
+    run(f"  its bare access pattern (probe, 128-B pieces), hidden {H}", lambda: P.msim_probe_stream(1, hidden.data_ptr(), rows, H, sink.data_ptr(), st),
         rows * H * 2)
     zh = torch.zeros_like(hidden)
     run(f"  K3 on ZERO hidden states, hidden {H}", lambda: amd.embedding_head(zh, weight, bias, mask), B * S * H * 2 + B * S * 256)

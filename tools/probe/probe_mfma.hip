@@ -1,4 +1,4 @@
-// Measurement aid behind msim_probe_mfma (include/maxsim.h): the matrix-core ceiling of THIS machine, under its own power
+// Measurement aid behind msim_probe_mfma (include/maxsim_probe.h): the matrix-core ceiling of THIS machine, under its own power
 // budget, for the instruction mix of the MaxSim kernels on REAL operand values.  Every SIMD of the chip runs
 // v_mfma_f32_32x32x16_bf16 back to back on operand fragments taken from the caller's matrix (unit-norm bf16 rows: the values the
 // scorer multiplies), two waves per SIMD like K1b, with nothing else in the way:

@@ -1,4 +1,4 @@
-// Measurement aid behind msim_probe_stream (include/maxsim.h): the streaming ceiling of THIS machine for the access
+// Measurement aid behind msim_probe_stream (include/maxsim_probe.h): the streaming ceiling of THIS machine for the access
 // patterns the kernels use.  A CU-filling persistent grid pulls a row-major [M, H] 16-bit matrix through LDS with the same
 // LDS-DMA instruction, cache policy (nt) and ring discipline as K1s / K3 -- PIECE bytes of ROWS rows per wave and ring
 // slot, DEPTH slots, WAVES waves per workgroup -- and does nothing else (one ds_read per slot keeps the data dependency).

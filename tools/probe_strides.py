@@ -8,7 +8,8 @@ import torch
 import colpali_amd as amd
 
 dev = torch.device("cuda:0")
-L = amd._lib.lib()
+from tools import probe
+L = probe.lib()          # tools/probe/libmaxsim_probe.so (include/maxsim_probe.h): make -C tools/probe
 sink = torch.zeros(4, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream()
 for H in [int(x) for x in os.environ.get("PS_WIDTHS", "1536,1984,2048,2112,2560,3072,3584,4096").split(",")]:
@@ -28,7 +29,7 @@ for H in [int(x) for x in os.environ.get("PS_WIDTHS", "1536,1984,2048,2112,2560,
             rc = L.msim_probe_stream(variant, x.data_ptr(), rows, H, sink.data_ptr(), st.cuda_stream)
             b.record(st)
             torch.cuda.synchronize()
-            assert rc == 0, L.msim_last_error()
+            assert rc == 0, L.msim_probe_last_error()
             if i >= 2:
                 ms.append(a.elapsed_time(b))
         t = sorted(ms)[len(ms) // 2]
