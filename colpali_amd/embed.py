@@ -178,6 +178,11 @@ class CorpusWriter:
         if hidden_states.dtype != self.blob.dtype or hidden_states.device != self.device:
             raise ValueError("hidden states must have the writer's dtype and device")
         B, S, _ = hidden_states.shape
+        if B == 0 or S == 0:        # nothing to write: the row counter must not be replaced by a buffer no kernel filled
+            if S == 0 and B > 0:
+                self._counts.append(torch.zeros((B,), dtype=torch.int64, device=self.device))
+                self._padded_lens.append(torch.zeros((B,), dtype=torch.int64))
+            return B
         if self._rows_upper + B * S > self.capacity:
             # the bound counts masked positions too (no sync per append); reconcile it with the exact device-side count once
             # before refusing -- a rejected append leaves the writer unchanged

@@ -11,6 +11,10 @@ After the call
     (and the same names in `colpali_engine.loss.late_interaction_losses`) are the fused versions, so
     YAML configs that name the class by dotted path (scripts/configs/qwen2/train_colqwen2_model.yaml:24-25)
     pick them up.
+  * with `models=True`: the forward of every Col* model class that is importable (`colpali_engine.models`, or the model modules
+    already imported) ends in the fused embedding head (colpali_amd/models.py): the class's own argument handling and VLM
+    backbone run unchanged on PyTorch-ROCm, `custom_text_proj` + L2 norm + masks (modeling_colpali.py:67-77 and the same lines
+    in the other families) become one HIP kernel.
 `unpatch_colpali_engine()` restores the originals.
 """
 from __future__ import annotations
@@ -19,6 +23,7 @@ import importlib
 import sys
 
 from . import loss as _loss
+from . import models as _models
 from .pooling import HierarchicalTokenPooler
 from .retrieval import create_plaid_index, get_topk_plaid
 from .scoring import get_similarity_maps_from_embeddings, score_multi_vector, score_single_vector
@@ -28,7 +33,28 @@ _LOSS_NAMES = ("ColbertPairwiseCELoss", "ColbertLoss", "ColbertSigmoidLoss", "Co
 _saved = {}
 
 
-def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
+def _model_classes():
+    """Col* model classes of an importable colpali_engine: the whole `colpali_engine.models` package when its dependencies are
+    installed, else whatever model modules the caller has imported (the package __init__ pulls every family)."""
+    try:
+        importlib.import_module("colpali_engine.models")
+    except Exception:      # a family's dependency is missing here: patch the families that ARE imported
+        pass
+    found = []
+    for name, mod in list(sys.modules.items()):
+        if mod is None or not name.startswith("colpali_engine.models"):
+            continue
+        for cname in _models.MODEL_CLASS_NAMES:
+            cls = getattr(mod, cname, None)
+            if isinstance(cls, type) and cls not in found and getattr(cls, "__module__", "").startswith("colpali_engine.models"):
+                found.append(cls)
+    return found
+
+
+def patch_colpali_engine(scorer: bool = True, losses: bool = True, models: bool = False) -> None:
+    if models:
+        for cls in _model_classes():
+            _models.install(cls)
     if scorer:
         pu = importlib.import_module("colpali_engine.utils.processing_utils")
         cls = pu.BaseVisualRetrieverProcessor
@@ -63,6 +89,7 @@ def patch_colpali_engine(scorer: bool = True, losses: bool = True) -> None:
 
 
 def unpatch_colpali_engine() -> None:
+    _models.uninstall()
     for key, obj in list(_saved.items()):
         if key in ("score_multi_vector", "score_single_vector", "get_topk_plaid", "create_plaid_index"):
             pu = importlib.import_module("colpali_engine.utils.processing_utils")

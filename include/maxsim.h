@@ -288,7 +288,7 @@ int msim_embed_head_row_map(const void *mask, int mask_kind, const void *extra, 
  * what replaces README.md:121-126 `torch.unbind(embeddings.to("cpu"))` + the scorer's per-block pad_sequence):
  *   row_map[b * S + s] = keep(b, s) ? *rows_before + (kept positions of pages < b) + (kept positions of page b before s) : -1
  *   counts[b] = kept positions of page b (int64, device);  *rows_after = *rows_before + sum of counts;  tile padding of the map = -1.
- * mask / extra as in msim_embed_head_row_map, [B * S] elements; rows_before / rows_after: device int64 (may alias).
+ * mask / extra as in msim_embed_head_row_map, [B * S] elements; rows_before / rows_after: device int64; they must NOT alias (the page workgroups read *rows_before while another one writes *rows_after).
  */
 int msim_embed_head_writer_map(const void *mask, int mask_kind, const void *extra, int extra_kind, int B, int S, const int64_t *rows_before,
                                int64_t *counts, int32_t *row_map, int64_t *rows_after, void *stream);

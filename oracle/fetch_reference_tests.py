@@ -11,6 +11,12 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 REF = os.environ.get("COLPALI_REFERENCE", "/root/reference")
 FILES = ("tests/utils/test_processing_utils.py", "tests/loss/test_li_losses.py")
+# the model files whose forward colpali_amd.patch_colpali_engine(models=True) wraps: the GPU tests and bench.py's "VLM in the loop"
+# leg run the REAL classes (random init), so these travel the same way -- verbatim, git-ignored, under tests/_reference_pkg/
+MODEL_FILES = ("colpali_engine/models/paligemma/colpali/modeling_colpali.py",
+               "colpali_engine/models/qwen2/colqwen2/modeling_colqwen2.py",
+               "colpali_engine/models/qwen2_5/colqwen2_5/modeling_colqwen2_5.py",
+               "colpali_engine/models/idefics3/colidefics3/modeling_colidefics3.py")
 
 
 def main() -> int:
@@ -23,6 +29,15 @@ def main() -> int:
     for rel in FILES:
         src = os.path.join(REF, rel)
         dst = os.path.join(dst_dir, os.path.basename(rel))
+        shutil.copyfile(src, dst)
+        lines.append(f"{hashlib.sha256(open(dst, 'rb').read()).hexdigest()}  {rel}")
+    pkg_dir = os.path.join(ROOT, "tests", "_reference_pkg")
+    for rel in MODEL_FILES:
+        src = os.path.join(REF, rel)
+        if not os.path.exists(src):
+            continue
+        dst = os.path.join(pkg_dir, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
         shutil.copyfile(src, dst)
         lines.append(f"{hashlib.sha256(open(dst, 'rb').read()).hexdigest()}  {rel}")
     with open(os.path.join(dst_dir, "SOURCES.txt"), "w") as f:

@@ -15,6 +15,9 @@ import sys
 import types
 
 REFERENCE_ROOT = os.environ.get("COLPALI_REFERENCE_ROOT", "/root/reference")
+# where oracle/fetch_reference_tests.py leaves verbatim, git-ignored copies of the reference's model files (they travel to the
+# GPU box with the working tree, like the reference's own tests under tests/_reference_tests/)
+FETCHED_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "_reference_pkg"))
 
 
 def available() -> bool:
@@ -52,6 +55,34 @@ def load_colpali_class():
     from colpali_engine.models.paligemma.colpali.modeling_colpali import ColPali  # noqa: E402
 
     return ColPali
+
+
+def model_root() -> str:
+    """The directory holding `colpali_engine/models/...`: the reference checkout here, the fetched copy on the GPU box."""
+    if available():
+        return REFERENCE_ROOT
+    if os.path.isdir(os.path.join(FETCHED_ROOT, "colpali_engine", "models")):
+        return FETCHED_ROOT
+    raise RuntimeError("no reference model files: neither the checkout nor tests/_reference_pkg/ (oracle/fetch_reference_tests.py)")
+
+
+def load_model_class(rel_module: str, cls_name: str):
+    """A Col* model class of the (live or fetched) reference, e.g. ("models/qwen2/colqwen2/modeling_colqwen2", "ColQwen2").
+    Random-init use only.  Every package on the way is a stub (the real __init__ files import every family and, through
+    them, dependencies that are not installed)."""
+    root = model_root()
+    sys.dont_write_bytecode = True
+    parts = rel_module.split("/")
+    for i in range(len(parts)):
+        name = ".".join(["colpali_engine"] + parts[:i])
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [os.path.join(root, "colpali_engine", *parts[:i])]
+            sys.modules[name] = pkg
+    import importlib
+
+    mod = importlib.import_module(".".join(["colpali_engine"] + parts))
+    return getattr(mod, cls_name)
 
 
 def load_similarity_map_utils():
