@@ -52,9 +52,9 @@ def text_batch(B=5, S=37, seed=2, left_pad=False, device="cpu"):
     ids = torch.randint(0, 290, (B, S), generator=g)
     mask = torch.ones(B, S, dtype=torch.long)
     if left_pad:
-        mask[1, :7] = 0
-        mask[3, :20] = 0
+        mask[1, :S // 5] = 0
+        mask[B - 1, :S // 2] = 0
     else:
-        mask[1, 30:] = 0
-        mask[3, 11:] = 0
+        mask[1, S - S // 5:] = 0
+        mask[B - 1, S // 3:] = 0
     return dict(input_ids=ids.to(device), attention_mask=mask.to(device))
