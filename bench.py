@@ -51,8 +51,9 @@ def parse_args():
                          "BASELINE config 4 over 8 GPUs")
     ap.add_argument("--doc-len", type=int, default=1024)
     ap.add_argument("--nq", type=int, default=4, help="queries per step (32 tokens each); 4 = BASELINE config 1's query batch")
-    ap.add_argument("--regimes", type=str, default="1,6,8,10,12,16,20,32,40,1000,4x40,16x40,1000x20,1000x40,1000x48,1000xr12-48",
-                    help="other query batches measured after the headline and reported under 'regimes' ('' = none): N = N queries of "
+    ap.add_argument("--regimes", type=str, default=None,
+                    help="other query batches measured after the headline and reported under 'regimes' ('' = none; default: REGIMES_SINGLE "
+                         "at --gpus 1, the shorter REGIMES_MULTI above): N = N queries of "
                          "--q-len tokens; NxL = N queries of L tokens; NxrA-B = N queries of ragged lengths U{A..B} (real query lengths: "
                          "processing_utils.py:86 appends 10 augmentation tokens, SURVEY: Lq ~ 20-40)")
     ap.add_argument("--q-len", type=int, default=32)
@@ -713,6 +714,18 @@ def _free_port():
     return p
 
 
+def rank_launch_command(n_gpus, argv, port, environ):
+    """(command, environment) of the self-launch: `python -m torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1 (the
+    container's hostname may not resolve), HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver only supports dmabuf IPC: without it RCCL
+    fails with `hipIpcGetMemHandle: invalid argument`), the host's threads divided between the ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(environ, BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    return cmd, env
+
+
 def launch_ranks(n_gpus):
     """`--gpus N` without a launcher: run N ranks of this file under torch.distributed.run (one per GPU, RCCL) and forward
     rank 0's JSON line.  Refuses (exit code 2) when fewer than N GPUs are visible, unless BENCH_SHARE_GPU=1."""
@@ -723,12 +736,15 @@ def launch_ranks(n_gpus):
         sys.stderr.write(f"bench.py: --gpus {n_gpus} requested but only {visible} GPU(s) are visible; refusing to run "
                          f"{n_gpus} ranks on fewer devices (set BENCH_SHARE_GPU=1 for a plumbing-only run)\n")
         return 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, BENCH_SELF_LAUNCHED="1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    cmd, env = rank_launch_command(n_gpus, sys.argv[1:], _free_port(), os.environ)
     return subprocess.call(cmd, env=env)
+
+
+# N > 1: the regimes every rank runs after the headline.  Eight ranks each re-score their parity sample on the cores torchrun
+# leaves them and the driver's clock covers the whole run, so the multi-GPU line carries the regimes that say something about
+# scaling -- the HBM-bound headline's neighbours and config 4's 1000-query batch, uniform and ragged -- not the single-GPU ridge sweep.
+REGIMES_SINGLE = "1,6,8,10,12,16,20,32,40,1000,4x40,16x40,1000x20,1000x40,1000x48,1000xr12-48"
+REGIMES_MULTI = "1,32,1000,1000xr12-48"
 
 
 def main():
@@ -741,6 +757,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.regimes is None:
+        args.regimes = REGIMES_SINGLE if world == 1 else REGIMES_MULTI
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -857,6 +875,24 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             par["merge_equals_oracle_merge_on_all_ranks"] = bool(okt.item())
             par["ranks_checked"] = world
+            # small corpora (plumbing runs): rank 0 also rebuilds EVERY shard from its seed, scores the unsharded corpus and takes its
+            # top-k -- the list the collective returned must be that list, ids and scores (contiguous id ranges: shard r = ids r*docs ..)
+            if args.docs * world <= 65536:
+                same = True
+                if rank == 0:
+                    from colpali_amd.corpus import PackedCorpus
+
+                    shards = [make_shard(args.docs, args.doc_len, dev, seed=1234 + r) for r in range(world)]
+                    whole = PackedCorpus(blob=torch.cat([s.blob for s in shards]),
+                                         offsets=(torch.arange(args.docs * world + 1, dtype=torch.int64) * args.doc_len).to(torch.int32).to(dev),
+                                         clamp0=None, lengths=torch.full((args.docs * world,), args.doc_len, dtype=torch.int64))
+                    ws_, wi_ = amd.topk(amd.maxsim_scores(q, whole), args.topk, 0)
+                    same = bool(torch.equal(wi_, top[1]) and torch.equal(ws_, top[0]))
+                    del shards, whole
+                st_ = torch.tensor([int(same)], dtype=torch.int32, device=ones.device)
+                dist.broadcast(st_, src=0)
+                par["merged_topk_equals_unsharded_topk"] = bool(st_.item())
+                par["id_base_per_rank"] = [r * args.docs for r in range(world)]
         if rank == 0:
             out["topk_parity"] = par
             out["parity_max_rel_err_vs_oracle_sample"] = par["max_rel_err"]

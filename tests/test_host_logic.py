@@ -282,6 +282,34 @@ def test_bench_refuses_more_ranks_than_visible_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_bench_self_launch_builds_one_rank_per_gpu_on_the_loopback():
+    """What `python bench.py --gpus 8` executes when no launcher started it (the driver's 8-GPU run may come either way): the
+    command and environment, without starting anything."""
+    import importlib.util
+    import sys
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd, env = bench.rank_launch_command(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"], 29511, {"PATH": "/usr/bin"})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-7] == os.path.join(ROOT, "bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert env["BENCH_SELF_LAUNCHED"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and int(env["OMP_NUM_THREADS"]) >= 1
+    # an 8-GPU request on a box with fewer GPUs is refused like the 2-GPU one (exit code 2, nothing on stdout)
+    import subprocess
+
+    clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=clean, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+    # the multi-GPU line runs a bounded regime list (eight ranks, each with its own oracle sample, inside the driver's clock)
+    assert len(bench.REGIMES_MULTI.split(",")) <= 5 and "1000" in bench.REGIMES_MULTI.split(",")
+    for spec_ in bench.REGIMES_SINGLE.split(",") + bench.REGIMES_MULTI.split(","):
+        n, lens, label = bench.parse_regime(spec_, 32)
+        assert n == len(lens) and min(lens) >= 1
+
+
 def test_loss_offset_and_pair_checks_run_before_any_device_work():
     from colpali_amd import loss as Lm
 
