@@ -911,6 +911,11 @@ def main():
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
+    zero_corpus = None
+    if world == 1 and os.environ.get("BENCH_ZERO_SHARD", "1") != "0":
+        from colpali_amd.corpus import PackedCorpus
+
+        zero_corpus = PackedCorpus(blob=torch.zeros_like(corpus.blob), offsets=corpus.offsets, clamp0=None, lengths=corpus.lengths)
     for spec in [x for x in args.regimes.split(",") if x]:
         nq, lens, len_label = parse_regime(spec, args.q_len)
         if "x" in spec:      # real query lengths: a host list of ragged / non-tile-sized queries, packed as the product packs them
@@ -931,7 +936,20 @@ def main():
             ps = power_sample(amd, qq, corpus)
             if ps:
                 regimes[-1]["power"] = ps
+        if zero_corpus is not None and nq <= 64:
+            # the same launch on a zero-filled shard of the same shape: the same HBM traffic and instruction stream with operands that
+            # toggle nothing, i.e. the kernel WITHOUT the socket's power cap -- splits "structure" from "cap" for every later reader
+            _, kmz, _, _ = run_regime(amd, qq, zero_corpus, 3, 1, args.topk, world, rank, dist)
+            rz = regime_numbers(nq, args.q_len, args.docs, args.doc_len, sum(kmz) / len(kmz), q_tokens=sum(lens))
+            regimes[-1].setdefault("power", {})["frac_on_zeros"] = rz["frac"]
+            regimes[-1]["power"]["kernel_ms_on_zeros"] = rz["kernel_ms"]
         del qq
+    if zero_corpus is not None:
+        _, kmz, _, _ = run_regime(amd, q, zero_corpus, 3, 1, args.topk, world, rank, dist)
+        rz = regime_numbers(args.nq, args.q_len, args.docs, args.doc_len, sum(kmz) / len(kmz))
+        out["roofline"].setdefault("power", {})["frac_on_zeros"] = rz["frac"]
+        out["roofline"]["power"]["kernel_ms_on_zeros"] = rz["kernel_ms"]
+        del zero_corpus
     out["regimes"] = regimes
     if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("BENCH_VLM", "1") != "0":
         try:        # context only, and last: a 3 B-parameter random-init VLM must never take the bench line down

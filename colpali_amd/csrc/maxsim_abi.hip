@@ -311,10 +311,16 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
         return MSIM_OK;
     }
     static const int shapes[6][2] = {{2, 8}, {2, 10}, {4, 8}, {4, 10}, {8, 8}, {8, 10}};
+    // round 4 re-measured the ladder in units (profiles/r04_logs/ab_plan_ladder.log, 16 GiB shard, random rows / zero-filled shard):
+    // 18 units: pair x 10 (9 + 9) 4.12 ms / 2.97 vs 4 waves (5/5/4/4) 4.23 / 2.99; 20 units: 4 waves x 5 units 4.38 / 3.04 vs the
+    // pair 4.42-4.45 / 3.19 -- four evenly loaded waves beat two ten-unit ones once the units divide by four
     const int forced = batch_nw_override();
+    static const int forced_maxu = ab_env("MSIM_BATCH_MAXU", 0);      // 8 | 10 (measurement builds)
     for (const auto &sh : shapes) {
         if (forced && sh[0] != forced) continue;
+        if (forced_maxu && sh[1] != forced_maxu) continue;
         if (units > sh[0] * sh[1] || n_q > sh[0] * 8) continue;
+        if (!forced && !forced_maxu && sh[0] == 2 && sh[1] == 10 && units > 18 && n_q <= 32) continue;   // 19..20 units: the 4-wave form
         if (!fill_blocks(hq, n_q, sh[0], sh[1], p.blk_q0) || p.n_blocks() != 1) continue;
         p.nw = sh[0];
         p.maxu = sh[1];
@@ -1655,6 +1661,14 @@ int msim_query_compact(const void *box, int n_q, int Lq, int row_bytes, const in
 // launch has enough workgroups to fill the chip even for a single row); later levels use full segments.
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// level 0 as the streaming threshold filter (topk_select.hip: topk_filter_kernel): rows of raw scores long enough for it, few
+// enough winners per row, and enough (row, segment) workgroups to fill the chip -- the many-query regime, where the bitonic level
+// was the one kernel of the timed step two orders off its roof
+static bool topk_use_filter(const int64_t *ids, int n_q, long long n, int k) {
+    if (ids != nullptr || k > msim::kTopkFilterMaxK || n < 2LL * msim::kTopkFilterSeg) return false;
+    return (long long)n_q * ((n + msim::kTopkFilterSeg - 1) / msim::kTopkFilterSeg) >= 512;
+}
+
 static int topk_first_segment(int n_q, long long n, int k) {
     int seg = 512;
     while (seg < 4 * k) seg <<= 1;                       // every level must shrink its input at least 4x
@@ -1673,15 +1687,24 @@ static int topk_later_segment(int k) {
 // one more workgroup-per-segment level only while the row is longer than two segments; otherwise one workgroup finishes the row
 static inline bool topk_is_last(long long n, int seg) { return n <= 2LL * seg && n <= msim::kTopkSeg; }
 
-size_t msim_topk_workspace_bytes(int n_q, int64_t n, int k) {
-    if (n_q <= 0 || k <= 0 || k > msim::kTopkMaxK) return 0;
-    const int seg0 = topk_first_segment(n_q, n, k);
+static size_t topk_plan_bytes(int n_q, long long n, int k, int seg0) {
     if (topk_is_last(n, seg0)) return 0;
     const int seg1 = topk_later_segment(k);
     const long long na = topk_level_out(n, seg0, k);
     const long long nb = topk_is_last(na, seg1) ? 0 : topk_level_out(na, seg1, k);
     return align16((size_t)n_q * na * 4) + align16((size_t)n_q * na * 8) + align16((size_t)n_q * nb * 4) +
            align16((size_t)n_q * nb * 8);
+}
+
+size_t msim_topk_workspace_bytes(int n_q, int64_t n, int k) {
+    if (n_q <= 0 || k <= 0 || k > msim::kTopkMaxK) return 0;
+    // the same problem takes the filter level without explicit ids and the plain level with them: room for either
+    size_t need = topk_plan_bytes(n_q, n, k, topk_first_segment(n_q, n, k));
+    if (topk_use_filter(nullptr, n_q, n, k)) {
+        const size_t f = topk_plan_bytes(n_q, n, k, msim::kTopkFilterSeg);
+        if (f > need) need = f;
+    }
+    return need;
 }
 
 int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, int64_t ld, int k, int64_t id_base,
@@ -1691,7 +1714,8 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
     if (!out_scores || !out_ids || (n > 0 && !scores)) return fail(MSIM_EINVAL, "null pointer argument");
     if (k > msim::kTopkMaxK) return fail(MSIM_EUNSUPPORTED, "k=%d > %d", k, msim::kTopkMaxK);
     if (ld < n) return fail(MSIM_EINVAL, "ld=%lld < n=%lld", (long long)ld, (long long)n);
-    const int seg0 = topk_first_segment(n_q, n, k);
+    const bool filter0 = topk_use_filter(ids, n_q, n, k);
+    const int seg0 = filter0 ? msim::kTopkFilterSeg : topk_first_segment(n_q, n, k);
     const int seg1 = topk_later_segment(k);
     if (!topk_is_last(n, seg0) && !workspace) return fail(MSIM_EINVAL, "workspace required (msim_topk_workspace_bytes)");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1723,6 +1747,11 @@ int msim_topk_f32(const float *scores, const int64_t *ids, int n_q, int64_t n, i
         if (!last && o_ld > bufs_ld[which]) return fail(MSIM_ELAUNCH, "internal: top-k level does not fit its buffer");
         for (int r0 = 0; r0 < n_q; r0 += 65535) {   // grid.y limit
             const int rows = (n_q - r0 < 65535) ? (n_q - r0) : 65535;
+            if (filter0 && in_s == scores) {        // level 0: the streaming filter
+                hipLaunchKernelGGL(msim::topk_filter_kernel, dim3((unsigned)segs, (unsigned)rows), dim3(msim::kTopkThreads), 0, st,
+                                   in_s + (size_t)r0 * in_ld, in_n, in_ld, in_base, k, o_s + (size_t)r0 * o_ld, o_i + (size_t)r0 * o_ld, o_ld);
+                continue;
+            }
             hipLaunchKernelGGL(msim::topk_segment_kernel, dim3((unsigned)segs, (unsigned)rows), dim3(msim::kTopkThreads), 0, st,
                                in_s + (size_t)r0 * in_ld, in_i ? in_i + (size_t)r0 * in_ld : nullptr, in_n, in_ld, in_base, k,
                                last ? msim::kTopkSeg : seg, o_s + (size_t)r0 * o_ld, o_i + (size_t)r0 * o_ld, o_ld);

@@ -32,6 +32,45 @@ def test_topk_matches_oracle_with_ties(amd, n_q, n, k):
     np.testing.assert_array_equal(gs.cpu().numpy(), ws)
 
 
+@pytest.mark.parametrize("n_q,n,k,kind", [
+    (100, 125000, 10, "ties"),          # BASELINE config 4's shard width: 8 filter segments per row
+    (200, 40001, 100, "ties"),          # odd row length: rows start off the 16-byte grid (scalar loads), ragged last segment
+    (600, 33000, 256, "normal"),        # the largest k the filter takes
+    (520, 32768, 10, "ascending"),      # adversarial: every score beats the threshold -> one cut per round
+    (520, 50000, 10, "descending"),     # the first round already holds the winners
+    (520, 32770, 7, "constant"),        # all equal: ids decide everything
+    (70, 125000, 10, "special"),        # -inf, NaN-free extremes, signed zeros
+])
+def test_streaming_filter_level_matches_oracle(amd, n_q, n, k, kind):
+    """Many rows x long rows take the streaming threshold filter at level 0 (topk_select.hip: topk_filter_kernel): ids and scores
+    bit-exact against the oracle ranking (score desc, id asc), whatever the data does to the threshold."""
+    g = torch.Generator().manual_seed(n + k)
+    if kind == "ties":
+        s = (torch.randn(n_q, n, generator=g) * 8).round() / 8
+    elif kind == "normal":
+        s = torch.randn(n_q, n, generator=g)
+    elif kind == "ascending":
+        s = torch.arange(n, dtype=torch.float32).repeat(n_q, 1) + torch.arange(n_q, dtype=torch.float32)[:, None]
+    elif kind == "descending":
+        s = -torch.arange(n, dtype=torch.float32).repeat(n_q, 1)
+    elif kind == "constant":
+        s = torch.full((n_q, n), 3.25)
+    else:
+        s = torch.randn(n_q, n, generator=g)
+        s[:, ::97] = float("-inf")
+        s[0, 5] = 3.0e38
+        s[1, :] = float("-inf")
+        s[2, 10] = 0.0
+        s[2, 11] = -0.0
+        s[2, 12:] = -1.0
+    L = amd._lib.lib()
+    assert L.msim_topk_workspace_bytes(n_q, n, k) > 0
+    gs, gi = amd.topk(s.cuda(), k, id_base=5000)
+    ws, wi = topk_oracle.topk(s.numpy(), k, id_base=5000)
+    np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(gs.cpu().numpy(), ws)
+
+
 def test_topk_with_explicit_ids_and_padding(amd):
     s = torch.tensor([[1.0, 5.0, 5.0, -1.0, 5.0, 9.0]])
     ids = torch.tensor([[70, 30, 10, -1, 20, -1]])
