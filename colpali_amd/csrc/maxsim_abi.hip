@@ -1352,9 +1352,9 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     a.trace = nullptr;
     a.stagger = ab_env("MSIM_HEAD_STAGGER", 0);
     a.stagger_sleep = ab_env("MSIM_HEAD_STAGGER_SLEEP", 1);
-    if constexpr (msim::kTraceBuild) {                       // `make trace` only: device address of 9 x 8 uint64 (tools/trace_head.py)
-        if (const char *tp = getenv("MSIM_HEAD_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
-    }
+#ifdef MSIM_TRACE                                            // `make trace` only: device address of 9 x 8 uint64 (tools/trace_head.py)
+    if (const char *tp = getenv("MSIM_HEAD_TRACE_PTR")) a.trace = reinterpret_cast<unsigned long long *>(strtoull(tp, nullptr, 0));
+#endif
     const long long tiles = (M + msim::kHeadBM - 1) / msim::kHeadBM;
     const int grid = tiles < di->cus ? (int)tiles : di->cus;
     const long long tiles_h = (M + 127) / 128;                               // HALF variant: 128-row tiles, two workgroups per CU
@@ -1377,8 +1377,10 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
     const bool f16 = dtype == MSIM_DTYPE_F16;
     // Shipped: loader two weight chunks ahead (rings 3 + 3), output rows staged through LDS and stored as whole rows with the
     // streaming policy (needs 16-byte aligned output rows; the 2-byte-store form of the same kernel otherwise).  Every other
-    // variant of embed_head_kernel was measured and not kept; they are compiled into measurement builds only.
-    if constexpr (!msim::kAbBuild) {
+    // variant of embed_head_kernel was measured and not kept; they are compiled into measurement builds only
+    // (preprocessor, not `if constexpr`: in a non-template function a discarded branch is still instantiated and code-generated).
+#if !defined(MSIM_AB) && !defined(MSIM_TRACE)
+    {
         const bool whole_rows = ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
         static std::atomic<int> cfg[4][kMaxDevices];
         if (whole_rows)
@@ -1387,7 +1389,10 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
         else
             rc = f16 ? go(msim::embed_head_kernel<true, false, false, false, true>, cfg[2], msim::kHeadFLds)
                      : go(msim::embed_head_kernel<false, false, false, false, true>, cfg[3], msim::kHeadFLds);
-    } else {
+        (void)go_half;
+    }
+#else
+    {
         static std::atomic<int> configured[12][kMaxDevices];
         // MSIM_HEAD_VARIANT = bit 0: flag-synchronised weight ring instead of one s_barrier per K chunk; bit 1: hand-pipelined operand
         // fetch; bit 2: swapped MFMA roles + per-row epilogue; bit 3 (default): loader two weight chunks ahead, rings 3 + 3; bit 4: two half-size workgroups per CU; bit 5: DMA pieces between the
@@ -1444,6 +1449,7 @@ int msim_embed_head(int dtype, const void *X, int64_t M, int H, const void *W, c
                               : go(msim::embed_head_kernel<false, false, false>, configured[7], msim::kHeadLds); break;
         }
     }
+#endif
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "embed_head_kernel launch: %s", hipGetErrorString(e));

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from .corpus import PackedCorpus
+from .corpus import PackedQueries, pack_queries
 from .scoring import maxsim_scores
 
 
@@ -127,8 +128,12 @@ class ShardedRetriever:
 
             self.dist = dist_mod
 
-    def search(self, queries: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
-        """queries: bf16 [n_q, Lq, 128] on this rank's GPU (replicated on every rank)."""
+    def search(self, queries, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+        """queries (replicated on every rank): a `PackedQueries`, a list of [len_i, 128] tensors, or a [n_q, Lq, 128] tensor -- the
+        last two are packed into the flat layout first (zero padding rows dropped: they add exactly 0 and would only cost MFMA work;
+        one small D2H of the per-query counts for a device tensor)."""
+        if self._score is maxsim_scores and not isinstance(queries, PackedQueries):
+            queries = pack_queries(queries, self.shard.device)
         scores = self._score(queries, self.shard)
         return shard_topk(scores, k, self.shard.id_base, self.world, self.dist, self.group, self._select,
                           force_collective=self.force_collective)

@@ -73,11 +73,12 @@ int msim_abi_version(void);
 const char *msim_last_error(void);
 
 /* Number of bytes of scratch msim_fwd can use for this problem (16-byte aligned device memory, contents irrelevant: the
- * call initialises what it uses on the stream).  Non-zero exactly when several query blocks stream the same document range
- * (from 33 token tiles up, and for some shapes of 2- and 3-tile queries from 9): the workgroups of an XCD then keep in step
- * through progress counters so that the range is fetched from HBM once and served to the others from that XCD's L2.
+ * call initialises what it uses on the stream).  Non-zero exactly when the launch plan holds several query blocks (bf16 / f16,
+ * width 128: more than 1280 query tokens or 64 queries in total -- a block takes whole queries, up to 1024 or 1280 tokens): the
+ * workgroups of an XCD that stream the same document range for different blocks then keep in step through progress counters, so
+ * that the range is fetched from HBM once and served to the others from that XCD's L2.
  * Queries longer than 128 tokens (bf16 / f16, width 128: pages as queries, the trainer's symmetric direction) are scored as
- * 128-token segments on the tuned kernels -- MaxSim is a sum over query tokens -- and need room for the partial sums:
+ * 128-token pieces on the tuned kernels -- MaxSim is a sum over query tokens -- and need room for the partial sums:
  * 4096 + n_q * ceil(Lq / 128) * n_d * 4 bytes.
  * Passing NULL is legal and only switches those off (no convoy; long queries take the generic kernels: the same scores up to fp32
  * summation order, 3-4 x slower on a large corpus); a non-NULL workspace must hold at least the number of bytes this function
