@@ -42,7 +42,9 @@ struct StreamArgs {
 constexpr unsigned kFlagRefBf16 = 1u;
 constexpr unsigned kFlagPartial = 2u;     // internal (long queries scored in 128-token pieces): the token sum is a PARTIAL sum, not rounded here
 
-constexpr int kStreamTokBytes = 8 * kUnitTok * 16;   // wave-private per-token max table: 8 units x 16 tokens x 4 lane groups x 4 B = 2 KiB
+constexpr int kStreamMaxUnits = 8;      // (nine / ten units with eight of them in AGPRs, as in K1b's ten-unit form, were tried in round 4:
+                                        // next to the interleaved LDS-DMA issue the slab body does not fit 128 VGPRs and spills into the counted-vmcnt stream)
+constexpr int kStreamTokBytes = kStreamMaxUnits * kUnitTok * 16 + 64;   // wave-private: per-token max table (8 units x 16 tokens x 4 lane groups x 4 B) + 8 token ranges
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -77,10 +79,13 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
     QueryUnit qu[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) load_query_unit(qu[u], Qt, u * kUnitTok, n_tok, lane, true);
-    // this lane's query (8 lanes per query) and its token range in the table
-    const int rq = lane >> 3, ri = lane & 7;
-    const bool r_live = rq < a.n_q;
-    const int r_s = r_live ? flat_qoff(a.fq, rq) : 0, r_e = r_live ? flat_qoff(a.fq, rq + 1) : 0;
+    // 8 lanes per query in the reduction; the queries' token ranges wait in LDS behind the table, written here by the lanes that read
+    // them back (nothing derived from the lane id needs to stay in registers across the slab loop)
+    int *const rtab = reinterpret_cast<int *>(tokmax + kStreamMaxUnits * kUnitTok * 16);
+    if ((lane >> 3) < a.n_q) {
+        rtab[2 * (lane >> 3)] = flat_qoff(a.fq, lane >> 3);
+        rtab[2 * (lane >> 3) + 1] = flat_qoff(a.fq, (lane >> 3) + 1);
+    }
 
     // the query loads are ordinary VMEM loads: retire them before the LDS-DMA stream starts so that the
     // compiler's own vmcnt waits for them never drain the ring later on
@@ -202,13 +207,12 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
             }
 
             const char *src = ring + c_slot * kSlabBytes;
+            c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
             bf16x8 af[2][kKSteps16];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int ks = 0; ks < kKSteps16; ++ks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[g][ks]);
-            c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
-
             slab_units<F16, NU, kTail, true>(m, af, qu, rows_left, lane, [&](int mf) {
                 if constexpr (IL) {                 // one DMA piece per NU MFMAs: 8 per slab (a slab is 8 * NU MFMAs)
                     if (mf % NU == 0) {
@@ -235,8 +239,11 @@ __global__ __launch_bounds__(256, 2) void maxsim_stream_kernel(const uint16_t *_
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) store_token_max(tokmax, u, m[u], lane);
-        if (r_live) {
-            float tot = reduce_query_tokens<F16>(tokmax, r_s, r_e, ri, clamp, ref_bf16);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));            // opaque: no row pointer or table address is hoisted out of the document loop
+        const int rq = ln >> 3, ri = ln & 7;
+        if (rq < a.n_q) {
+            float tot = reduce_query_tokens<F16>(tokmax, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
             if (ref_bf16 && !(a.flags & kFlagPartial)) tot = round_to_input<F16>(tot);
             if (ri == 0) scores[(size_t)rq * a.ld + c_idx] = tot;
         }

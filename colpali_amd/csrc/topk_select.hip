@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kTopkThreads) void topk_segment_kernel(const float 
 
 // Level 0 for LONG rows of raw scores (ids implicit: id_base + column): a streaming threshold filter instead of a full sort.
 // One workgroup owns kTopkFilterSeg = 16 384 consecutive scores of one row (64 KiB, sixteen 16-byte loads per thread, all issued
-// up front) and walks them in rounds of 1024 in column order.  A candidate list in LDS takes every score above the threshold T
+// up front).  Fast path: a threshold from the 256 per-thread maxima, one pass (see the kernel).  Slow path (ties): rounds of 1024 in column order.  A candidate list in LDS takes every score above the threshold T
 // (T = 0 at first: everything); whenever the list holds a round's worth (1024) it is sorted, cut to its best k, and T becomes the
 // k-th key.  From then on a score <= T cannot reach the top k: the list already holds k entries that rank before it -- higher
 // key, or the same key and a SMALLER id, because rounds are taken in column order (which is why a strict `>` is exact for ties).
@@ -112,7 +112,7 @@ constexpr int kTopkFilterCap = 2048;       // candidate list (16 KiB of LDS)
 constexpr int kTopkFilterMaxK = 256;       // k <= cap / 8: a cut always frees at least 7/8 of the list
 
 // bitonic sort of sv[0 .. npow2) in DESCENDING order (npow2 a power of two <= kTopkFilterCap; all threads of the workgroup call it)
-__device__ __forceinline__ void topk_sort_desc(uint64_t *sv, int npow2, int tid) {
+__device__ __noinline__ void topk_sort_desc(uint64_t *sv, int npow2, int tid) {
     for (int size = 2; size <= npow2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
@@ -144,51 +144,86 @@ __global__ __launch_bounds__(kTopkThreads) void topk_filter_kernel(const float *
     const float *srow = scores + row * ld + base;
     constexpr int kRounds = kTopkFilterSeg / kTopkFilterRound;
 
-    // all of this thread's scores, requested before anything is looked at (a row start need not be 16-byte aligned: 4-byte loads then)
-    float v[kRounds][4];
+    // all of this thread's scores, requested before anything is looked at (a row start need not be 16-byte aligned: 4-byte loads
+    // then), turned into order-preserving keys in place; columns past the row's end get key 0 (below every real score)
+    uint32_t key[kRounds][4];
     const bool aligned = ((reinterpret_cast<uintptr_t>(srow) & 15) == 0);
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         const int c0 = r * kTopkFilterRound + tid * 4;
+        float v[4];
         if (aligned && c0 + 3 < cnt) {
             const float4 q = *reinterpret_cast<const float4 *>(srow + c0);
-            v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w;
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[r][j] = c0 + j < cnt ? srow[c0 + j] : 0.0f;
+            for (int j = 0; j < 4; ++j) v[j] = c0 + j < cnt ? srow[c0 + j] : 0.0f;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) key[r][j] = c0 + j < cnt ? score_key(v[j]) : 0u;
     }
+
+    // ---- fast path.  The k-th largest of the 256 per-thread maxima is a lower bound T0 of the row segment's k-th best key (k threads
+    // hold a key >= T0 each), and on score rows as the scorer produces them the best k sit in k different threads, so T0 IS the k-th
+    // best: one pass over the registers leaves k .. a few dozen candidates (every key >= T0: ties kept, the sort decides them by id).
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = key[r][j] > mx ? key[r][j] : mx;
+    cand[tid] = (uint64_t)mx << 32;
     if (tid == 0) n_cand = 0;
-    uint32_t thr = 0u;                       // keys above it enter the list (0 is below every real score's key)
+    topk_sort_desc(cand, kTopkThreads, tid);                 // (starts and ends with a barrier)
+    const uint32_t t0 = (uint32_t)(cand[(k < kTopkThreads ? k : kTopkThreads) - 1] >> 32);
     __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < kRounds; ++r) {
-        if (r * kTopkFilterRound >= cnt) break;                          // (uniform)
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = r * kTopkFilterRound + tid * 4 + j;
-            const uint32_t key = c < cnt ? score_key(v[r][j]) : 0u;
-            if (key > thr) {
+            const uint32_t ky = key[r][j];
+            if (ky >= t0 && ky != 0u) {
                 const int slot = atomicAdd(&n_cand, 1);
-                cand[slot] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)c);
+                if (slot < kTopkFilterCap) cand[slot] = ((uint64_t)ky << 32) | (uint32_t)(~(uint32_t)(r * kTopkFilterRound + tid * 4 + j));
             }
         }
+    __syncthreads();
+    int have = n_cand;
+    __syncthreads();
+    if (have > kTopkFilterCap) {
+        // ---- slow path (massive ties at the threshold, e.g. a constant row): rounds of 1024 in column order.  The list takes every key
+        // above a threshold T (0 at first); whenever it holds a round's worth it is sorted, cut to its best k, and T becomes the k-th
+        // key: a later score <= T cannot reach the top k, the list already holds k entries that rank before it -- a higher key, or the
+        // same key and a SMALLER id, because rounds are taken in column order (which is why the strict `>` is exact for ties).
+        if (tid == 0) n_cand = 0;
+        uint32_t thr = 0u;
         __syncthreads();
-        const int have = n_cand;                                         // (uniform after the barrier)
-        __syncthreads();                                                 // ... and read by everyone before the next round adds to it
-        const bool more = (r + 1) * kTopkFilterRound < cnt;
-        if (more && have >= kTopkFilterRound) {                          // cut the list to its best k: the next round (<= 1024 more) always fits
-                                                                         // the 2048 slots, and a 1024-entry sort is the cheapest first cut
-            int npow2 = 64;
-            while (npow2 < have) npow2 <<= 1;
-            for (int i = have + tid; i < npow2; i += kTopkThreads) cand[i] = 0ull;
-            topk_sort_desc(cand, npow2, tid);
-            if (have >= k) thr = (uint32_t)(cand[k - 1] >> 32);
-            if (tid == 0) n_cand = have < k ? have : k;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            if (r * kTopkFilterRound >= cnt) break;                          // (uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (key[r][j] > thr) {
+                    const int slot = atomicAdd(&n_cand, 1);
+                    cand[slot] = ((uint64_t)key[r][j] << 32) | (uint32_t)(~(uint32_t)(r * kTopkFilterRound + tid * 4 + j));
+                }
+            }
             __syncthreads();
+            const int cur = n_cand;                                          // (uniform after the barrier)
+            __syncthreads();                                                 // ... and read by everyone before the next round adds to it
+            const bool more = (r + 1) * kTopkFilterRound < cnt;
+            if (more && cur >= kTopkFilterRound) {                           // cut: the next round (<= 1024 more) always fits the 2048 slots
+                int np = 64;
+                while (np < cur) np <<= 1;
+                for (int i = cur + tid; i < np; i += kTopkThreads) cand[i] = 0ull;
+                topk_sort_desc(cand, np, tid);
+                if (cur >= k) thr = (uint32_t)(cand[k - 1] >> 32);
+                if (tid == 0) n_cand = cur < k ? cur : k;
+                __syncthreads();
+            }
         }
+        have = n_cand;
+        __syncthreads();
     }
-    const int have = n_cand;
     int npow2 = 64;
     while (npow2 < have) npow2 <<= 1;
     for (int i = have + tid; i < npow2; i += kTopkThreads) cand[i] = 0ull;
@@ -198,9 +233,9 @@ __global__ __launch_bounds__(kTopkThreads) void topk_filter_kernel(const float *
     int64_t *oi = out_ids + row * out_ld + (long long)blockIdx.x * k;
     for (int j = tid; j < k; j += kTopkThreads) {
         const uint64_t e = j < have ? cand[j] : 0ull;
-        const uint32_t key = (uint32_t)(e >> 32);
-        const bool valid = key != 0u;
-        os[j] = valid ? key_score(key) : -INFINITY;
+        const uint32_t ky = (uint32_t)(e >> 32);
+        const bool valid = ky != 0u;
+        os[j] = valid ? key_score(ky) : -INFINITY;
         oi[j] = valid ? (int64_t)(id_base + base + (long long)(uint32_t)(~(uint32_t)e)) : -1;
     }
 }
