@@ -310,6 +310,52 @@ def test_bench_self_launch_builds_one_rank_per_gpu_on_the_loopback():
         assert n == len(lens) and min(lens) >= 1
 
 
+def test_native_host_packing_drops_exactly_the_all_zero_rows():
+    """msim_host_count_nonzero_rows / msim_host_gather_nonzero_rows (the host side of the flat query layout: include/maxsim.h): rows
+    whose bytes are all zero are dropped, everything else -- a row with one non-zero element, with -0.0 -- keeps its order."""
+    import numpy as np
+
+    L = colpali_amd._lib.lib()
+    g = torch.Generator().manual_seed(1)
+    qs = [torch.randn(n, 128, generator=g).to(torch.bfloat16) for n in (5, 0, 9, 3)]
+    qs[0][1] = 0
+    qs[0][4] = 0
+    qs[2][:4] = 0                       # left padding
+    qs[2][6, 17] = 0                    # one zero element does not make a zero row
+    qs[3][:] = 0
+    qs[3][2, 0] = -0.0                  # -0.0 has a non-zero byte: kept (dropping it would be just as exact; the test pins the rule)
+    keep = [q.contiguous() for q in qs]
+    srcs = np.asarray([q.data_ptr() if q.numel() else 0 for q in keep], dtype=np.uint64)
+    rows = np.asarray([q.shape[0] for q in keep], dtype=np.int64)
+    counts = np.zeros(len(keep), dtype=np.int32)
+    assert L.msim_host_count_nonzero_rows(srcs.ctypes.data, rows.ctypes.data, 256, len(keep), counts.ctypes.data, 3) == 0
+    want_rows = [[0, 2, 3], [], [4, 5, 6, 7, 8], [2]]
+    assert counts.tolist() == [len(w) for w in want_rows]
+    off = np.zeros(len(keep) + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    dst = torch.full((int(off[-1]) + 1, 128), 7.0).to(torch.bfloat16)
+    assert L.msim_host_gather_nonzero_rows(dst.data_ptr(), srcs.ctypes.data, rows.ctypes.data, 256, off[:-1].copy().ctypes.data,
+                                           len(keep), 2) == 0
+    want = torch.cat([q[w] for q, w in zip(keep, want_rows) if w])
+    assert torch.equal(dst[:-1].view(torch.int16), want.view(torch.int16)) and bool((dst[-1] == 7.0).all())
+    assert L.msim_host_count_nonzero_rows(srcs.ctypes.data, rows.ctypes.data, 0, len(keep), counts.ctypes.data, 1) == -1
+    assert L.msim_host_count_nonzero_rows(None, rows.ctypes.data, 256, len(keep), counts.ctypes.data, 1) == -1
+
+
+def test_flat_plan_errors_and_limits_without_a_gpu():
+    """msim_fwd_ragged validates on the host before any device work: unsupported shapes, broken offsets."""
+    import numpy as np
+
+    L = colpali_amd._lib.lib()
+    off = np.asarray([0, 12, 52], dtype=np.int32)
+    args = lambda dtype=0, dim=128, o=off, n_q=2: (dtype, 16, 16, o.ctypes.data, n_q, 16, 16, None, 5, dim, 16, 5, 0, None, None)  # noqa: E731
+    assert L.msim_fwd_ragged(*args(dtype=2)) == -2 and L.msim_fwd_ragged(*args(dim=64)) == -2
+    assert L.msim_fwd_ragged(*args(o=np.asarray([1, 12, 52], dtype=np.int32))) == -1
+    assert L.msim_fwd_ragged(*args(o=np.asarray([0, 12, 5], dtype=np.int32))) == -1
+    assert L.msim_fwd_ragged(*args(n_q=0)) == 0                                    # empty problem: a no-op
+    assert L.msim_fwd_ragged_workspace_bytes(0, off.ctypes.data, 2, 5, 128) == 0   # K1s: no scratch
+
+
 def test_loss_offset_and_pair_checks_run_before_any_device_work():
     from colpali_amd import loss as Lm
 
