@@ -58,3 +58,22 @@ def text_batch(B=5, S=37, seed=2, left_pad=False, device="cpu"):
         mask[1, S - S // 5:] = 0
         mask[B - 1, S // 3:] = 0
     return dict(input_ids=ids.to(device), attention_mask=mask.to(device))
+
+
+def colqwen2_page_batch(model, B=3, h=4, w=4, n_text=6, seed=3, device="cpu"):
+    """ColQwen2-style inputs WITH an image, as ColQwen2Processor hands them over: `pixel_values` padded per image beyond its h x w
+    patches (the forward un-pads with image_grid_thw, modeling_colqwen2.py:50-56), h*w/4 image tokens between the vision markers,
+    left padding, mm_token_type_ids (1 = image token: transformers' M-RoPE needs it)."""
+    cfg = model.config
+    g = torch.Generator().manual_seed(seed)
+    n_img = h * w // 4
+    S = 2 + n_img + n_text + 2
+    ids = torch.randint(0, 290, (B, S), generator=g)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, :2] = 0                                  # left padding in front of the vision block
+    ids[:, 2] = cfg.vision_start_token_id
+    ids[:, 3:3 + n_img] = cfg.image_token_id
+    ids[:, 3 + n_img] = cfg.vision_end_token_id
+    pix = torch.randn(B, h * w + 5, 3 * 2 * 14 * 14, generator=g)
+    return dict(input_ids=ids.to(device), attention_mask=mask.to(device), pixel_values=pix.to(device),
+                image_grid_thw=torch.tensor([[1, h, w]] * B, device=device), mm_token_type_ids=(ids == cfg.image_token_id).int().to(device))

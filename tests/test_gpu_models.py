@@ -20,7 +20,7 @@ try:
 except RuntimeError:
     pytest.skip("no reference model files (tests/_reference_pkg/ is fetched by __graft_entry__.build())", allow_module_level=True)
 
-from tests.model_fixtures import colpali_page_batch, text_batch, tiny_colpali, tiny_colqwen2  # noqa: E402
+from tests.model_fixtures import colpali_page_batch, colqwen2_page_batch, text_batch, tiny_colpali, tiny_colqwen2  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -82,6 +82,28 @@ def test_patched_colpali_with_an_image_and_the_image_token_mask(patched, mask_no
     assert ok and same > 0.9, same
     if mask_non_image:
         assert bool((got[:, 4:] == 0).all()) and bool((got[:, :4].float().norm(dim=-1) > 0.9).all())
+
+
+@pytest.mark.parametrize("mask_non_image", [False, True])
+def test_patched_colqwen2_with_an_image(patched, mask_non_image):
+    """ColQwen2.forward's own preamble (un-padding `pixel_values` with image_grid_thw, modeling_colqwen2.py:50-56) and the Qwen2-VL
+    backbone run unchanged in front of the fused head; `mask_non_image_embeddings` uses this family's `config.image_token_id`."""
+    model, cls = tiny_colqwen2()
+    model.mask_non_image_embeddings = mask_non_image
+    model = model.to(DEV, torch.bfloat16)
+    batch = colqwen2_page_batch(model, device=DEV)
+    batch["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
+    with torch.no_grad():
+        want = model(**{k: (v.clone() if k == "pixel_values" else v) for k, v in batch.items()})
+    colpali_amd.patch_colpali_engine(scorer=False, losses=False, models=True)
+    assert cls in M.installed()
+    with torch.no_grad():
+        got = model(**batch)
+    ok, same = one_ulp_close(got, want, torch.bfloat16)
+    assert ok and same > 0.9, same
+    if mask_non_image:
+        img = batch["input_ids"] == model.config.image_token_id
+        assert bool((got[~img] == 0).all()) and bool((got[img].float().norm(dim=-1) > 0.9).all())
 
 
 def test_patched_forward_is_differentiable_like_the_reference(patched):

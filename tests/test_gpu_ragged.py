@@ -99,6 +99,19 @@ def test_ragged_thousand_queries_many_blocks(amd):
     assert close(got, oracle(qs, ps, batch_size=128))
 
 
+def test_more_query_blocks_than_one_launch_carries(amd):
+    """The block table travels in the kernel arguments, 256 blocks per launch: 17 000 one-token queries are 266 blocks (64 queries each,
+    the reduction's limit), i.e. two launches writing disjoint score rows."""
+    g = torch.Generator().manual_seed(41)
+    tok = unit_rows(17000, g)
+    qs = list(tok.split(1))
+    ps = docs(g, 40, 1, 70)
+    got = amd.maxsim_scores(amd.pack_queries(qs, DEV), amd.pack_passages(ps, DEV, batch_size=None)).cpu().numpy()
+    # one-token queries: the score is the best dot product with any row of the document
+    want = np.stack([(tok.float() @ p.float().T).max(dim=1).values.numpy() for p in ps], axis=1)
+    assert got.shape == (17000, 40) and close(got, want)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_zero_rows_are_dropped_and_change_no_score(amd, dtype):
     """The model's padded positions are zero rows (modeling_colpali.py:72 right-padded, modeling_colqwen2.py:69 left-padded).  The flat
