@@ -25,6 +25,7 @@ attention_mask keyword.
 """
 from __future__ import annotations
 
+import threading
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -69,8 +70,11 @@ def _wrap(orig_forward: Callable) -> Callable:
             return orig_forward(self, *args, **kwargs)
         taken = []
         mask = kwargs["attention_mask"]
+        me = threading.get_ident()
 
         def take(_module, inputs):
+            if threading.get_ident() != me:      # another thread's forward through the same module: not this call's hidden states
+                return
             hidden = inputs[0]
             if hidden.dim() == 3 and hidden.dtype == lin.weight.dtype and hidden.shape[:2] == mask.shape:
                 taken.append(hidden)
