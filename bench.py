@@ -79,6 +79,54 @@ def make_shard(n_docs, doc_len, device, seed):
     return PackedCorpus(blob=blob, offsets=offsets, clamp0=None, lengths=lengths)
 
 
+def make_ragged_shard(n_docs, lo, hi, device, seed):
+    """BASELINE config 3's page geometry on the resident path: ColQwen2 pages of U{lo..hi} patch rows each (dynamic resolution), unit-norm
+    bf16 rows generated on the device."""
+    from colpali_amd.corpus import PackedCorpus
+
+    gl = torch.Generator().manual_seed(seed)
+    lengths = torch.randint(lo, hi + 1, (n_docs,), generator=gl)
+    offsets = torch.zeros(n_docs + 1, dtype=torch.int64)
+    torch.cumsum(lengths, 0, out=offsets[1:])
+    rows = int(offsets[-1])
+    g = torch.Generator(device=device).manual_seed(seed)
+    blob = torch.empty((rows, 128), dtype=torch.bfloat16, device=device)
+    step = 1 << 19
+    for r0 in range(0, rows, step):
+        n = min(step, rows - r0)
+        x = torch.randn((n, 128), generator=g, device=device, dtype=torch.float32)
+        blob[r0:r0 + n] = torch.nn.functional.normalize(x, dim=-1).to(torch.bfloat16)
+    return PackedCorpus(blob=blob, offsets=offsets.to(torch.int32).to(device), clamp0=None, lengths=lengths.to(torch.int64))
+
+
+def ragged_docs_numbers(amd, dev, topk):
+    """The resident path on BASELINE config 3's page geometry (ColQwen2: 267..779 patch rows per page, here 60 000 pages = 8 GiB): the
+    HBM-bound and the MFMA-bound regime with ragged documents AND ragged queries.  Context (the headline shard is config 4's 1024-row pages)."""
+    corpus = make_ragged_shard(60000, 267, 779, dev, seed=77)
+    rows = int(corpus.blob.shape[0])
+    out = {"workload": f"60000 pages x U{{267..779}} rows ({rows} rows, {rows * 256 / 2**30:.1f} GiB resident)"}
+    for name, lens in (("4_queries_x_32", [32] * 4), ("4_queries_ragged_12_48", parse_regime("4xr12-48", 32)[1]),
+                       ("1000_queries_ragged_12_48", parse_regime("1000xr12-48", 32)[1])):
+        q = amd.pack_queries(make_query_list(lens, seed=sum(lens)), dev)
+        scores = torch.empty((len(lens), len(corpus)), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            amd.maxsim_scores(q, corpus, out=scores)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in evs:
+            a.record(); amd.maxsim_scores(q, corpus, out=scores); b.record()
+        amd.topk(scores, topk)
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[2]
+        alg = rows * 256 + sum(lens) * 256 + len(lens) * len(corpus) * 4
+        flops = 2.0 * sum(lens) * rows * 128
+        gbs, tf = alg / ms / 1e6, flops / ms / 1e9
+        bound = "hbm" if alg / HBM_PEAK_GBS / 1e9 >= flops / MFMA_PEAK_TFLOPS / 1e12 else "mfma"
+        out[name] = {"kernel_ms": ms, "pairs_per_s": len(lens) * len(corpus) / ms * 1e3, "hbm_gbs": gbs, "mfma_tflops": tf, "bound": bound,
+                     "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS, "q_tokens": sum(lens)}
+    del corpus
+    return out
+
+
 def make_queries(n_q, q_len, device, seed):
     g = torch.Generator().manual_seed(seed)
     q = torch.nn.functional.normalize(torch.randn(n_q, q_len, 128, generator=g), dim=-1).to(torch.bfloat16)
@@ -941,6 +989,7 @@ def main():
         out["embed_head"] = embed_head_numbers(amd, dev)
         out["dropin_from_host_lists"] = dropin_numbers(amd)
         out["embed_and_score_1k_pages"] = embed_and_score_numbers(amd, dev)
+        out["resident_colqwen2_page_geometry"] = ragged_docs_numbers(amd, dev, args.topk)
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
