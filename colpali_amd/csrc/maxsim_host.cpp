@@ -8,10 +8,12 @@
 // row) in k order, max over rows, token sum in fp32 -- the "truth tier" of the GPU kernels (scores within 1e-5 of a float64 evaluation).
 // MSIM_FLAG_REF_ROUNDING reproduces the reference's 16-bit rounding like the kernels do.
 //
-// Shape of the computation: a document is taken 16 rows at a time, widened to fp32 and transposed to k-major (Dt[k][16 rows], 8 KiB for
-// dim 128: L1-resident); a block of 8 query tokens then runs acc[token][16 rows] += q[token][k] * Dt[k][:] -- per k one vector load and
-// 8 broadcast-FMAs, no horizontal operation until the document ends.  Written on the compiler's generic vector type and cloned for
-// AVX-512 / AVX2 / baseline x86-64 (resolved at load time); documents are dealt to std::threads in contiguous chunks.
+// Shape of the computation: the QUERIES are re-laid once per call -- blocks of whole queries of ~256 tokens, the tokens in the lanes of
+// 16-float vectors, k-major -- so that the streaming side, the documents, needs no transposition: eight rows are widened to fp32 with
+// contiguous loops and every (row, 16 tokens) runs acc += d[row][k] * Qt[k][:], a broadcast-FMA; the max over rows is an element-wise
+// vector max, and nothing horizontal happens until a query's tokens are summed, once per (query, document).  Written on the compiler's
+// generic vector type and cloned for AVX-512 / AVX2 / baseline x86-64 (resolved at load time); documents are dealt to a persistent pool
+// of native threads in contiguous chunks.
 #include <pthread.h>
 
 #include <atomic>
@@ -103,12 +105,15 @@ inline float widen(const void *base, int dtype, size_t idx) {
     }
 }
 
+// one call, both sides as lists of row blocks: query q = q_len[q] rows at q_ptr[q], document c = d_len[c] rows at d_ptr[c] (the packed
+// entry point fills the lists from its box / blob; the list entry point passes the caller's tensors through: nothing is copied)
 struct HostCall {
     int dtype;
-    const void *Q;
-    int n_q, Lq;
-    const void *D;
-    const int32_t *d_off;
+    const void *const *q_ptr;
+    const int64_t *q_len;
+    int n_q;
+    const void *const *d_ptr;
+    const int64_t *d_len;
     const uint8_t *clamp0;
     int n_d, dim;
     float *scores;
@@ -116,79 +121,90 @@ struct HostCall {
     bool ref_round;
 };
 
-constexpr int kTok = 8;       // query tokens per register block
-constexpr int kRows = 16;     // document rows per vector
+constexpr int kTok = 8;       // (msim_sim_matrix_host) A rows per register block
+constexpr int kRows = 16;     // (msim_sim_matrix_host) B rows per vector
+constexpr int kLanes = 16;    // query tokens per vector
+constexpr int kGroup = 8;     // document rows per register block
 
-// documents [c_lo, c_hi): `qf` = all queries widened to fp32 [n_q * Lq, dim], `dt` = scratch for one 16-row group (dim * 16 floats),
-// `tmax` = scratch [n_q * Lq] running maxima of the current document
+// One block of whole queries: its tokens sit in the LANES of 16-float vectors, k-major (Qt[(tv * dim + k) * 16 + lane] = token
+// 16 tv + lane, component k; lanes past the block's last token are zero) -- built once per call.  A document row then needs no
+// transposition at all: acc[row][16 tokens] += d[row][k] (a scalar, broadcast) * Qt[k][16 tokens], eight rows per register block,
+// and the max over rows is an element-wise vector max: no horizontal operation until a query's tokens are summed, once per
+// (query, document).  Rows are widened to fp32 eight at a time with contiguous, vectorisable loops.
+struct QueryBlock {
+    int q0, nq;          // queries of the block
+    int n_tv;            // token vectors
+    size_t qt_off;       // offset of the block's Qt in floats
+};
+
+// documents [c_lo, c_hi) against every query block: `df` = scratch for 8 widened rows (8 * dim floats), `tmaxv` = scratch for the block's
+// running maxima (n_tv vectors); `tok0[q]` = first token of query q inside its block.  A block's operands are ~128 KiB (256 tokens at
+// dim 128: L2-resident) and the block walks all the documents of the range before the next one starts.
 __attribute__((target_clones("avx512f", "avx2,fma", "default")))
-void score_range(const HostCall &c, const float *qf, float *dt, float *tmax, int c_lo, int c_hi) {
+void score_range(const HostCall &c, const float *qt, const QueryBlock *blocks, int n_blocks, const int *tok0, float *df, v16f *tmaxv,
+                 int c_lo, int c_hi) {
     const int dim = c.dim;
     const float ninf = -std::numeric_limits<float>::infinity();
-    // Queries are taken in blocks of whole queries of about 256 tokens (128 KiB of fp32 operands at dim 128: L2-resident) and every
-    // block walks ALL documents of the range before the next one starts: with the token loop innermost over the whole batch, a
-    // 1000-query batch streamed 16 MB of query operands from the last-level cache for every 16-row group (measured on the 128-thread GPU host:
-    // 5 GFLOP/s per thread, against 90 with the operands in L2).  The 16-row group is widened again per block -- 2048 conversions
-    // against 0.5 M multiply-adds.
-    const int q_per_blk = c.Lq > 0 ? (256 / c.Lq > 0 ? 256 / c.Lq : 1) : c.n_q;
-    for (int q0 = 0; q0 < c.n_q; q0 += q_per_blk) {
-        const int nq = c.n_q - q0 < q_per_blk ? c.n_q - q0 : q_per_blk;
-        const int n_tok = nq * c.Lq;
-        const float *qblk = qf + (size_t)q0 * c.Lq * dim;
+    for (int b = 0; b < n_blocks; ++b) {
+        const QueryBlock &qb = blocks[b];
+        const float *qtb = qt + qb.qt_off;
         for (int doc = c_lo; doc < c_hi; ++doc) {
-            const int r0 = c.d_off[doc], len = c.d_off[doc + 1] - r0;
-            for (int t = 0; t < n_tok; ++t) tmax[t] = ninf;
-            for (int g = 0; g < len; g += kRows) {
-                const int valid = len - g < kRows ? len - g : kRows;
-                // widen + transpose this group: dt[k * 16 + r] = D[r0 + g + r][k]; rows that do not exist are zero here and masked below
-                for (int r = 0; r < kRows; ++r) {
-                    if (r < valid) {
-                        const size_t base = (size_t)(r0 + g + r) * dim;
-                        for (int k = 0; k < dim; ++k) dt[k * kRows + r] = widen(c.D, c.dtype, base + k);
+            const int len = (int)c.d_len[doc];
+            for (int tv = 0; tv < qb.n_tv; ++tv)
+                for (int l = 0; l < kLanes; ++l) tmaxv[tv][l] = ninf;
+            for (int g = 0; g < len; g += kGroup) {
+                const int nr = len - g < kGroup ? len - g : kGroup;
+                for (int r = 0; r < nr; ++r) {                       // widen: contiguous in, contiguous out
+                    const size_t base = (size_t)(g + r) * dim;
+                    float *o = df + (size_t)r * dim;
+                    if (c.dtype == MSIM_DTYPE_BF16) {
+                        const uint16_t *p = static_cast<const uint16_t *>(c.d_ptr[doc]) + base;
+                        for (int k = 0; k < dim; ++k) o[k] = bf16_to_f32(p[k]);
+                    } else if (c.dtype == MSIM_DTYPE_F16) {
+                        const uint16_t *p = static_cast<const uint16_t *>(c.d_ptr[doc]) + base;
+                        for (int k = 0; k < dim; ++k) o[k] = f16_to_f32(p[k]);
                     } else {
-                        for (int k = 0; k < dim; ++k) dt[k * kRows + r] = 0.0f;
+                        memcpy(o, static_cast<const float *>(c.d_ptr[doc]) + base, (size_t)dim * sizeof(float));
                     }
                 }
-                v16f lane_mask;                       // 0 for real rows, -inf for the others (added after the products: x + 0 = x)
-                for (int r = 0; r < kRows; ++r) lane_mask[r] = r < valid ? 0.0f : ninf;
-                for (int t0 = 0; t0 < n_tok; t0 += kTok) {
-                    const int nt = n_tok - t0 < kTok ? n_tok - t0 : kTok;
-                    v16f acc[kTok];
-                    for (int i = 0; i < kTok; ++i) acc[i] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    const float *q = qblk + (size_t)t0 * dim;
-                    if (nt == kTok) {
+                for (int tv = 0; tv < qb.n_tv; ++tv) {
+                    const float *qp = qtb + (size_t)tv * dim * kLanes;
+                    v16f acc[kGroup];
+                    for (int r = 0; r < kGroup; ++r) acc[r] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    if (nr == kGroup) {
                         for (int k = 0; k < dim; ++k) {
-                            const v16f d = *reinterpret_cast<const v16f *>(dt + k * kRows);
-                            for (int i = 0; i < kTok; ++i) acc[i] += q[(size_t)i * dim + k] * d;
+                            const v16f qv = *reinterpret_cast<const v16f *>(qp + (size_t)k * kLanes);
+                            for (int r = 0; r < kGroup; ++r) acc[r] += df[(size_t)r * dim + k] * qv;
                         }
                     } else {
                         for (int k = 0; k < dim; ++k) {
-                            const v16f d = *reinterpret_cast<const v16f *>(dt + k * kRows);
-                            for (int i = 0; i < nt; ++i) acc[i] += q[(size_t)i * dim + k] * d;
+                            const v16f qv = *reinterpret_cast<const v16f *>(qp + (size_t)k * kLanes);
+                            for (int r = 0; r < nr; ++r) acc[r] += df[(size_t)r * dim + k] * qv;
                         }
                     }
-                    for (int i = 0; i < nt; ++i) {
-                        v16f a = acc[i];
-                        if (c.ref_round) {             // the reference's 16-bit einsum rounds every similarity before the max
-                            for (int r = 0; r < kRows; ++r) a[r] = c.dtype == MSIM_DTYPE_F16 ? round_f16(a[r]) : round_bf16(a[r]);
-                        }
-                        a += lane_mask;
-                        float m = tmax[t0 + i];
-                        for (int r = 0; r < kRows; ++r) m = a[r] > m ? a[r] : m;
-                        tmax[t0 + i] = m;
+                    v16f m = tmaxv[tv];
+                    for (int r = 0; r < nr; ++r) {
+                        v16f a = acc[r];
+                        if (c.ref_round)               // the reference's 16-bit einsum rounds every similarity before the max
+                            for (int l = 0; l < kLanes; ++l) a[l] = c.dtype == MSIM_DTYPE_F16 ? round_f16(a[l]) : round_bf16(a[l]);
+                        m = a > m ? a : m;
                     }
+                    tmaxv[tv] = m;
                 }
             }
             const bool clamp = c.clamp0 != nullptr && c.clamp0[doc] != 0;
-            for (int qi = 0; qi < nq; ++qi) {
+            const float *tm = reinterpret_cast<const float *>(tmaxv);
+            for (int qi = 0; qi < qb.nq; ++qi) {
+                const int q = qb.q0 + qi;
+                const int t0 = tok0[q], t1 = t0 + (int)c.q_len[q];
                 float tot = 0.0f;
-                for (int i = 0; i < c.Lq; ++i) {
-                    float m = tmax[qi * c.Lq + i];
+                for (int t = t0; t < t1; ++t) {
+                    float m = tm[t];
                     if (clamp && !(m > 0.0f)) m = m != m ? m : 0.0f;      // max(m, 0), NaN kept
                     tot += m;
                 }
                 if (c.ref_round) tot = c.dtype == MSIM_DTYPE_F16 ? round_f16(tot) : round_bf16(tot);
-                c.scores[(size_t)(q0 + qi) * c.ld + doc] = tot;
+                c.scores[(size_t)q * c.ld + doc] = tot;
             }
         }
     }
@@ -330,28 +346,53 @@ extern "C" {
 
 const char *msim_host_last_error(void) { return g_host_err; }
 
-int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0, int n_d,
-                  int dim, float *scores, int64_t ld_scores, uint32_t flags, int n_threads) {
-    auto fail = [](int code, const char *msg) {
-        strncpy(g_host_err, msg, sizeof(g_host_err) - 1);
-        return code;
-    };
-    if (n_q < 0 || n_d < 0 || Lq < 0 || dim <= 0) return fail(MSIM_EINVAL, "negative size");
-    if (n_q == 0 || n_d == 0) return MSIM_OK;
-    if (!Q || !D || !d_off || !scores) return fail(MSIM_EINVAL, "null pointer argument");
-    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16 && dtype != MSIM_DTYPE_F32)
-        return fail(MSIM_EUNSUPPORTED, "msim_fwd_host takes bfloat16 (0), float16 (1) or float32 (2) embeddings");
-    if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores < n_d");
-    if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags");
-    if ((flags & MSIM_FLAG_REF_ROUNDING) && dtype == MSIM_DTYPE_F32) flags &= ~MSIM_FLAG_REF_ROUNDING;   // fp32 inputs: nothing is rounded
-    HostCall c{dtype, Q, n_q, Lq, D, d_off, d_clamp0, n_d, dim, scores, ld_scores, (flags & MSIM_FLAG_REF_ROUNDING) != 0};
-    const size_t n_tok = (size_t)n_q * Lq;
-    std::vector<float> qf(n_tok * dim + 16);
-    for (size_t i = 0; i < n_tok * dim; ++i) qf[i] = widen(Q, dtype, i);
+}  // extern "C"
+
+namespace {
+
+int fail_host(int code, const char *msg) {
+    strncpy(g_host_err, msg, sizeof(g_host_err) - 1);
+    return code;
+}
+
+int fwd_host_lists(const HostCall &c, int n_threads) {
+    const int n_q = c.n_q, n_d = c.n_d, dim = c.dim;
+    // ---- the queries, once: blocks of whole queries of about 256 tokens, tokens in vector lanes, k-major
+    std::vector<QueryBlock> blocks;
+    std::vector<int> tok0(n_q);
+    size_t qt_floats = 0;
+    int max_tv = 1;
+    long long total_tok = 0;
+    for (int q0 = 0; q0 < n_q;) {
+        int nq = 0, ntok = 0;
+        while (q0 + nq < n_q && (nq == 0 || ntok + c.q_len[q0 + nq] <= 256)) {
+            tok0[q0 + nq] = ntok;
+            ntok += (int)c.q_len[q0 + nq];
+            ++nq;
+        }
+        const int n_tv = (ntok + kLanes - 1) / kLanes;
+        blocks.push_back(QueryBlock{q0, nq, n_tv, qt_floats});
+        qt_floats += (size_t)n_tv * dim * kLanes;
+        if (n_tv > max_tv) max_tv = n_tv;
+        total_tok += ntok;
+        q0 += nq;
+    }
+    std::vector<float> qt_store(qt_floats + 16, 0.0f);
+    float *qt = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(qt_store.data()) + 63) & ~(uintptr_t)63);
+    for (const QueryBlock &qb : blocks)
+        for (int qi = 0; qi < qb.nq; ++qi) {
+            const int q = qb.q0 + qi;
+            for (int i = 0; i < (int)c.q_len[q]; ++i) {
+                const int t = tok0[q] + i;
+                float *o = qt + qb.qt_off + (size_t)(t / kLanes) * dim * kLanes + (t % kLanes);
+                for (int k = 0; k < dim; ++k) o[(size_t)k * kLanes] = widen(c.q_ptr[q], c.dtype, (size_t)i * dim + k);
+            }
+        }
+    int64_t rows = 0;
+    for (int d = 0; d < n_d; ++d) rows += c.d_len[d];
     int nt = n_threads < 1 ? 1 : (n_threads > 256 ? 256 : n_threads);
-    const int64_t rows = d_off[n_d] - d_off[0];
-    const double work = (double)rows * (double)n_tok * dim;            // multiply-adds
-    const int by_work = (int)(work / 4e6) + 1;                          // a thread is worth starting for a few million of them
+    const double work = (double)rows * (double)total_tok * dim;         // multiply-adds
+    const int by_work = (int)(work / 4e6) + 1;                          // a thread is worth waking for a few million of them
     if (nt > by_work) nt = by_work;
     if (nt > n_d) nt = n_d;
     // contiguous chunks of documents with about the same number of rows each, a few per thread (dynamic assignment evens out
@@ -362,7 +403,7 @@ int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, cons
         const int64_t per = (rows + n_chunks - 1) / n_chunks;
         int64_t acc = 0;
         for (int d = 0; d < n_d; ++d) {
-            acc += d_off[d + 1] - d_off[d];
+            acc += c.d_len[d];
             if ((acc >= per && (int)cut.size() < n_chunks) || d + 1 == n_d) {
                 cut.push_back(d + 1);
                 acc = 0;
@@ -370,16 +411,65 @@ int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, cons
         }
     }
     const std::function<void(int)> body = [&](int chunk) {
-        thread_local std::vector<float> dt, tmax;
-        if (dt.size() < (size_t)dim * kRows + 16) dt.resize((size_t)dim * kRows + 16);
-        if (tmax.size() < n_tok + 16) tmax.resize(n_tok + 16);
-        float *dta = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(dt.data()) + 63) & ~(uintptr_t)63);
-        score_range(c, qf.data(), dta, tmax.data(), cut[chunk], cut[chunk + 1]);
+        thread_local std::vector<float> scratch;
+        const size_t need = (size_t)kGroup * dim + (size_t)max_tv * kLanes + 64;
+        if (scratch.size() < need) scratch.resize(need);
+        float *al = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(scratch.data()) + 63) & ~(uintptr_t)63);
+        v16f *tmaxv = reinterpret_cast<v16f *>(al);
+        float *df = al + (size_t)max_tv * kLanes;
+        score_range(c, qt, blocks.data(), (int)blocks.size(), tok0.data(), df, tmaxv, cut[chunk], cut[chunk + 1]);
     };
     HostPool::get().run((int)cut.size() - 1, nt, body);
     return MSIM_OK;
 }
 
+int check_host(int dtype, int n_q, int n_d, int dim, const float *scores, int64_t ld_scores, uint32_t flags) {
+    if (n_q < 0 || n_d < 0 || dim <= 0) return fail_host(MSIM_EINVAL, "negative size");
+    if (dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16 && dtype != MSIM_DTYPE_F32)
+        return fail_host(MSIM_EUNSUPPORTED, "the host scorer takes bfloat16 (0), float16 (1) or float32 (2) embeddings");
+    if (n_q > 0 && n_d > 0 && !scores) return fail_host(MSIM_EINVAL, "null pointer argument");
+    if (ld_scores < n_d) return fail_host(MSIM_EINVAL, "ld_scores < n_d");
+    if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail_host(MSIM_EINVAL, "unknown flags");
+    return MSIM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0, int n_d,
+                  int dim, float *scores, int64_t ld_scores, uint32_t flags, int n_threads) {
+    if (Lq < 0) return fail_host(MSIM_EINVAL, "negative size");
+    if (int rc = check_host(dtype, n_q, n_d, dim, scores, ld_scores, flags)) return rc;
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!Q || !D || !d_off) return fail_host(MSIM_EINVAL, "null pointer argument");
+    const size_t es = dtype == MSIM_DTYPE_F32 ? 4 : 2;
+    std::vector<const void *> qp(n_q), dp(n_d);
+    std::vector<int64_t> ql(n_q, Lq), dl(n_d);
+    for (int q = 0; q < n_q; ++q) qp[q] = static_cast<const char *>(Q) + (size_t)q * Lq * dim * es;
+    for (int d = 0; d < n_d; ++d) {
+        if (d_off[d + 1] < d_off[d]) return fail_host(MSIM_EINVAL, "d_off must be non-decreasing");
+        dp[d] = static_cast<const char *>(D) + (size_t)d_off[d] * dim * es;
+        dl[d] = d_off[d + 1] - d_off[d];
+    }
+    const bool rr = (flags & MSIM_FLAG_REF_ROUNDING) != 0 && dtype != MSIM_DTYPE_F32;      // fp32 inputs: nothing is rounded
+    return fwd_host_lists(HostCall{dtype, qp.data(), ql.data(), n_q, dp.data(), dl.data(), d_clamp0, n_d, dim, scores, ld_scores, rr},
+                          n_threads);
+}
+
+int msim_fwd_host_lists(int dtype, const void *const *q_ptr, const int64_t *q_rows, int n_q, const void *const *d_ptr,
+                        const int64_t *d_rows, const uint8_t *d_clamp0, int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags,
+                        int n_threads) {
+    if (int rc = check_host(dtype, n_q, n_d, dim, scores, ld_scores, flags)) return rc;
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!q_ptr || !q_rows || !d_ptr || !d_rows) return fail_host(MSIM_EINVAL, "null pointer argument");
+    for (int q = 0; q < n_q; ++q)
+        if (q_rows[q] < 0 || q_rows[q] > 0x7fffffff || (q_rows[q] > 0 && !q_ptr[q])) return fail_host(MSIM_EINVAL, "bad query buffer");
+    for (int d = 0; d < n_d; ++d)
+        if (d_rows[d] < 0 || d_rows[d] > 0x7fffffff || (d_rows[d] > 0 && !d_ptr[d])) return fail_host(MSIM_EINVAL, "bad document buffer");
+    const bool rr = (flags & MSIM_FLAG_REF_ROUNDING) != 0 && dtype != MSIM_DTYPE_F32;
+    return fwd_host_lists(HostCall{dtype, q_ptr, q_rows, n_q, d_ptr, d_rows, d_clamp0, n_d, dim, scores, ld_scores, rr}, n_threads);
+}
 
 int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n_b, int dim, float *out, int64_t ld_out, uint32_t flags,
                          int n_threads) {

@@ -49,41 +49,65 @@ def _host_threads() -> int:
 
 
 def _score_on_host(qs, ps, batch_size: int, ref_rounding: bool) -> torch.Tensor:
-    """`device="cpu"`: the library's own host-core scorer (msim_fwd_host, colpali_amd/csrc/maxsim_host.cpp) on host copies of the
-    same packed layout -- the reference computes on the device it is given (processing_utils.py:161, :172-179), so a CPU request
-    is served on the CPU.  No torch arithmetic, no oracle; a GPU request never comes here."""
+    """`device="cpu"`: the library's own host-core scorer (msim_fwd_host_lists, colpali_amd/csrc/maxsim_host.cpp) straight on the
+    caller's host tensors -- the reference computes on the device it is given (processing_utils.py:161, :172-179), so a CPU request
+    is served on the CPU.  Nothing is packed or copied (torch.cat of a thousand pages costs more than scoring them on a many-core
+    host), ragged queries are multiplied at their real lengths, the passages' block zero-padding travels as the same clamp0 flags
+    the GPU path uses.  No torch arithmetic, no oracle; a GPU request never comes here."""
     import numpy as np
 
+    from .corpus import block_clamp0
+
     L = _lib.lib()
-    cpu = torch.device("cpu")
-    q = pack_queries([t.to(cpu) for t in qs] if not isinstance(qs, torch.Tensor) else qs.to(cpu), cpu, layout="box")
-    if isinstance(ps, torch.Tensor):
-        if ps.dim() != 3:
-            raise ValueError("a passage tensor must be 3-D (n_passages, max_len, dim)")
-        _check_embeddings(ps, "passages")
-        n, Lp, dim = ps.shape
-        blob = _widen(ps.to(cpu).reshape(n * Lp, dim)).contiguous()
-        lengths = np.full(n, Lp, dtype=np.int64)
-        clamp0 = None
-    else:
-        corpus = pack_passages([t.to(cpu) for t in ps], cpu, batch_size=batch_size)      # host blob, same clamp0 rule
-        blob, clamp0 = corpus.blob, corpus.clamp0
-        lengths = corpus.lengths.numpy()
-    if q.dtype != blob.dtype:
-        raise RuntimeError(f"expected queries and passages of one dtype, got {q.dtype} and {blob.dtype}")
-    if q.shape[2] != blob.shape[1]:
-        raise RuntimeError(f"queries have embedding width {q.shape[2]}, the corpus {blob.shape[1]}")
-    off = np.zeros(len(lengths) + 1, dtype=np.int32)
-    np.cumsum(lengths, out=off[1:])
-    n_q, Lq, dim = q.shape
-    out = torch.empty((n_q, len(lengths)), dtype=torch.float32)
-    rc = L.msim_fwd_host(_lib.dtype_code(q.dtype), q.data_ptr(), n_q, Lq, blob.data_ptr(), off.ctypes.data,
-                         clamp0.data_ptr() if clamp0 is not None else None, len(lengths), dim, out.data_ptr(),
-                         out.stride(0) if n_q > 1 else max(len(lengths), 1), _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0,
-                         _host_threads())
+
+    def rows_of(x, what):
+        """(keep-alive list, pointers, row counts, dim, dtype) of a list of [len, dim] tensors or a [n, len, dim] tensor."""
+        if isinstance(x, torch.Tensor):
+            if x.dim() != 3:
+                raise ValueError(f"a {what} tensor must be 3-D (n, max_len, dim)")
+            _check_embeddings(x, what)
+            t = x.to("cpu").contiguous()
+            n, ln, dim = t.shape
+            step = ln * dim * t.element_size()
+            return [t], np.asarray([t.data_ptr() + i * step for i in range(n)], dtype=np.uint64), np.full(n, ln, dtype=np.int64), dim, t.dtype
+        keep = []
+        for t in x:
+            if t.dim() != 2:
+                raise ValueError(f"each {what[:-1] if what.endswith('s') else what} must be 2-D (sequence_length, dim)")
+            _check_embeddings(t, what)
+            if t.dtype != x[0].dtype:
+                raise RuntimeError(f"expected {what} of one dtype, got {x[0].dtype} and {t.dtype}")
+            if t.shape[1] != x[0].shape[1]:
+                raise RuntimeError(f"expected {what} of one embedding width, got {x[0].shape[1]} and {t.shape[1]}")
+            keep.append(t.to("cpu").contiguous())
+        return (keep, np.asarray([t.data_ptr() if t.numel() else 0 for t in keep], dtype=np.uint64),
+                np.asarray([t.shape[0] for t in keep], dtype=np.int64), int(x[0].shape[1]), x[0].dtype)
+
+    q_keep, q_ptr, q_rows, q_dim, q_dtype = rows_of(qs, "queries")
+    p_keep, p_ptr, p_rows, p_dim, p_dtype = rows_of(ps, "passages")
+    if q_dtype != p_dtype:
+        raise RuntimeError(f"expected queries and passages of one dtype, got {q_dtype} and {p_dtype}")
+    if q_dim != p_dim:
+        raise RuntimeError(f"queries have embedding width {q_dim}, the corpus {p_dim}")
+    clamp0 = None
+    if not isinstance(ps, torch.Tensor):          # a 3-D passage tensor keeps its physical zero rows: no flag needed
+        lengths = torch.from_numpy(p_rows)
+        flags = block_clamp0(lengths, batch_size)
+        if bool((lengths == 0).any()):
+            for j in range(0, len(p_rows), batch_size):      # an all-empty block makes the reference's max() over an empty dim raise
+                if int(lengths[j: j + batch_size].max()) == 0:
+                    raise RuntimeError("max(): Expected reduction dim 3 to have non-zero size.")
+        clamp0 = flags.numpy() if bool(flags.any()) else None
+    n_q, n_d = len(q_rows), len(p_rows)
+    out = torch.empty((n_q, n_d), dtype=torch.float32)
+    rc = L.msim_fwd_host_lists(_lib.dtype_code(q_dtype), q_ptr.ctypes.data, q_rows.ctypes.data, n_q, p_ptr.ctypes.data,
+                               p_rows.ctypes.data, clamp0.ctypes.data if clamp0 is not None else None, n_d, q_dim, out.data_ptr(),
+                               out.stride(0) if n_q > 1 else max(n_d, 1), _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0,
+                               _host_threads())
+    del q_keep, p_keep
     if rc != 0:
         msg = L.msim_host_last_error().decode("utf-8", "replace")
-        raise (NotImplementedError if rc == -2 else ValueError if rc == -1 else RuntimeError)(f"msim_fwd_host: {msg}")
+        raise (NotImplementedError if rc == -2 else ValueError if rc == -1 else RuntimeError)(f"msim_fwd_host_lists: {msg}")
     return out
 
 

@@ -119,6 +119,14 @@ int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq,
                   int n_d, int dim,
                   float *scores, int64_t ld_scores,
                   uint32_t flags, int n_threads);
+/* The same without any packing: query q = q_rows[q] rows of `dim` elements at q_ptr[q], document c = d_rows[c] rows at d_ptr[c] -- the
+ * caller's own host tensors (a list of ragged queries and passages is what the reference's callers hold: README.md:121-126); nothing
+ * is copied, and only the real tokens of a ragged query are multiplied. */
+int msim_fwd_host_lists(int dtype, const void *const *q_ptr, const int64_t *q_rows, int n_q,
+                        const void *const *d_ptr, const int64_t *d_rows, const uint8_t *d_clamp0,
+                        int n_d, int dim,
+                        float *scores, int64_t ld_scores,
+                        uint32_t flags, int n_threads);
 /* out[i, j] = <A_i, B_j> on the host cores (score_single_vector with device="cpu": processing_utils.py:103-130) */
 int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n_b, int dim,
                          float *out, int64_t ld_out, uint32_t flags, int n_threads);

@@ -94,6 +94,29 @@ def test_single_vector_scores_on_cpu():
     assert torch.allclose(got, torch.stack(qs) @ torch.stack(ps).T, atol=1e-5)
 
 
+def test_packed_and_list_entry_points_agree_bit_for_bit():
+    """msim_fwd_host (box + packed blob, the layout of the GPU entry points) and msim_fwd_host_lists (the caller's tensors as they are)
+    are one implementation: equal queries give equal bits; zero padding rows of a box add exactly 0."""
+    L = amd._lib.lib()
+    g = torch.Generator().manual_seed(4)
+    qs = [torch.randn(n, 128, generator=g).to(torch.bfloat16) for n in (32, 32, 32)]
+    ps = [torch.randn(n, 128, generator=g).to(torch.bfloat16) for n in (40, 1, 17, 300, 8)]
+    want = amd.score_multi_vector(qs, ps, batch_size=2, device="cpu")
+    box = torch.stack(qs).contiguous()
+    blob = torch.cat(ps).contiguous()
+    off = np.zeros(len(ps) + 1, dtype=np.int32)
+    np.cumsum([p.shape[0] for p in ps], out=off[1:])
+    clamp0 = np.asarray([1, 1, 1, 0, 0], dtype=np.uint8)        # blocks of two: (40, 1) -> the 1-row page is padded; (17, 300); (8) alone
+    clamp0[0] = 0
+    out = torch.empty((3, len(ps)), dtype=torch.float32)
+    rc = L.msim_fwd_host(0, box.data_ptr(), 3, 32, blob.data_ptr(), off.ctypes.data, clamp0.ctypes.data, len(ps), 128, out.data_ptr(),
+                         len(ps), 0, 4)
+    assert rc == 0 and torch.equal(out, want)
+    assert L.msim_fwd_host(0, box.data_ptr(), 3, 32, blob.data_ptr(), off.ctypes.data, None, len(ps), 128, out.data_ptr(), 2, 0, 4) == -1
+    assert L.msim_fwd_host(5, box.data_ptr(), 3, 32, blob.data_ptr(), off.ctypes.data, None, len(ps), 128, out.data_ptr(), len(ps), 0, 4) == -2
+    assert b"bfloat16" in L.msim_host_last_error()
+
+
 def test_results_do_not_depend_on_the_thread_count(monkeypatch):
     g = torch.Generator().manual_seed(8)
     qs = [torch.randn(n, 128, generator=g).to(torch.bfloat16) for n in (32, 12, 40)]
