@@ -37,6 +37,8 @@ def block_clamp0(lengths: torch.Tensor, batch_size: int) -> torch.Tensor:
         raise ValueError("batch_size must be positive")
     n = lengths.numel()
     lengths = lengths.to(torch.int64).cpu()
+    if batch_size >= n:                   # one block (and no padding to a multiple of a huge batch_size)
+        return (lengths < (lengths.max() if n else 0)).to(torch.uint8)
     pad = (-n) % batch_size
     padded = torch.cat([lengths, lengths.new_full((pad,), -1)]) if pad else lengths
     block_max = padded.view(-1, batch_size).max(dim=1).values.repeat_interleave(batch_size)[:n]

@@ -91,11 +91,14 @@ def test_golden_tensor3d_inputs(amd):
 
 def _random_case(seed, n_q, lq_max, n_d, ld_max, fixed_ld=None):
     g = torch.Generator().manual_seed(seed)
-    def unit(n):
-        return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16)
+
+    def units(lens):        # one torch call per list, cut into pieces: a many-core host spends tens of ms in every small CPU op
+        rows = torch.nn.functional.normalize(torch.randn(sum(lens), 128, generator=g), dim=-1).to(torch.bfloat16)
+        return [t.clone() for t in rows.split(lens)]
+
     q_lens = torch.randint(1, lq_max + 1, (n_q,), generator=g).tolist()
     d_lens = [fixed_ld] * n_d if fixed_ld else torch.randint(1, ld_max + 1, (n_d,), generator=g).tolist()
-    return [unit(n) for n in q_lens], [unit(n) for n in d_lens]
+    return units(q_lens), units(d_lens)
 
 
 def _oracle(qs, ps, batch_size):

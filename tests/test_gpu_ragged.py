@@ -37,12 +37,19 @@ def unit_rows(n, g, dtype=torch.bfloat16):
     return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(dtype)
 
 
+def unit_row_list(lens, g, dtype=torch.bfloat16):
+    """One tensor of unit rows cut into pieces of the given lengths (one torch call instead of one per piece: a many-core host spends
+    tens of milliseconds in every small CPU op)."""
+    lens = [int(n) for n in lens]
+    return list(unit_rows(sum(lens), g, dtype).split(lens)) if lens else []
+
+
 def oracle(qs, ps, batch_size=10**9):
     return mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], batch_size=batch_size, mode="f32")
 
 
 def docs(g, n, lo, hi, dtype=torch.bfloat16):
-    return [unit_rows(int(x), g, dtype) for x in torch.randint(lo, hi + 1, (n,), generator=g)]
+    return unit_row_list(torch.randint(lo, hi + 1, (n,), generator=g).tolist(), g, dtype)
 
 
 # (query lengths, what the plan makes of them) -- flat_plan in colpali_amd/csrc/maxsim_abi.hip
@@ -75,8 +82,8 @@ PLANS = [
 @pytest.mark.parametrize("lens,what", PLANS, ids=[w for _, w in PLANS])
 def test_flat_queries_in_every_plan_shape_match_the_oracle(amd, lens, what):
     g = torch.Generator().manual_seed(1000 + sum(lens) + len(lens))
-    qs = [unit_rows(n, g) for n in lens]
-    ps = docs(g, 150, 1, 300) + [unit_rows(1024, g), unit_rows(32, g), unit_rows(33, g), unit_rows(128, g), unit_rows(129, g)]
+    qs = unit_row_list(lens, g)
+    ps = docs(g, 150, 1, 300) + unit_row_list([1024, 32, 33, 128, 129], g)
     want = oracle(qs, ps, batch_size=16)
     got = amd.score_multi_vector(qs, ps, batch_size=16, device="cuda:0").numpy()
     assert got.shape == (len(qs), len(ps))
@@ -84,7 +91,7 @@ def test_flat_queries_in_every_plan_shape_match_the_oracle(amd, lens, what):
     q = amd.pack_queries(qs, DEV)
     assert isinstance(q, amd.PackedQueries) and q.lengths.tolist() == lens
     # the same through the resident-corpus entry, the whole corpus as ONE of the reference's passage blocks
-    corpus = amd.pack_passages(ps, DEV, batch_size=10**9)
+    corpus = amd.pack_passages(ps, DEV, batch_size=len(ps))
     assert close(amd.maxsim_scores(q, corpus).cpu().numpy(), oracle(qs, ps)), what
 
 
@@ -93,7 +100,7 @@ def test_ragged_thousand_queries_many_blocks(amd):
     convoy counters in the workspace; and a corpus large enough for every XCD range to hold documents."""
     g = torch.Generator().manual_seed(77)
     lens = torch.randint(12, 49, (1000,), generator=g).tolist()
-    qs = [unit_rows(n, g) for n in lens]
+    qs = unit_row_list(lens, g)
     ps = docs(g, 700, 20, 140)
     got = amd.score_multi_vector(qs, ps, device="cuda:0").numpy()
     assert close(got, oracle(qs, ps, batch_size=128))
@@ -120,7 +127,7 @@ def test_zero_rows_are_dropped_and_change_no_score(amd, dtype):
     lens = [12, 33, 40, 7, 25]
     l_max = 48
     ps = docs(g, 120, 5, 400, dtype)
-    corpus = amd.pack_passages(ps, DEV, batch_size=10**9)
+    corpus = amd.pack_passages(ps, DEV, batch_size=len(ps))
     real = [unit_rows(n, g, dtype) for n in lens]
     want = oracle(real, ps)
     for side in ("right", "left"):
@@ -148,7 +155,7 @@ def test_a_query_scores_the_same_bits_in_any_batch(amd):
     batch, in one 8-wave block and in a multi-block launch, at any position."""
     g = torch.Generator().manual_seed(9)
     lens = torch.randint(10, 49, (90,), generator=g).tolist()
-    qs = [unit_rows(n, g) for n in lens]
+    qs = unit_row_list(lens, g)
     ps = docs(g, 300, 30, 500)
     corpus = amd.pack_passages(ps, DEV)
     full = amd.maxsim_scores(amd.pack_queries(qs, DEV), corpus).cpu().numpy()           # several blocks
