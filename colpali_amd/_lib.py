@@ -88,6 +88,8 @@ def lib() -> ctypes.CDLL:
     L.msim_fwd_host_lists.restype = i32
     L.msim_sim_matrix_host.argtypes = [i32, vp, i32, vp, i32, i32, vp, i64, u32, i32]
     L.msim_sim_matrix_host.restype = i32
+    L.msim_fwd_plan.argtypes = [vp, i32, i32, vp]
+    L.msim_fwd_plan.restype = i32
     L.msim_fwd_ragged_workspace_bytes.argtypes = [i32, vp, i32, i32, i32]
     L.msim_fwd_ragged_workspace_bytes.restype = sz
     L.msim_fwd_ragged.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]

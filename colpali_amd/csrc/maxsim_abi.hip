@@ -887,6 +887,21 @@ size_t msim_fwd_workspace_bytes(int dtype, int n_q, int Lq, int n_d, int dim) {
     return flat_workspace_bytes(HostQ{nullptr, Lq, 0, 1}, n_q);                     // exactly launch_batch's condition
 }
 
+int msim_fwd_plan(const int32_t *q_off_host, int n_q, int Lq, int32_t *out5) {
+    if (!out5 || n_q <= 0 || (!q_off_host && Lq <= 0)) return fail(MSIM_EINVAL, "bad arguments");
+    thread_local FlatPlan plan;
+    const HostQ hq = q_off_host ? HostQ{q_off_host, 0, 0, 1}
+                                : (Lq > kLongSegRows ? HostQ{nullptr, Lq, kLongSegRows, long_segments(Lq)} : HostQ{nullptr, Lq, 0, 1});
+    const int n = (!q_off_host && Lq > kLongSegRows) ? n_q * long_segments(Lq) : n_q;
+    if (int rc = flat_plan(hq, n, plan)) return rc;
+    out5[0] = plan.stream ? 0 : 1;
+    out5[1] = plan.stream ? plan.nu : plan.nw;
+    out5[2] = plan.stream ? 0 : plan.maxu;
+    out5[3] = plan.stream ? 1 : plan.n_blocks();
+    out5[4] = plan.stream ? plan.nu : heaviest_wave_units(hq, plan.blk_q0, plan.nw);
+    return MSIM_OK;
+}
+
 size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim) {
     if (n_q <= 0 || n_d <= 0 || !q_off_host) return 0;
     if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || dim != msim::kDim) return 0;

@@ -141,6 +141,12 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
  * n_q + 1 numbers (read during the call only).  Workspace as msim_fwd's: msim_fwd_ragged_workspace_bytes() bytes or NULL.
  * Replaces the same reference lines as msim_fwd (processing_utils.py:172-179 with its pad_sequence of the query block).
  */
+/* Which kernel shape a tuned forward call (bf16 / f16, width 128) takes for these queries -- host-only, no device work; the same
+ * plan msim_fwd / msim_fwd_ragged make.  q_off_host = the n_q + 1 token offsets, or NULL for n_q uniform queries of Lq tokens
+ * (more than 128 tokens: the 128-token pieces msim_fwd scores with a workspace).  out5 = { 0 = K1s (every wave holds all units:
+ * HBM-bound regime) | 1 = K1b (waves share a document stream),  K1s: 16-token units per wave | K1b: waves per stream (2, 4, 8),
+ * K1b: units a wave holds at most (8, 10),  query blocks (passes over a document range),  units of the heaviest wave }. */
+int msim_fwd_plan(const int32_t *q_off_host, int n_q, int Lq, int32_t *out5);
 size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim);
 int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32_t *q_off_host, int n_q,
                     const void *D, const int32_t *d_off, const uint8_t *d_clamp0,

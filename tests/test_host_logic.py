@@ -356,6 +356,46 @@ def test_flat_plan_errors_and_limits_without_a_gpu():
     assert L.msim_fwd_ragged_workspace_bytes(0, off.ctypes.data, 2, 5, 128) == 0   # K1s: no scratch
 
 
+def test_the_launch_plan_is_the_ladder_design_md_describes():
+    """msim_fwd_plan (host-only): the kernel shape per batch -- DESIGN.md 3.0's ladder in 16-token units, the balanced multi-block plans,
+    the eight-vs-ten-units cost rule, the 64-queries-per-block limit, long queries as 128-token pieces."""
+    import numpy as np
+
+    L = colpali_amd._lib.lib()
+
+    def plan(lens=None, n_q=0, lq=0):
+        out = np.zeros(5, dtype=np.int32)
+        if lens is not None:
+            off = np.zeros(len(lens) + 1, dtype=np.int32)
+            np.cumsum(np.asarray(lens, dtype=np.int32), out=off[1:])
+            rc = L.msim_fwd_plan(off.ctypes.data, len(lens), 0, out.ctypes.data)
+        else:
+            rc = L.msim_fwd_plan(None, n_q, lq, out.ctypes.data)
+        assert rc == 0, L.msim_last_error()
+        return tuple(int(v) for v in out)
+
+    # (kernel, units | waves, max units per wave, blocks, units of the heaviest wave)
+    assert plan(n_q=1, lq=32) == (0, 2, 0, 1, 2) and plan(n_q=4, lq=32) == (0, 8, 0, 1, 8)         # K1s: the headline is 8 units
+    assert plan(n_q=4, lq=20) == (0, 5, 0, 1, 5) and plan(lens=[25, 25, 25, 25]) == (0, 7, 0, 1, 7)  # real lengths: fewer units
+    assert plan(n_q=4, lq=40) == (1, 2, 8, 1, 5)                                                    # 10 units: the pair form, 5 + 5
+    assert plan(n_q=8, lq=32) == (1, 2, 8, 1, 8) and plan(n_q=9, lq=32) == (1, 2, 10, 1, 9)          # pair; pair x 10 units (9 + 9)
+    assert plan(n_q=10, lq=32) == (1, 4, 8, 1, 5)                                                   # round 4: 5/5/5/5 on four waves
+    assert plan(n_q=16, lq=32) == (1, 4, 8, 1, 8) and plan(n_q=20, lq=32) == (1, 4, 10, 1, 10)
+    assert plan(n_q=32, lq=32) == (1, 8, 8, 1, 8) and plan(n_q=40, lq=32) == (1, 8, 10, 1, 10)
+    assert plan(n_q=1000, lq=32) == (1, 8, 8, 32, 8)                                                # 32 blocks: one round of an XCD's CUs
+    assert plan(n_q=1000, lq=40) == (1, 8, 8, 40, 8) and plan(n_q=1000, lq=20) == (1, 8, 8, 20, 8)
+    assert plan(n_q=80, lq=32) == (1, 8, 8, 3, 7)      # three blocks of 27/27/26 queries: 7 units on the heaviest wave (round 3's 32-token
+    #                                                     tiles made that 4 tiles = 8 units, and two ten-unit blocks won: 3 x 7 < 1.1 x 2 x 10 now)
+    assert plan(n_q=9, lq=8) == (1, 2, 8, 1, 3)                                                     # more than 8 queries never go to K1s
+    assert plan(lens=[7] * 70)[3] == 2 and plan(lens=[13] * 64) == (1, 8, 8, 1, 7)                  # 64 queries per block at most
+    g = np.random.default_rng(0)
+    k, nw, maxu, nb, heavy = plan(lens=g.integers(12, 49, 1000).tolist())
+    assert (k, nw, maxu) == (1, 8, 8) and 29 <= nb <= 31 and heavy == 8                             # ~30 balanced blocks of whole queries
+    assert plan(n_q=3, lq=780) == (1, 8, 8, 3, 7)                                                   # 21 pieces of 128 tokens: 8 + 8 + 5 per block
+    out = np.zeros(5, dtype=np.int32)
+    assert L.msim_fwd_plan(np.asarray([0, 1300], dtype=np.int32).ctypes.data, 1, 0, out.ctypes.data) == -2   # one query above a block
+
+
 def test_loss_offset_and_pair_checks_run_before_any_device_work():
     from colpali_amd import loss as Lm
 
