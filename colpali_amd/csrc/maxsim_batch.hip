@@ -1,25 +1,27 @@
-// K1b -- "batch" MaxSim kernel for gfx950 (MI355X): more than 4 token tiles (of 32 query tokens) in total, i.e. the ridge
-// and the MFMA-bound regime.  Same arithmetic as K1s (colpali_engine/utils/processing_utils.py:179 and
+// K1b -- "batch" MaxSim kernel for gfx950 (MI355X): more than 8 units (of 16 query tokens) or more than 8 queries in total, i.e. the
+// ridge and the MFMA-bound regime.  Same arithmetic as K1s (colpali_engine/utils/processing_utils.py:179 and
 // colpali_engine/loss/late_interaction_losses.py:297-298), different blocking.
 //
 // Structure
-//   * NW waves share ONE document stream through an LDS ring; every wave keeps up to 4 query token tiles (32 tokens x 128
-//     each = 32 VGPRs) in registers as MFMA B operands and scores them against every slab of the stream:
-//       NW = 2 ("pair", 5..8 tiles):  four pairs per CU -- two waves per SIMD at <= 256 registers where one wave holding all
-//               8 tiles needs 300+ and runs alone on its SIMD; one 32-row slab per barrier, and the barrier spans two waves only;
-//       NW = 4 (9..16 tiles):         two workgroups per CU, 64-row chunks: one computes while the other sits at its barrier;
-//       NW = 8 (more):                one workgroup per CU, 128-row chunks, up to 32 tiles per query block -- the fewest passes
-//               over the corpus;
-//     the queries are split EVENLY over the query blocks and dealt to the waves of a block round-robin (query j of the block ->
-//     wave j % NW), and a wave runs the loop body compiled for the number of tiles it actually holds;
+//   * the queries are ONE flat token matrix (maxsim_common.hpp: the flat layout); a query BLOCK is a run of whole queries (the host
+//     plan, maxsim_abi.hip: flat_plan, cuts them: <= NW * MAXU units of tokens, <= NW * 8 queries) and its 16-token units are dealt to
+//     the waves round-robin, whatever queries they belong to; every wave keeps its units (16 VGPRs each, up to 8; 10 with eight of them
+//     in AGPRs) in registers as MFMA B operands and runs the loop body compiled for the number it actually holds;
+//   * NW waves share ONE document stream through an LDS ring:
+//       NW = 2 ("pair", <= 16 / 20 units):  four pairs per CU -- two waves per SIMD at <= 256 registers; one 32-row slab per barrier,
+//               and the barrier spans two waves only;
+//       NW = 4 (<= 32 / 40 units):          two workgroups per CU, 64-row chunks: one computes while the other sits at its barrier;
+//       NW = 8 (more; several blocks):      one workgroup per CU, 128-row chunks -- the fewest passes over the corpus;
 //   * a chunk = NW/2 slabs; each wave issues 4 of the chunk's LDS-DMA wave-instructions (buffer_load_dwordx4 ... lds,
 //     per-document bounds-checked descriptor, XOR-swizzled source); ONE raw s_barrier per chunk, LDS-DMA stays in flight across it
 //     (counted vmcnt, never 0);
-//   * per slab a wave reads the 8 operand fragments ONCE (ds_read_b128, conflict free), then runs 8 MFMAs per tile with the
-//     16 -> 1 max fold of one tile underneath the MFMAs of the next; per-token running max in registers, no cross-wave
-//     reduction at all.  (A first version processed the tiles in two passes and re-read the fragments for the second: the
-//     one-pass body is 1-5 % faster everywhere -- this regime is POWER-bound on real data, see DESIGN.md, and an LDS read
-//     costs energy.)
+//   * per slab a wave reads the 8 operand fragments ONCE (ds_read_b128, conflict free), then runs 8 MFMAs per unit and folds the
+//     16 -> 1 max; per-token running max in registers.  (A first version processed the units in two passes and re-read the fragments
+//     for the second: the one-pass body is 1-5 % faster everywhere -- this regime is POWER-bound on real data, see DESIGN.md, and an
+//     LDS read costs energy.)
+//   * end of a document: every wave writes its per-token maxima to the workgroup's token table in LDS; behind the next chunk barrier
+//     (the one that exists anyway) 8 lanes per query add that query's tokens -- in an order fixed by the query's length alone -- and
+//     one lane stores the score;
 //   * grid: blockIdx -> (XCD, slot); the workgroups resident on one XCD stream the SAME document range for different query
 //     blocks, so a document is pulled from HBM once per XCD and served to the other CUs from that XCD's L2 (placement only
 //     affects speed, never results).
