@@ -892,6 +892,8 @@ int msim_fwd_plan(const int32_t *q_off_host, int n_q, int Lq, int32_t *out5) {
     thread_local FlatPlan plan;
     const HostQ hq = q_off_host ? HostQ{q_off_host, 0, 0, 1}
                                 : (Lq > kLongSegRows ? HostQ{nullptr, Lq, kLongSegRows, long_segments(Lq)} : HostQ{nullptr, Lq, 0, 1});
+    if (!q_off_host && Lq > kLongSegRows && (long long)n_q * long_segments(Lq) > 0x7fffffff / 8)
+        return fail(MSIM_EUNSUPPORTED, "too many 128-token pieces (%d queries x %d)", n_q, long_segments(Lq));
     const int n = (!q_off_host && Lq > kLongSegRows) ? n_q * long_segments(Lq) : n_q;
     if (int rc = flat_plan(hq, n, plan)) return rc;
     out5[0] = plan.stream ? 0 : 1;

@@ -163,6 +163,8 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
  *   msim_host_count_nonzero_rows / msim_host_gather_nonzero_rows
  *                             host (native threads; synchronous): the same for a list of host buffers src[i] of rows[i] rows --
  *                             counts, then the copy of source i's non-zero rows to row dst_row[i] .. of `dst` (pinned staging).
+ * Both forms are two passes over the same data (count, then copy to offsets built from the counts): the sources must not change in
+ * between -- the copy trusts the offsets.
  */
 int msim_query_compact(const void *box, int n_q, int Lq, int row_bytes, const int32_t *q_off, int32_t *counts, void *out,
                        void *stream);
