@@ -128,6 +128,33 @@ def test_results_do_not_depend_on_the_thread_count(monkeypatch):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_concurrent_callers_share_the_thread_pool_without_deadlock():
+    """One parallel region at a time: a second caller scores on its own thread instead of waiting for the pool (ctypes releases the
+    GIL inside the call, so python threads really overlap).  Same bits as a lone call."""
+    import threading
+
+    g = torch.Generator().manual_seed(12)
+    qs = [torch.randn(n, 128, generator=g).to(torch.bfloat16) for n in (32, 20, 40, 12)]
+    ps = [torch.randn(n, 128, generator=g).to(torch.bfloat16) for n in torch.randint(50, 400, (120,), generator=g).tolist()]
+    want = amd.score_multi_vector(qs, ps, device="cpu")
+    got, errs = [None] * 6, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = amd.score_multi_vector(qs, ps, device="cpu")
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errs and all(not th.is_alive() for th in threads)
+    assert all(torch.equal(x, want) for x in got)
+
+
 def test_the_reference_scorer_tests_pass_on_a_host_without_a_gpu():
     """/root/reference/tests/utils/test_processing_utils.py, unmodified, in a subprocess that sees NO GPU: `device` defaults to
     get_torch_device("auto") = "cpu" there, and both scorers must work (round-3 review: the patched package used to raise)."""
