@@ -224,7 +224,7 @@ int launch_stream(const FwdCall &c) {
 //     no barriers at all);
 //   * more: K1b, whose query blocks hold WHOLE queries -- at most nw * maxu units of tokens and nw * 8 queries (one 8-lane group of the
 //     workgroup per query in the reduction).  One block if the batch fits one of the six shapes
-//         units <= 16: pair (2 waves) | <= 20: pair, ten units per wave | <= 32: 4 waves | <= 40: 4 waves x 10 | <= 64: 8 waves | <= 80: 8 x 10
+//         units <= 16: pair (2 waves) | <= 20: 4 waves x 5 units, three workgroups per CU | <= 32: 4 waves | <= 40: 4 waves x 10 | <= 64: 8 waves | <= 80: 8 x 10
 //     (the measured ladder of rounds 2-3 in 16-token units: profiles/r02_logs/ab_ridge.log, r03_logs/ab_batch_t5.log,
 //     ab_batch8_final.log), else several blocks on the 8-wave form, filled greedily in query order and then re-cut evenly; eight or
 //     ten units per wave by cost: a block's pace is set by its heaviest wave, so a plan costs (blocks) x (units of the heaviest
@@ -310,17 +310,22 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
         p.nu = units > 0 ? (int)units : 1;
         return MSIM_OK;
     }
-    static const int shapes[6][2] = {{2, 8}, {2, 10}, {4, 8}, {4, 10}, {8, 8}, {8, 10}};
+    static const int shapes[7][2] = {{2, 8}, {4, 5}, {2, 10}, {4, 8}, {4, 10}, {8, 8}, {8, 10}};
     // round 4 re-measured the ladder in units (profiles/r04_logs/ab_plan_ladder.log, 16 GiB shard, random rows / zero-filled shard):
     // 18 units: pair x 10 (9 + 9) 4.12 ms / 2.97 vs 4 waves (5/5/4/4) 4.23 / 2.99; 20 units: 4 waves x 5 units 4.38 / 3.04 vs the
-    // pair 4.42-4.45 / 3.19 -- four evenly loaded waves beat two ten-unit ones once the units divide by four
+    // pair 4.42-4.45 / 3.19 -- four evenly loaded waves beat two ten-unit ones once the units divide by four.  Then the FIVE-unit
+    // form of the 4-wave shape: a kernel that never holds more than five units needs 168 registers, so THREE workgroups share a CU
+    // (three waves per SIMD; 2-chunk ring, 37.5 KiB of LDS each) -- 17..20 units: 9 queries 4.02 -> 3.98 ms, 10 queries 4.25 -> 4.13
+    // (zero shard 0.726 -> 0.747, 0.731 -> 0.740), bit-identical (profiles/r04_logs/ab_five_units_3wg.log; with the 3-chunk ring the
+    // third workgroup does not fit the LDS and it is slower than the two-workgroup form).  The pair x 10 shape is a measurement-build
+    // shape since
     const int forced = batch_nw_override();
     static const int forced_maxu = ab_env("MSIM_BATCH_MAXU", 0);      // 8 | 10 (measurement builds)
     for (const auto &sh : shapes) {
         if (forced && sh[0] != forced) continue;
         if (forced_maxu && sh[1] != forced_maxu) continue;
         if (units > sh[0] * sh[1] || n_q > sh[0] * 8) continue;
-        if (!forced && !forced_maxu && sh[0] == 2 && sh[1] == 10 && units > 18 && n_q <= 32) continue;   // 19..20 units: the 4-wave form
+        if (sh[0] == 2 && sh[1] == 10 && !(forced == 2 || forced_maxu == 10)) continue;       // superseded by {4, 5}: measurement builds only
         if (!fill_blocks(hq, n_q, sh[0], sh[1], p.blk_q0) || p.n_blocks() != 1) continue;
         p.nw = sh[0];
         p.maxu = sh[1];
@@ -357,7 +362,7 @@ template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
 int launch_batch(const FwdCall &c, const FlatPlan &plan) {
     auto kern = msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
     constexpr int lds = RING * (NW / 2) * msim::kSlabBytes + NW * MAXU * msim::kUnitTok * 16 + NW * 8 * 8;   // ring + the per-token max table + the queries' token ranges
-    constexpr int wg_per_cu = 8 / NW;
+    constexpr int wg_per_cu = MAXU == 5 ? 3 : 8 / NW;       // the five-unit form: 168 registers, three workgroups per CU
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
@@ -451,7 +456,17 @@ int fwd_dispatch(const FwdCall &c) {
     // MSIM_BATCH_NT=0 switches that off for A/B measurements (tuning knob, not part of the ABI).
     static const bool nt_off = ab_env("MSIM_BATCH_NT", 1) == 0;
     const bool single = plan.n_blocks() == 1 && !nt_off;
-    if (plan.nw == 2) return plan.maxu == 10 ? launch_batch<F16, 2, 4, 2, 10>(c, plan) : launch_batch<F16, 2, 4, 2, 8>(c, plan);
+    if (plan.nw == 4 && plan.maxu == 5) {
+#ifdef MSIM_AB
+        static const int ring5 = ab_env("MSIM_BATCH_RING5", 2);
+        if (ring5 == 3) return launch_batch<F16, 4, 3, 2, 5>(c, plan);
+#endif
+        return launch_batch<F16, 4, 2, 2, 5>(c, plan);
+    }
+#ifdef MSIM_AB
+    if (plan.nw == 2 && plan.maxu == 10) return launch_batch<F16, 2, 4, 2, 10>(c, plan);
+#endif
+    if (plan.nw == 2) return launch_batch<F16, 2, 4, 2, 8>(c, plan);
     if (plan.nw == 4) return plan.maxu == 10 ? launch_batch<F16, 4, 3, 2, 10>(c, plan) : launch_batch<F16, 4, 3, 2, 8>(c, plan);
     if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10>(c, plan) : launch_batch<F16, 8, 3, 0, 10>(c, plan);
     return single ? launch_batch<F16, 8, 3, 2, 8>(c, plan) : launch_batch<F16, 8, 3, 0, 8>(c, plan);

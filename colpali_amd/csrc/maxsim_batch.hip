@@ -85,7 +85,7 @@ __device__ __forceinline__ int lower_bound_doc(const int32_t *__restrict__ d_off
 // MAXU: 16-token units a wave holds at most: 8, or 10 (round 3's five-tile form): 160 B-operand registers, 128 of them pinned to
 //       AGPRs, still two waves per SIMD.  How many it really holds is a run-time, wave-uniform number that selects the compiled body.
 template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
-__global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t *__restrict__ Qt,
+__global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_kernel(const uint16_t *__restrict__ Qt,
                                                                const uint16_t *__restrict__ D,
                                                                const int32_t *__restrict__ d_off,
                                                                const uint8_t *__restrict__ clamp0,
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
     int g_chunk = 0;                                        // chunks consumed by this workgroup (wave-uniform)
 
     // ---- this block's tokens; block-local unit u lives in wave u % NW (slot u / NW)
-    static_assert(MAXU == 8 || MAXU == 10, "a wave holds up to 8 units (10: the AGPR form)");
+    static_assert(MAXU == 5 || MAXU == 8 || MAXU == 10, "a wave holds up to 8 units (10: the AGPR form; 5: three workgroups per CU)");
     const int qb0 = a.blk_q0[qblock];                                       // first query of this block
     const int qb_n = a.blk_q0[qblock + 1] - qb0;                            // queries in this block (<= 8 * NW)
     const int tok0 = flat_qoff(a.fq, qb0);
@@ -341,9 +341,9 @@ __global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_kernel(const uint16_t
         case 3: run(std::integral_constant<int, 3>{}); break;
         case 4: run(std::integral_constant<int, 4>{}); break;
         case 5: run(std::integral_constant<int, 5>{}); break;
-        case 6: run(std::integral_constant<int, 6>{}); break;
-        case 7: run(std::integral_constant<int, 7>{}); break;
-        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 6: if constexpr (MAXU >= 6) run(std::integral_constant<int, 6>{}); break;
+        case 7: if constexpr (MAXU >= 7) run(std::integral_constant<int, 7>{}); break;
+        case 8: if constexpr (MAXU >= 8) run(std::integral_constant<int, 8>{}); break;
         case 9: if constexpr (MAXU >= 9) run(std::integral_constant<int, 9>{}); break;
         default: if constexpr (MAXU >= 10) run(std::integral_constant<int, 10>{}); break;
     }

@@ -62,11 +62,12 @@ PLANS = [
     ([40, 40, 40], "K1s, 8 units (120 tokens)"),
     ([1] * 8, "K1s, 8 one-token queries in one unit"),
     ([12] * 9, "pair form: 9 queries > K1s's 8"),
+    ([10] * 30, "4 waves x 5 units: 30 short queries (more than the pair's 16), 19 units"),
     ([40] * 4, "pair form: 160 tokens = 10 units, 5 + 5"),
     ([33, 47, 12, 40, 21, 38], "pair form: 191 tokens = 12 units"),
-    ([40] * 7, "pair form x 10 units: 280 tokens = 18 units"),
-    ([40] * 8, "pair form x 10 units: 320 tokens = 20 units exactly"),
-    ([20] * 17, "4-wave form: 17 queries > the pair's 16"),
+    ([40] * 7, "4 waves x 5 units (three workgroups per CU): 280 tokens = 18 units"),
+    ([40] * 8, "4 waves x 5 units: 320 tokens = 20 units exactly"),
+    ([20] * 17, "4-wave form: 17 queries > the pair's 16 (22 units: the 8-unit kernel)"),
     ([48] * 10, "4-wave form: 480 tokens = 30 units"),
     ([40] * 15, "4-wave form x 10 units: 600 tokens"),
     ([31] * 30, "8-wave form: 930 tokens = 59 units"),

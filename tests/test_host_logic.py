@@ -378,8 +378,9 @@ def test_the_launch_plan_is_the_ladder_design_md_describes():
     assert plan(n_q=1, lq=32) == (0, 2, 0, 1, 2) and plan(n_q=4, lq=32) == (0, 8, 0, 1, 8)         # K1s: the headline is 8 units
     assert plan(n_q=4, lq=20) == (0, 5, 0, 1, 5) and plan(lens=[25, 25, 25, 25]) == (0, 7, 0, 1, 7)  # real lengths: fewer units
     assert plan(n_q=4, lq=40) == (1, 2, 8, 1, 5)                                                    # 10 units: the pair form, 5 + 5
-    assert plan(n_q=8, lq=32) == (1, 2, 8, 1, 8) and plan(n_q=9, lq=32) == (1, 2, 10, 1, 9)          # pair; pair x 10 units (9 + 9)
-    assert plan(n_q=10, lq=32) == (1, 4, 8, 1, 5)                                                   # round 4: 5/5/5/5 on four waves
+    assert plan(n_q=8, lq=32) == (1, 2, 8, 1, 8)                                                    # pair form
+    assert plan(n_q=9, lq=32) == (1, 4, 5, 1, 5) and plan(n_q=10, lq=32) == (1, 4, 5, 1, 5)          # round 4: 17..20 units on four waves of <= 5 units,
+    assert plan(n_q=8, lq=40) == (1, 4, 5, 1, 5) and plan(n_q=11, lq=32) == (1, 4, 8, 1, 6)          # three workgroups per CU (168 registers); 22 units: the 8-unit kernel
     assert plan(n_q=16, lq=32) == (1, 4, 8, 1, 8) and plan(n_q=20, lq=32) == (1, 4, 10, 1, 10)
     assert plan(n_q=32, lq=32) == (1, 8, 8, 1, 8) and plan(n_q=40, lq=32) == (1, 8, 10, 1, 10)
     assert plan(n_q=1000, lq=32) == (1, 8, 8, 32, 8)                                                # 32 blocks: one round of an XCD's CUs
@@ -454,7 +455,7 @@ def test_fwd_workspace_bytes_reports_scratch_exactly_when_several_query_blocks_s
         return L.msim_fwd_workspace_bytes(dtype, n_q, lq, 1000, dim)
 
     # the plan (maxsim_abi.hip: flat_plan) works in 16-token units of the flat token matrix: one query block holds up to
-    # 256 / 320 / 512 / 640 / 1024 / 1280 tokens (pair, pair x 10 units, 4 waves, 4 x 10, 8 waves, 8 x 10) and 16 / 32 / 64 queries
+    # 256 / 320 / 512 / 640 / 1024 / 1280 tokens (pair, 4 waves x 5 units, 4 waves, 4 x 10, 8 waves, 8 x 10) and 16 / 32 / 64 queries
     assert ws(1, 32) == 0 and ws(4, 32) == 0                       # K1s
     assert ws(8, 32) == 0 and ws(16, 32) == 0 and ws(32, 32) == 0  # one query block (pair / 4-wave / 8-wave form)
     assert ws(17, 32) == 0 and ws(20, 32) == 0 and ws(33, 32) == 0 and ws(40, 32) == 0   # ONE block: ten units per wave (round 3's five tiles)
