@@ -321,6 +321,14 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
     // shape since
     const int forced = batch_nw_override();
     static const int forced_maxu = ab_env("MSIM_BATCH_MAXU", 0);      // 8 | 10 (measurement builds)
+#ifdef MSIM_AB
+    // measurement builds only (next lead): the five-unit instantiation of the PAIR form -- six pairs per CU
+    if (forced == 2 && forced_maxu == 5 && units <= 10 && n_q <= 16 && fill_blocks(hq, n_q, 2, 5, p.blk_q0) && p.n_blocks() == 1) {
+        p.nw = 2;
+        p.maxu = 5;
+        return MSIM_OK;
+    }
+#endif
     for (const auto &sh : shapes) {
         if (forced && sh[0] != forced) continue;
         if (forced_maxu && sh[1] != forced_maxu) continue;
@@ -362,7 +370,7 @@ template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
 int launch_batch(const FwdCall &c, const FlatPlan &plan) {
     auto kern = msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
     constexpr int lds = RING * (NW / 2) * msim::kSlabBytes + NW * MAXU * msim::kUnitTok * 16 + NW * 8 * 8;   // ring + the per-token max table + the queries' token ranges
-    constexpr int wg_per_cu = MAXU == 5 ? 3 : 8 / NW;       // the five-unit form: 168 registers, three workgroups per CU
+    constexpr int wg_per_cu = MAXU == 5 ? 12 / NW : 8 / NW;  // the five-unit form: 168 registers, three waves per SIMD (three 4-wave workgroups per CU)
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     // blockIdx -> (XCD = b % 8, slot = b / 8): the CUs of one XCD share a document range through its L2
@@ -465,6 +473,10 @@ int fwd_dispatch(const FwdCall &c) {
     }
 #ifdef MSIM_AB
     if (plan.nw == 2 && plan.maxu == 10) return launch_batch<F16, 2, 4, 2, 10>(c, plan);
+    if (plan.nw == 2 && plan.maxu == 5) {
+        static const int ring5p = ab_env("MSIM_BATCH_RING5", 2);
+        return ring5p == 3 ? launch_batch<F16, 2, 3, 2, 5>(c, plan) : launch_batch<F16, 2, 2, 2, 5>(c, plan);
+    }
 #endif
     if (plan.nw == 2) return launch_batch<F16, 2, 4, 2, 8>(c, plan);
     if (plan.nw == 4) return plan.maxu == 10 ? launch_batch<F16, 4, 3, 2, 10>(c, plan) : launch_batch<F16, 4, 3, 2, 8>(c, plan);
