@@ -29,6 +29,13 @@
 
 #include "../../include/maxsim.h"
 
+// (sanitizer builds define MSIM_HOST_NO_CLONES: an ifunc resolver runs before ThreadSanitizer's runtime is up)
+#ifdef MSIM_HOST_NO_CLONES
+#define MSIM_HOST_CLONES
+#else
+#define MSIM_HOST_CLONES __attribute__((target_clones("avx512f", "avx2,fma", "default")))
+#endif
+
 namespace {
 
 typedef float v16f __attribute__((vector_size(64)));
@@ -140,7 +147,7 @@ struct QueryBlock {
 // documents [c_lo, c_hi) against every query block: `df` = scratch for 8 widened rows (8 * dim floats), `tmaxv` = scratch for the block's
 // running maxima (n_tv vectors); `tok0[q]` = first token of query q inside its block.  A block's operands are ~128 KiB (256 tokens at
 // dim 128: L2-resident) and the block walks all the documents of the range before the next one starts.
-__attribute__((target_clones("avx512f", "avx2,fma", "default")))
+MSIM_HOST_CLONES
 void score_range(const HostCall &c, const float *qt, const QueryBlock *blocks, int n_blocks, const int *tok0, float *df, v16f *tmaxv,
                  int c_lo, int c_hi) {
     const int dim = c.dim;
@@ -212,7 +219,7 @@ void score_range(const HostCall &c, const float *qt, const QueryBlock *blocks, i
 
 // out[i, j] = <A_i, B_j> for the rows [b_lo, b_hi) of B: the same register blocking without the reduction (score_single_vector,
 // processing_utils.py:126 einsum("bd,cd->bc"))
-__attribute__((target_clones("avx512f", "avx2,fma", "default")))
+MSIM_HOST_CLONES
 void sim_range(int dtype, const float *af, int n_a, const void *B, int dim, float *out, int64_t ld, bool ref_round, float *dt, int b_lo,
                int b_hi) {
     for (int g = b_lo; g < b_hi; g += kRows) {
