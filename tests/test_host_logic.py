@@ -397,6 +397,32 @@ def test_the_launch_plan_is_the_ladder_design_md_describes():
     assert L.msim_fwd_plan(np.asarray([0, 1300], dtype=np.int32).ctypes.data, 1, 0, out.ctypes.data) == -2   # one query above a block
 
 
+def test_launch_plans_of_random_batches_respect_every_capacity():
+    """Invariants of flat_plan on 400 random batches (host-only): a wave never holds more units than the kernel is compiled for, the
+    blocks cover the tokens and respect the 8-lanes-per-query limit, K1s only takes <= 8 queries in <= 8 units."""
+    import numpy as np
+
+    L = colpali_amd._lib.lib()
+    rng = np.random.default_rng(7)
+    out = np.zeros(5, dtype=np.int32)
+    for _ in range(400):
+        n_q = int(rng.integers(1, 300))
+        hi = int(rng.choice([1, 8, 20, 48, 130, 700]))
+        lens = rng.integers(0, hi + 1, n_q).astype(np.int32)
+        off = np.zeros(n_q + 1, dtype=np.int32)
+        np.cumsum(lens, out=off[1:])
+        assert L.msim_fwd_plan(off.ctypes.data, n_q, 0, out.ctypes.data) == 0, L.msim_last_error()
+        kernel, a, maxu, blocks, heavy = (int(v) for v in out)
+        units = -(-int(off[-1]) // 16)
+        if kernel == 0:
+            assert n_q <= 8 and units <= 8 and a == max(units, 1) and blocks == 1
+        else:
+            nw = a
+            assert nw in (2, 4, 8) and maxu in (5, 8, 10) and 1 <= heavy <= maxu
+            assert blocks * nw * maxu >= units and blocks * nw * 8 >= n_q          # capacity in units and in queries
+            assert blocks == 1 or nw == 8                                            # several blocks only on the 8-wave form
+
+
 def test_loss_offset_and_pair_checks_run_before_any_device_work():
     from colpali_amd import loss as Lm
 
