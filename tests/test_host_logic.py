@@ -397,6 +397,24 @@ def test_the_launch_plan_is_the_ladder_design_md_describes():
     assert L.msim_fwd_plan(np.asarray([0, 1300], dtype=np.int32).ctypes.data, 1, 0, out.ctypes.data) == -2   # one query above a block
 
 
+def test_bench_counts_real_tokens_only():
+    """bench.py's roofline arithmetic for ragged batches: FLOP and bytes are those of the REAL query tokens -- padding an
+    implementation adds is never credited (round-3 review: every measured leg used Lq = 32, where that cannot show)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, lens, label = bench.parse_regime("1000xr12-48", 32)
+    assert n == 1000 and label == "U{12..48}" and min(lens) >= 12 and max(lens) <= 48
+    assert bench.parse_regime("1000xr12-48", 32)[1] == lens                      # seeded: the same batch every run
+    r = bench.regime_numbers(n, 32, 125000, 1024, 600.0, q_tokens=sum(lens))
+    assert r["flops_per_launch"] == 2.0 * sum(lens) * 125000 * 1024 * 128
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["flops_per_launch"] / 0.6 / 1e12 / 2500.0) < 1e-12
+    u = bench.regime_numbers(4, 32, 125000, 1024, 4.8)                          # the headline: HBM-bound, bytes = corpus + queries + scores
+    assert u["bound"] == "hbm" and u["algorithmic_bytes_per_launch"] == 125000 * 1024 * 256 + 4 * 32 * 256 + 4 * 125000 * 4
+
+
 def test_launch_plans_of_random_batches_respect_every_capacity():
     """Invariants of flat_plan on 400 random batches (host-only): a wave never holds more units than the kernel is compiled for, the
     blocks cover the tokens and respect the 8-lanes-per-query limit, K1s only takes <= 8 queries in <= 8 units."""
