@@ -3,9 +3,9 @@
 Every Col* model of the reference ends its forward with the same lines (e.g.
 colpali_engine/models/paligemma/colpali/modeling_colpali.py:65-78,
 colpali_engine/models/qwen2/colqwen2/modeling_colqwen2.py:59-75, and the same in colqwen2_5 / colqwen3 / colqwen3_5 /
-colgemma3 / colidefics3 / colmodernvbert / colqwen_omni):
+colgemma3 / colidefics3 / colqwen_omni):
 
-    proj = self.custom_text_proj(last_hidden_states)          # `self.linear` in ColIdefics3 / ColModernVBert
+    proj = self.custom_text_proj(last_hidden_states)          # `self.linear` in ColIdefics3
     proj = proj / proj.norm(dim=-1, keepdim=True)
     proj = proj * kwargs["attention_mask"].unsqueeze(-1)
     if "pixel_values" in kwargs and self.mask_non_image_embeddings:
@@ -20,8 +20,19 @@ a family's forward is restated here, so the wrapper serves every family, includi
 
 The wrapper steps aside (the reference's own lines run, untouched) whenever the fused kernel is not an exact stand-in:
 the projection is not a plain nn.Linear (a peft LoRA wrapper adds its own term), its output width is not 128, the weights
-are not bf16 / fp16 on the GPU, the hidden size is not a multiple of 64, autocast is active, or the call carries no
-attention_mask keyword.
+are not bf16 / fp16 on the GPU, the hidden size is not a multiple of 64, autocast is active, the call carries no
+attention_mask keyword -- or the forward is being traced by torch.compile (trainer/colmodel_torch_training.py:57-63 wraps the
+model in DDP and then in torch.compile(backend="inductor", dynamic=True)): a forward that ends by raising out of a module hook is
+not something dynamo can turn into a graph, and a C-ABI launch through ctypes is opaque to it, so under compilation the reference's
+own four lines are what inductor compiles (tests/test_gpu_models.py runs both wrappers on the real classes).
+
+Consequence, stated plainly: in the training configurations the reference SHIPS the fused head is
+bypassed -- scripts/configs/qwen2/train_colqwen2_model.yaml:62 puts a LoRA adapter on `custom_text_proj` (not a plain nn.Linear any
+more), the HF Trainer path runs under bf16 autocast, and the torch loop compiles the model.  The fused head and its backward serve
+inference / corpus building and full-fine-tuning loops in eager mode; the loss kernels are unaffected by any of this.
+
+ColModernVBert is NOT wrapped: its tail divides by `norm.clamp_min(1e-12)` (modeling_colmodernvbert.py:59), so a projection row that
+underflows to zero comes out 0 there and NaN from a kernel that divides by the unclamped norm (round-4 advisor finding).
 """
 from __future__ import annotations
 
@@ -32,8 +43,7 @@ import torch
 
 from .embed import HEAD_DIM, embedding_head
 
-MODEL_CLASS_NAMES = ("ColPali", "ColQwen2", "ColQwen2_5", "ColQwen3", "ColQwen3_5", "ColGemma3", "ColIdefics3", "ColModernVBert",
-                     "ColQwen2_5Omni")
+MODEL_CLASS_NAMES = ("ColPali", "ColQwen2", "ColQwen2_5", "ColQwen3", "ColQwen3_5", "ColGemma3", "ColIdefics3", "ColQwen2_5Omni")
 _PROJECTION_ATTRS = ("custom_text_proj", "linear")
 
 _originals: Dict[type, Callable] = {}
@@ -65,6 +75,8 @@ def _image_token_id(config):
 
 def _wrap(orig_forward: Callable) -> Callable:
     def forward(self, *args, **kwargs):
+        if torch.compiler.is_compiling():        # dynamo is tracing this forward: the reference's own lines are what gets compiled
+            return orig_forward(self, *args, **kwargs)
         lin = _projection(self)
         if lin is None or not _fusable(lin, kwargs):
             return orig_forward(self, *args, **kwargs)

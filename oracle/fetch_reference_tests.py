@@ -13,7 +13,10 @@ REF = os.environ.get("COLPALI_REFERENCE", "/root/reference")
 FILES = ("tests/utils/test_processing_utils.py", "tests/loss/test_li_losses.py")
 # the model files whose forward colpali_amd.patch_colpali_engine(models=True) wraps: the GPU tests and bench.py's "VLM in the loop"
 # leg run the REAL classes (random init), so these travel the same way -- verbatim, git-ignored, under tests/_reference_pkg/
-MODEL_FILES = ("colpali_engine/models/paligemma/colpali/modeling_colpali.py",
+MODEL_FILES = ("colpali_engine/loss/late_interaction_losses.py",         # bench.py: the reference's own loss module timed beside ours
+               "colpali_engine/utils/processing_utils.py",              # bench.py: cpu_baseline.kind = "reference"
+               "colpali_engine/utils/torch_utils.py",
+               "colpali_engine/models/paligemma/colpali/modeling_colpali.py",
                "colpali_engine/models/qwen2/colqwen2/modeling_colqwen2.py",
                "colpali_engine/models/qwen2_5/colqwen2_5/modeling_colqwen2_5.py",
                "colpali_engine/models/idefics3/colidefics3/modeling_colidefics3.py")

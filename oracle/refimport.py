@@ -39,6 +39,29 @@ def load():
     return BaseVisualRetrieverProcessor, late_interaction_losses
 
 
+def load_hot_path(allow_fetched: bool = True):
+    """(BaseVisualRetrieverProcessor, late_interaction_losses module, "live" | "fetched") from the reference checkout where it exists,
+    else from the verbatim git-ignored copies oracle/fetch_reference_tests.py leaves under tests/_reference_pkg/ (the GPU box).
+    bench.py times THESE as `cpu_baseline.kind = "reference"` and as the reference loss module on the same GPU."""
+    if available():
+        proc, losses = load()
+        return proc, losses, "live"
+    have = all(os.path.exists(os.path.join(FETCHED_ROOT, "colpali_engine", rel)) for rel in
+               ("loss/late_interaction_losses.py", "utils/processing_utils.py", "utils/torch_utils.py"))
+    if not (allow_fetched and have):
+        raise RuntimeError("no reference hot-path files: neither the checkout nor tests/_reference_pkg/ (oracle/fetch_reference_tests.py)")
+    sys.dont_write_bytecode = True
+    for name, sub in (("colpali_engine", ""), ("colpali_engine.loss", "loss"), ("colpali_engine.utils", "utils")):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [os.path.join(FETCHED_ROOT, "colpali_engine", sub)]
+            sys.modules[name] = pkg
+    from colpali_engine.loss import late_interaction_losses  # noqa: E402
+    from colpali_engine.utils.processing_utils import BaseVisualRetrieverProcessor  # noqa: E402
+
+    return BaseVisualRetrieverProcessor, late_interaction_losses, "fetched"
+
+
 def load_colpali_class():
     """The live reference's ColPali model class (random-init use only: no weights exist here).  The model
     sub-packages' __init__ files import every family, so they are stubbed the same way as the top-level package."""

@@ -90,3 +90,82 @@ def test_a_wrapped_projection_layer_keeps_the_reference_path(monkeypatch):
             assert torch.equal(model(**batch), want)
     finally:
         M.uninstall(cls)
+
+
+def test_patched_forward_under_torch_compile_traces_the_reference_lines_in_one_graph(monkeypatch):
+    """trainer/colmodel_torch_training.py:57-63 compiles the model (torch.compile(..., dynamic=True)).  The wrapper ends an eager
+    forward by raising out of a module hook -- not something dynamo can graph -- so while dynamo traces it steps aside and the
+    reference's own lines are compiled: one graph, no graph break, no recompilation on a second batch shape, the eager result.
+    Here with dynamo's `eager` backend (the tracing is what is under test; inductor itself runs in tests/test_gpu_models.py).
+    `_fusable` is forced to True so that the ONLY reason the head does not run is the compile check."""
+    import torch._dynamo as dynamo
+    from torch._dynamo.utils import counters
+
+    model, cls = tiny_colpali()
+    b1, b2 = text_batch(), text_batch(B=3, S=21, seed=9)
+    with torch.no_grad():
+        want1, want2 = model(**b1), model(**b2)
+    monkeypatch.setattr(M, "_fusable", lambda lin, kwargs: True)
+    monkeypatch.setattr(M, "embedding_head", lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused head reached under compile")))
+    M.install(cls)
+    try:
+        dynamo.reset()
+        counters.clear()
+        compiled = torch.compile(model, backend="eager", dynamic=True)
+        with torch.no_grad():
+            got1, got2 = compiled(**b1), compiled(**b2)
+        assert torch.equal(got1, want1) and torch.equal(got2, want2)
+        assert sum(counters["graph_break"].values()) == 0, dict(counters["graph_break"])
+        assert counters["stats"]["unique_graphs"] == 1, dict(counters["stats"])
+    finally:
+        M.uninstall()
+        dynamo.reset()
+
+
+def test_a_lora_style_projection_is_left_to_the_reference_lines_compiled_or_not(monkeypatch):
+    """scripts/configs/qwen2/train_colqwen2_model.yaml:62 targets `custom_text_proj` with LoRA: peft replaces the nn.Linear by a
+    wrapper module that adds its own term.  The fused head reads `.weight` only, so it must not run -- eager or compiled."""
+    import torch._dynamo as dynamo
+
+    class LoraLinear(torch.nn.Module):          # what peft's lora.Linear computes, in miniature
+        def __init__(self, base):
+            super().__init__()
+            self.base_layer = base
+            self.lora_A = torch.nn.Linear(base.in_features, 4, bias=False)
+            self.lora_B = torch.nn.Linear(4, base.out_features, bias=False)
+            self.in_features, self.out_features = base.in_features, base.out_features
+
+        @property
+        def weight(self):
+            return self.base_layer.weight
+
+        @property
+        def bias(self):
+            return self.base_layer.bias
+
+        def forward(self, x):
+            return self.base_layer(x) + self.lora_B(self.lora_A(x)) * 2.0
+
+    model, cls = tiny_colpali()
+    torch.manual_seed(3)
+    model.custom_text_proj = LoraLinear(model.custom_text_proj)
+    batch = text_batch()
+    with torch.no_grad():
+        want = model(**batch)
+    monkeypatch.setattr(M, "_fusable", lambda lin, kwargs: True)
+    monkeypatch.setattr(M, "embedding_head", lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused head ran on a LoRA projection")))
+    M.install(cls)
+    try:
+        with torch.no_grad():
+            assert torch.equal(model(**batch), want)
+            dynamo.reset()
+            assert torch.equal(torch.compile(model, backend="eager", dynamic=True)(**batch), want)
+    finally:
+        M.uninstall()
+        dynamo.reset()
+
+
+def test_colmodernvbert_is_not_wrapped():
+    """Its tail clamps the norm (modeling_colmodernvbert.py:59: `.clamp_min(1e-12)`): the fused head, which divides by the unclamped
+    norm, is not an exact stand-in for it (round-4 advisor finding)."""
+    assert "ColModernVBert" not in M.MODEL_CLASS_NAMES
