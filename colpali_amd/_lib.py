@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 def dtype_code(dtype) -> int:
@@ -100,9 +100,13 @@ def lib() -> ctypes.CDLL:
     L.msim_host_count_nonzero_rows.restype = i32
     L.msim_host_gather_nonzero_rows.argtypes = [vp, vp, vp, i64, vp, i64, i32]
     L.msim_host_gather_nonzero_rows.restype = i32
-    L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.msim_fwd_transposed.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, vp, i64, vp, vp]
+    L.msim_fwd_transposed.restype = i32
+    L.msim_host_gather_range.argtypes = [vp, vp, vp, i64, i64, i64, i32]
+    L.msim_host_gather_range.restype = i32
+    L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.msim_pairs_argmax.restype = i32
-    L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
     L.msim_pairs_bwd.restype = i32
     L.msim_pairs_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32]
     L.msim_pairs_bwd_workspace_bytes.restype = sz
@@ -129,9 +133,9 @@ def lib() -> ctypes.CDLL:
     L.msim_pool_cluster.restype = i32
     L.msim_pool_reduce.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.msim_pool_reduce.restype = i32
-    L.msim_loss_epilogue_workspace_bytes.argtypes = [i32]
+    L.msim_loss_epilogue_workspace_bytes.argtypes = [i32, i32]
     L.msim_loss_epilogue_workspace_bytes.restype = sz
-    L.msim_loss_epilogue.argtypes = [i32, vp, i64, i32, i32, vp, i32, i32, i32, i32, f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]
+    L.msim_loss_epilogue.argtypes = [i32, vp, i64, i32, i32, vp, i32, i32, i32, i32, f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.msim_loss_epilogue.restype = i32
     L.msim_host_gather.argtypes = [vp, vp, vp, vp, i64, i32]
     L.msim_host_gather.restype = i32

@@ -102,6 +102,7 @@ class _Staging:
         self.buf: Optional[torch.Tensor] = None
         self.events = [None, None]
         self.lock = threading.Lock()
+        self.next_half = 0
 
     def _halves(self, want: int):
         half = max(min(want, STAGING_BYTES // 2), 1 << 20)
@@ -180,8 +181,77 @@ class _Staging:
         return dev
 
 
+    def upload_image(self, srcs, prefix, n: int, dst_bytes: torch.Tensor, side_stream, on_chunk=None) -> None:
+        """The byte image of n host buffers (buffer i = image bytes prefix[i] .. prefix[i+1]-1 at address srcs[i]; numpy uint64 /
+        int64 arrays) -> `dst_bytes` (a uint8 device view of the same length), through the two pinned halves: native threads gather
+        chunk k + 1 into one half (msim_host_gather_range: a persistent pool, one call per chunk, nothing per page on the Python side)
+        while the other half is on its way to the GPU on `side_stream`.  The halves alternate ACROSS calls too, so back-to-back
+        uploads keep overlapping.  `on_chunk(bytes_uploaded_so_far)` runs after each chunk's copy has been issued (the caller
+        launches work on what has arrived: scoring.py)."""
+        total = int(prefix[n])
+        if total == 0:
+            return
+        L = _lib_mod.lib()
+        with self.lock:
+            half = self._halves(total)
+            base = self.buf.data_ptr()
+            for c0 in range(0, total, half):
+                c1 = min(total, c0 + half)
+                h = self.next_half
+                self.next_half ^= 1
+                if self.events[h] is not None:
+                    self.events[h].synchronize()          # the previous upload has left this half
+                rc = L.msim_host_gather_range(base + h * half, srcs.ctypes.data, prefix.ctypes.data, n, c0, c1, _COPY_THREADS)
+                if rc != 0:
+                    raise RuntimeError(f"msim_host_gather_range failed: {L.msim_host_last_error().decode()}")
+                with torch.cuda.stream(side_stream):
+                    dst_bytes[c0:c1].copy_(self.buf[h * half : h * half + (c1 - c0)], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side_stream)
+                self.events[h] = ev
+                if on_chunk is not None:
+                    on_chunk(c1)
+
+
 _staging = _Staging()
 _staging_q = _Staging()      # queries: a second buffer, so that packing the queries never waits for the corpus upload
+_copy_streams = {}
+
+
+def copy_stream(device: torch.device) -> torch.cuda.Stream:
+    """The side stream the drop-in's uploads run on (one per device): H2D copies of the next passage range overlap the scoring of
+    the previous one on the caller's stream."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _copy_streams.get(key)
+    if st is None:
+        st = _copy_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def host_list_image(ps: Sequence[torch.Tensor], what: str = "passages"):
+    """ONE pass over a list of host tensors: the reference's checks (2-D, one dtype, one width) and what the upload needs --
+    (keep-alive list, source addresses uint64 [n], rows int64 [n], dim, dtype) -- or None when a tensor does not live on the host.
+    (A thousand pages x a handful of attribute reads each is ~1 ms of Python: it is done once, not once per helper.)"""
+    import numpy as np
+
+    first = ps[0]
+    dtype, dim = first.dtype, (first.shape[1] if first.dim() == 2 else -1)
+    keep = []
+    for p in ps:
+        if p.dim() != 2:
+            raise ValueError(f"each {what[:-1]} must be 2-D (sequence_length, dim)")
+        if p.dtype != dtype:
+            raise RuntimeError(f"expected {what} of one dtype, got {dtype} and {p.dtype}")
+        if p.shape[1] != dim:
+            raise RuntimeError(f"expected {what} of one embedding width, got {dim} and {p.shape[1]}")
+        if p.device.type != "cpu":
+            return None
+        keep.append(p if p.is_contiguous() else p.contiguous())
+    _check_embeddings(first, what)
+    srcs = np.fromiter((t.data_ptr() for t in keep), dtype=np.uint64, count=len(keep))
+    rows = np.fromiter((t.shape[0] for t in keep), dtype=np.int64, count=len(keep))
+    return keep, srcs, rows, int(dim), dtype
 
 
 def _gather_rows(ps: Sequence[torch.Tensor], dim: int, device: torch.device) -> torch.Tensor:

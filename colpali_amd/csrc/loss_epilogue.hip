@@ -33,6 +33,7 @@ struct EpiArgs {
     int B, C, Lq;
     int q_row_bytes;         // bytes between consecutive query tokens (width * element size)
     int q_elem_bytes;        // 2 or 4
+    int q_is_f16;            // 2-byte elements: fp16 (1) or bf16 (0)
     int offset;
     int mode;
     int normalize, filter;
@@ -45,46 +46,77 @@ __device__ __forceinline__ unsigned long long epi_key(float v, int idx) {   // l
     return ((unsigned long long)u << 32) | (uint32_t)(0x7fffffff - idx);
 }
 
-template <class T, class F>
-__device__ __forceinline__ T epi_block_reduce(T v, F op, T *sh) {   // result valid in every thread
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// reduction over the threads that share one row: the whole workgroup (WAVE = false: barriers + LDS) or one wave (WAVE = true:
+// shuffles only, so different waves of a workgroup can work on different rows without meeting at a barrier)
+template <bool WAVE, class T, class F>
+__device__ __forceinline__ T epi_reduce(T v, F op, T *sh) {   // result valid in every thread of the group
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = op(v, (T)__shfl_xor(v, o));
-    __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    T r = sh[0];
+    if constexpr (WAVE) {
+        return v;
+    } else {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) sh[wave] = v;
+        __syncthreads();
+        T r = sh[0];
 #pragma unroll
-    for (int w = 1; w < kEpiThreads / 64; ++w) r = op(r, sh[w]);
-    return r;
+        for (int w = 1; w < kEpiThreads / 64; ++w) r = op(r, sh[w]);
+        return r;
+    }
 }
 
-__global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float *__restrict__ scores,      // [B, ld] raw MaxSim scores
-                                                                    const char *__restrict__ Q,            // [B, Lq, width]
-                                                                    float *__restrict__ G,                 // [B, ld] (InfoNCE) or null
-                                                                    int32_t *__restrict__ pairs,           // [2B, 2] (pairwise)
-                                                                    float *__restrict__ coef,              // [2B]
-                                                                    int32_t *__restrict__ order,           // [2B]
-                                                                    float *__restrict__ ws_rows,           // [3, B] scratch: loss, min, max
-                                                                    unsigned int *__restrict__ ticket,     // zero before the first launch; left zero
-                                                                    float *__restrict__ out,               // [3]: loss, min, max of the normalised scores
-                                                                    EpiArgs a) {
-    __shared__ unsigned long long sh_u64[kEpiThreads / 64];
-    __shared__ float sh_f[kEpiThreads / 64];
-    __shared__ int sh_i[kEpiThreads / 64];
-    __shared__ int sh_last;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float *srow = scores + (size_t)b * a.ld;
+struct EpiShared {
+    unsigned long long u64[kEpiThreads / 64];
+    float f[kEpiThreads / 64];
+    int i[kEpiThreads / 64];
+};
 
-    // ---- :296 lengths: query rows whose FIRST component is non-zero (-0.0 counts as zero, NaN as non-zero, like `!= 0`)
+struct EpiRow {
+    float loss, lo, hi;
+    int doc0, doc1;        // pairwise: the documents of the row's two pair-list entries (2b, 2b + 1)
+};
+
+// the loss in the embeddings' own dtype (what the reference returns: bf16 in -> bf16 scalar), one rounding of the fp32 value
+__device__ __forceinline__ void epi_store_loss(void *loss_out, int elem_bytes, bool f16, float v) {
+    if (loss_out == nullptr) return;
+    if (elem_bytes == 4) *static_cast<float *>(loss_out) = v;
+    else if (f16) *static_cast<_Float16 *>(loss_out) = (_Float16)v;
+    else *static_cast<__bf16 *>(loss_out) = (__bf16)v;
+}
+
+// One query row b, worked on by a group of `nthr` threads (this thread is number `tid` of it): lengths, bounds, the row's loss term,
+// its gradient entries (pairwise: the two pair-list entries 2b, 2b + 1; InfoNCE: row b of G).
+// :296 lengths: this thread's share of the query rows whose FIRST component is non-zero (-0.0 counts as zero, NaN as non-zero, like `!= 0`)
+__device__ __forceinline__ int epi_count_tokens(int b, int tid, int nthr, const char *__restrict__ Q, const EpiArgs &a) {
+    // eight independent loads in flight per thread: every token's first component is a cache line of its own, and a loop of
+    // load -> test -> add is one memory round trip per iteration (13 of them per lane for a 780-token page: 26 us of a 38 us launch)
+    constexpr int kInFlight = 8;
+    const char *base = Q + (size_t)b * a.Lq * a.q_row_bytes;
     int cnt = 0;
-    for (int n = tid; n < a.Lq; n += kEpiThreads) {
-        const char *p = Q + ((size_t)b * a.Lq + n) * a.q_row_bytes;
-        const uint32_t bits = a.q_elem_bytes == 2 ? ((uint32_t) * reinterpret_cast<const uint16_t *>(p) & 0x7fffu)
-                                                  : (*reinterpret_cast<const uint32_t *>(p) & 0x7fffffffu);
-        cnt += bits != 0;
+    for (int n0 = tid; n0 < a.Lq; n0 += nthr * kInFlight) {
+        uint32_t bits[kInFlight];
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+            const int n = n0 + j * nthr;
+            const char *p = base + (size_t)(n < a.Lq ? n : 0) * a.q_row_bytes;
+            bits[j] = a.q_elem_bytes == 2 ? ((uint32_t) * reinterpret_cast<const uint16_t *>(p) & 0x7fffu)
+                                          : (*reinterpret_cast<const uint32_t *>(p) & 0x7fffffffu);
+        }
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) cnt += (n0 + j * nthr < a.Lq) && bits[j] != 0;
     }
-    const int length = epi_block_reduce<int>(cnt, [](int x, int y) { return x + y; }, sh_i);
+    return cnt;
+}
+
+// `srow`: the row's C raw scores (global memory, or the copy the small-batch kernel keeps in LDS); `length_in` >= 0: the row's token
+// count if the caller has it already.
+template <bool WAVE>
+__device__ __forceinline__ EpiRow epi_row(int b, int tid, int nthr, const float *srow, int length_in, const char *__restrict__ Q,
+                                          float *__restrict__ G, int32_t *__restrict__ pairs, float *__restrict__ coef,
+                                          const EpiArgs &a, EpiShared *sh) {
+    int length = length_in;
+    if (length_in < 0) length = epi_reduce<WAVE, int>(epi_count_tokens(b, tid, nthr, Q, a), [](int x, int y) { return x + y; }, sh->i);
     const float len_f = (float)length;
     const int pos_idx = a.offset + b;
     auto norm = [&](float raw) { return a.normalize ? raw / len_f : raw; };
@@ -98,32 +130,33 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
 
     // ---- bounds of the normalised scores (the reference prints when they leave [-tol, 1 + tol], :62-70)
     float lo = INFINITY, hi = -INFINITY;
-    for (int c = tid; c < a.C; c += kEpiThreads) {
+    for (int c = tid; c < a.C; c += nthr) {
         const float s = norm(srow[c]);
         lo = fminf(lo, s);
         hi = fmaxf(hi, s);
     }
-    lo = epi_block_reduce<float>(lo, [](float x, float y) { return fminf(x, y); }, sh_f);
-    hi = epi_block_reduce<float>(hi, [](float x, float y) { return fmaxf(x, y); }, sh_f);
+    lo = epi_reduce<WAVE, float>(lo, [](float x, float y) { return fminf(x, y); }, sh->f);
+    hi = epi_reduce<WAVE, float>(hi, [](float x, float y) { return fmaxf(x, y); }, sh->f);
 
     float row_loss = 0.f;
+    int doc0 = 0, doc1 = 0;
     const float inv_B = 1.0f / (float)a.B;
     if (a.mode == kEpiPairwise) {
         // top-2 of the row: (value desc, index asc)
         unsigned long long k1 = 0;
-        for (int c = tid; c < a.C; c += kEpiThreads) {
+        for (int c = tid; c < a.C; c += nthr) {
             const unsigned long long k = epi_key(value(c), c);
             k1 = k > k1 ? k : k1;
         }
-        k1 = epi_block_reduce<unsigned long long>(k1, [](unsigned long long x, unsigned long long y) { return x > y ? x : y; }, sh_u64);
+        k1 = epi_reduce<WAVE, unsigned long long>(k1, [](unsigned long long x, unsigned long long y) { return x > y ? x : y; }, sh->u64);
         const int i1 = 0x7fffffff - (int)(uint32_t)k1;
         unsigned long long k2 = 0;
-        for (int c = tid; c < a.C; c += kEpiThreads) {
+        for (int c = tid; c < a.C; c += nthr) {
             if (c == i1) continue;
             const unsigned long long k = epi_key(value(c), c);
             k2 = k > k2 ? k : k2;
         }
-        k2 = epi_block_reduce<unsigned long long>(k2, [](unsigned long long x, unsigned long long y) { return x > y ? x : y; }, sh_u64);
+        k2 = epi_reduce<WAVE, unsigned long long>(k2, [](unsigned long long x, unsigned long long y) { return x > y ? x : y; }, sh->u64);
         const int i2 = 0x7fffffff - (int)(uint32_t)k2;
         const float v1 = value(i1), v2 = value(i2);
         const bool first_is_pos = v1 == pos;                              // :311 exact float equality
@@ -136,14 +169,16 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
         float c_neg = up, c_pos = -up;
         if (filtered(neg_idx, norm(srow[neg_idx]))) c_neg *= a.filter_factor;
         if (a.normalize) { c_neg /= len_f; c_pos /= len_f; }
+        const bool pos_first = pos_idx <= neg_idx;
+        doc0 = pos_first ? pos_idx : neg_idx;
+        doc1 = pos_first ? neg_idx : pos_idx;
         if (tid == 0) {
-            const bool pos_first = pos_idx <= neg_idx;
             const int e = 2 * b;
             pairs[2 * e] = b;
-            pairs[2 * e + 1] = pos_first ? pos_idx : neg_idx;
+            pairs[2 * e + 1] = doc0;
             coef[e] = pos_first ? c_pos : c_neg;
             pairs[2 * e + 2] = b;
-            pairs[2 * e + 3] = pos_first ? neg_idx : pos_idx;
+            pairs[2 * e + 3] = doc1;
             coef[e + 1] = pos_first ? c_neg : c_pos;
         }
     } else {
@@ -154,19 +189,19 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
         // relative precision, where exp(logit - lse) - 1 would return the rounding error of lse (~4e-6 at logits of 100).
         auto logit = [&](int c) { return __fmul_rn(value(c), a.inv_T); };
         float m = -INFINITY;
-        for (int c = tid; c < a.C; c += kEpiThreads) m = fmaxf(m, logit(c));
-        m = epi_block_reduce<float>(m, [](float x, float y) { return fmaxf(x, y); }, sh_f);
+        for (int c = tid; c < a.C; c += nthr) m = fmaxf(m, logit(c));
+        m = epi_reduce<WAVE, float>(m, [](float x, float y) { return fmaxf(x, y); }, sh->f);
         float se_others = 0.f;
-        for (int c = tid; c < a.C; c += kEpiThreads)
+        for (int c = tid; c < a.C; c += nthr)
             if (c != pos_idx) se_others += expf(logit(c) - m);
-        se_others = epi_block_reduce<float>(se_others, [](float x, float y) { return x + y; }, sh_f);
+        se_others = epi_reduce<WAVE, float>(se_others, [](float x, float y) { return x + y; }, sh->f);
         const float d_pos = logit(pos_idx) - m;
         const float se = se_others + expf(d_pos);
         row_loss = logf(se) - d_pos;
         if (G != nullptr) {
             float *grow = G + (size_t)b * a.ld;
             const float scale = a.inv_T * inv_B / se;
-            for (int c = tid; c < a.C; c += kEpiThreads) {
+            for (int c = tid; c < a.C; c += nthr) {
                 const float s = norm(srow[c]);
                 const bool f = filtered(c, s);
                 float g = (c == pos_idx ? -se_others : expf(logit(c) - m)) * scale;
@@ -176,12 +211,31 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
             }
         }
     }
+    return EpiRow{row_loss, lo, hi, doc0, doc1};
+}
+
+__global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float *__restrict__ scores,      // [B, ld] raw MaxSim scores
+                                                                    const char *__restrict__ Q,            // [B, Lq, width]
+                                                                    float *__restrict__ G,                 // [B, ld] (InfoNCE) or null
+                                                                    int32_t *__restrict__ pairs,           // [2B, 2] (pairwise)
+                                                                    float *__restrict__ coef,              // [2B]
+                                                                    int32_t *__restrict__ order,           // [2B]
+                                                                    float *__restrict__ ws_rows,           // [3, B] scratch: loss, min, max
+                                                                    unsigned int *__restrict__ ticket,     // zero before the first launch; left zero
+                                                                    float *__restrict__ out,               // [3]: loss, min, max of the normalised scores
+                                                                    void *__restrict__ loss_out,           // the loss in the embeddings' dtype, or null
+                                                                    const int32_t *__restrict__ lengths,   // [B] token counts, or null
+                                                                    EpiArgs a) {
+    __shared__ EpiShared sh;
+    __shared__ int sh_last;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const EpiRow r = epi_row<false>(b, tid, kEpiThreads, scores + (size_t)b * a.ld, lengths ? lengths[b] : -1, Q, G, pairs, coef, a, &sh);
 
     // ---- per-row terms -> scratch; the last workgroup to arrive folds them in row order
     if (tid == 0) {
-        ws_rows[b] = row_loss;
-        ws_rows[a.B + b] = lo;
-        ws_rows[2 * a.B + b] = hi;
+        ws_rows[b] = r.loss;
+        ws_rows[a.B + b] = r.lo;
+        ws_rows[2 * a.B + b] = r.hi;
         __threadfence();
         sh_last = atomicAdd(ticket, 1u) == (unsigned)(a.B - 1);
     }
@@ -190,14 +244,16 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
     __threadfence();
     if (tid == 0) {
         float s = 0.f, mn = INFINITY, mx = -INFINITY;
-        for (int r = 0; r < a.B; ++r) {
-            s += __builtin_nontemporal_load(ws_rows + r);
-            mn = fminf(mn, __builtin_nontemporal_load(ws_rows + a.B + r));
-            mx = fmaxf(mx, __builtin_nontemporal_load(ws_rows + 2 * a.B + r));
+        for (int i = 0; i < a.B; ++i) {
+            s += __builtin_nontemporal_load(ws_rows + i);
+            mn = fminf(mn, __builtin_nontemporal_load(ws_rows + a.B + i));
+            mx = fmaxf(mx, __builtin_nontemporal_load(ws_rows + 2 * a.B + i));
         }
+        const float inv_B = 1.0f / (float)a.B;
         out[0] = s * inv_B;
         out[1] = mn;
         out[2] = mx;
+        epi_store_loss(loss_out, a.q_elem_bytes, a.q_is_f16 != 0, s * inv_B);
         *ticket = 0;                                                     // ready for the next launch
     }
     if (a.mode == kEpiPairwise) {
@@ -208,6 +264,110 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
             int rank = 0;
             for (int o = 0; o < n; ++o) {
                 const int d_o = __builtin_nontemporal_load(pairs + 2 * o + 1);
+                rank += (d_o < de) || (d_o == de && o < e);
+            }
+            order[rank] = e;
+        }
+    }
+}
+
+// ---- the same for SMALL batches (B <= kEpiSmallRows rows, B * C scores that one workgroup reads in a few microseconds -- BASELINE
+// config 5: 32 x 256): ONE workgroup of 16 waves.  Phase 1, one round trip to memory: the whole score matrix is copied into LDS (when
+// it fits kEpiStageFloats) and every wave counts the tokens of its rows.  Phase 2: one wave per row at a time (shuffle reductions
+// only), every pass over the row out of LDS; the per-row terms stay in LDS, one barrier, and the fold / the by-document permutation
+// read them from there.  No ticket, no scratch, no fence.  (History, rocprofv3 on the 150 us loss step of round 5: the multi-workgroup
+// form spent 19 us here -- a lone thread walking the per-row terms and the pair list in global memory; the first one-workgroup form
+// still 16 us -- each of its eight passes over a row was a dependent round trip to L2.)
+constexpr int kEpiSmallThreads = 1024;
+constexpr int kEpiSmallRows = 1024;
+constexpr int kEpiStageFloats = 24576;          // 96 KiB of dynamic LDS
+
+__global__ __launch_bounds__(kEpiSmallThreads) void loss_epilogue_small_kernel(const float *__restrict__ scores, const char *__restrict__ Q,
+                                                                               const int32_t *__restrict__ lengths,   // [B] token counts, or null: counted here
+                                                                               float *__restrict__ G, int32_t *__restrict__ pairs,
+                                                                               float *__restrict__ coef, int32_t *__restrict__ order,
+                                                                               float *__restrict__ out, void *__restrict__ loss_out, EpiArgs a,
+                                                                               int staged) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];            // [B][C] when `staged`
+    __shared__ float row_loss[kEpiSmallRows], row_lo[kEpiSmallRows], row_hi[kEpiSmallRows];
+    __shared__ int pair_doc[2 * kEpiSmallRows];
+    __shared__ int row_len[kEpiSmallRows];
+    __shared__ EpiShared unused;                    // the wave-level reductions never touch it
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kEpiSmallThreads / 64;
+    if (staged) {
+        // the whole matrix in one round trip: up to eight loads in flight per thread before the first LDS write
+        constexpr int kInFlight = 8;
+        const int n = a.B * a.C;
+        for (int i0 = tid; i0 < n; i0 += kEpiSmallThreads * kInFlight) {
+            float v[kInFlight];
+#pragma unroll
+            for (int j = 0; j < kInFlight; ++j) {
+                const int i = i0 + j * kEpiSmallThreads;
+                const int ic = i < n ? i : 0;
+                const int r = ic / a.C, c = ic - r * a.C;
+                v[j] = scores[(size_t)r * a.ld + c];
+            }
+#pragma unroll
+            for (int j = 0; j < kInFlight; ++j) {
+                const int i = i0 + j * kEpiSmallThreads;
+                if (i < n) stage[i] = v[j];
+            }
+        }
+    }
+    if (lengths != nullptr) {
+        for (int b = tid; b < a.B; b += kEpiSmallThreads) row_len[b] = lengths[b];
+    } else {
+        for (int b = wave; b < a.B; b += kWaves) {
+            int cnt = epi_count_tokens(b, lane, 64, Q, a);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0) row_len[b] = cnt;
+        }
+    }
+    __syncthreads();
+    for (int b = wave; b < a.B; b += kWaves) {
+        const float *srow = staged ? stage + (size_t)b * a.C : scores + (size_t)b * a.ld;
+        const EpiRow r = epi_row<true>(b, lane, 64, srow, row_len[b], Q, G, pairs, coef, a, &unused);
+        if (lane == 0) {
+            row_loss[b] = r.loss;
+            row_lo[b] = r.lo;
+            row_hi[b] = r.hi;
+            pair_doc[2 * b] = r.doc0;
+            pair_doc[2 * b + 1] = r.doc1;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // the mean over the rows: lane l adds rows l, l + 64, ... in that order, then a fixed butterfly -- an order that depends on B alone
+        float s = 0.f, mn = INFINITY, mx = -INFINITY;
+        for (int i = lane; i < a.B; i += 64) {
+            s += row_loss[i];
+            mn = fminf(mn, row_lo[i]);
+            mx = fmaxf(mx, row_hi[i]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            mn = fminf(mn, __shfl_xor(mn, o));
+            mx = fmaxf(mx, __shfl_xor(mx, o));
+        }
+        if (lane == 0) {
+            const float inv_B = 1.0f / (float)a.B;
+            out[0] = s * inv_B;
+            out[1] = mn;
+            out[2] = mx;
+            epi_store_loss(loss_out, a.q_elem_bytes, a.q_is_f16 != 0, s * inv_B);
+        }
+    }
+    if (a.mode == kEpiPairwise) {
+        const int n = 2 * a.B;
+        for (int e = tid; e < n; e += kEpiSmallThreads) {
+            const int de = pair_doc[e];
+            int rank = 0;
+#pragma unroll 8
+            for (int o = 0; o < n; ++o) {
+                const int d_o = pair_doc[o];
                 rank += (d_o < de) || (d_o == de && o < e);
             }
             order[rank] = e;

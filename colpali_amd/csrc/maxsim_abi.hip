@@ -15,6 +15,7 @@
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
+#include "maxsim_batch_t.hip"
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
 #include "maxsim_bwd.hip"
@@ -141,6 +142,7 @@ struct FwdCall {
     const int32_t *q_off = nullptr;        // device: token offsets [n_q + 1]; null = uniform queries of Lq tokens
     const int32_t *q_off_host = nullptr;   // the same numbers on the host: the plan below is made from them
     int seg = 0, n_seg = 1;                // uniform long queries: n_q counts PIECES of `seg` tokens (FlatQ::n_seg)
+    int avg_rows = 0;                      // the caller's hint: average rows per document (MSIM_FLAG_AVG_ROWS), 0 = unknown
 };
 
 constexpr size_t kFwdWorkspaceBytes = 4096;   // K1b's convoy counters: n_ranges * n_qblocks <= 8 * 64 ints
@@ -391,13 +393,22 @@ int launch_batch(const FwdCall &c, const FlatPlan &plan) {
         // of slots (blocks x ranges) should fill whole rounds of the XCD's resident workgroups -- 40 blocks on 32 CUs in ONE range each
         // are two rounds, the second a quarter full (round 4, 1000 queries x 40 tokens: 1125 ms; four ranges = 160 slots = five full
         // rounds); 20 blocks in one range leave 12 of 32 CUs idle.  Smallest number of ranges whose last round is >= 97 % full, else
-        // the fullest; never ranges of fewer than ~64 documents.
+        // the fullest; never ranges of fewer than two documents.
+        // a range costs its workgroup a prologue (the block's 64 units: 256 KiB out of L2) whatever its size, so it should hold ~2000
+        // rows.  The host does not see the row offsets: without the caller's hint (MSIM_FLAG_AVG_ROWS) that is taken as 64 documents.
+        // (Round 5: with that floor alone a 1000-page corpus of 1030-row pages -- the drop-in call of BASELINE config 2 -- got ONE range
+        // per XCD: 4 query blocks x 8 ranges = 32 workgroups on 256 CUs.)
+        int min_docs = 64;
+        if (c.avg_rows > 0) {
+            min_docs = (2048 + c.avg_rows - 1) / c.avg_rows;
+            min_docs = min_docs < 2 ? 2 : (min_docs > 64 ? 64 : min_docs);
+        }
         int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
         if (a.n_qblocks > 1) {
             double best = 0.0;
             int best_sub = 1;
             for (int s = 1; s <= 32; ++s) {
-                if (s > 1 && (long long)8 * s * 64 > c.n_d) break;
+                if (s > 1 && (long long)8 * s * min_docs > c.n_d) break;
                 const long long slots_x = (long long)a.n_qblocks * s;
                 const long long rounds = (slots_x + cus_per_xcd - 1) / cus_per_xcd;
                 const double eff = (double)slots_x / (double)(rounds * cus_per_xcd);
@@ -491,74 +502,150 @@ size_t flat_workspace_bytes(const HostQ &hq, int n_q) {
     return (!plan.stream && plan.n_blocks() > 1) ? kFwdWorkspaceBytes : 0;
 }
 
-template <int TPQ, bool F16>
+template <int TPQ, bool F16, int WPP>
 int launch_pairs_argmax(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                         const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                         const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ, F16>;
-    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes;
+    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ, F16, WPP>;
+    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes + (WPP > 1 ? 4 * TPQ * msim::kTokTile * 8 : 0);
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
-    const int wg_needed = (a.n_pairs + 3) / 4;
+    const int wg_needed = WPP > 1 ? a.n_pairs : (a.n_pairs + 3) / 4;
     const int wg_cap = di.cus * (di.lds_per_cu / lds);
     hipLaunchKernelGGL(kern, dim3(wg_needed < wg_cap ? wg_needed : wg_cap), dim3(256), lds, st, Q, D, d_off, clamp0, pairs,
                        out_scores, out_argmax, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_argmax_kernel<%d> launch: %s", TPQ, hipGetErrorString(e));
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_argmax_kernel<%d,%d> launch: %s", TPQ, WPP, hipGetErrorString(e));
     return MSIM_OK;
 }
+
+// short pair lists (the 2B pairs of the pairwise loss): one workgroup per pair, four waves sharing the document (latency);
+// long lists: one wave per pair (throughput)
+constexpr int kPairsSplitMax = 1024;
 
 template <bool F16>
 int pairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                           const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                           const DeviceInfo &di, hipStream_t st) {
+    if (a.n_pairs <= kPairsSplitMax) {
+        switch (tpq) {
+            case 1: return launch_pairs_argmax<1, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            case 2: return launch_pairs_argmax<2, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            case 3: return launch_pairs_argmax<3, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            default: return launch_pairs_argmax<4, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        }
+    }
     switch (tpq) {
-        case 1: return launch_pairs_argmax<1, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
-        case 2: return launch_pairs_argmax<2, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
-        case 3: return launch_pairs_argmax<3, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
-        default: return launch_pairs_argmax<4, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 1: return launch_pairs_argmax<1, F16, 1>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 2: return launch_pairs_argmax<2, F16, 1>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 3: return launch_pairs_argmax<3, F16, 1>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        default: return launch_pairs_argmax<4, F16, 1>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+    }
+}
+
+// long queries against short documents (the trainer's symmetric direction): the transposed pair kernel, one workgroup per pair
+template <int TPD, bool F16>
+int launch_pairs_argmax_t(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
+                          const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
+                          const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_pairs_argmax_t_kernel<TPD, F16>;
+    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes + 16;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    const int wg_cap = 4 * di.cus * (di.lds_per_cu / lds);        // a few rounds of resident workgroups; the kernel strides beyond
+    hipLaunchKernelGGL(kern, dim3(a.n_pairs < wg_cap ? a.n_pairs : wg_cap), dim3(256), lds, st, Q, D, d_off, clamp0, pairs,
+                       out_scores, out_argmax, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_argmax_t_kernel<%d> launch: %s", TPD, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <bool F16>
+int pairs_argmax_t_dispatch(int tpd, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
+                            const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
+                            const DeviceInfo &di, hipStream_t st) {
+    switch (tpd) {
+        case 1: return launch_pairs_argmax_t<1, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 2: return launch_pairs_argmax_t<2, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        default: return launch_pairs_argmax_t<4, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
     }
 }
 
 // dD for SHORT documents with LONG entry lists (the trainer's symmetric direction: maxsim_bwd.hip, dense form): number of splits of
 // every document's pair list, 0 = use the row-range kernel.  A function of the sizes alone (host side, no device read).
-int dd_dense_splits(int n_pairs, int Lq, int n_d, int max_doc_rows, int cus) {
-    if (n_d <= 0 || n_pairs <= 0 || max_doc_rows <= 0 || max_doc_rows > msim::kBwdRows) return 0;
+struct DdPlan {
+    int mode = 0;          // 0: the row-range kernel; 1: dense, per (document, split); 2: dense, per (pair, split)
+    int splits = 0;
+    size_t bytes = 0;      // scratch
+};
+
+DdPlan dd_plan(int n_pairs, int Lq, int n_d, int dim, int max_doc_rows, int cus) {
+    DdPlan pl;
+    if (n_d <= 0 || n_pairs <= 0 || max_doc_rows <= 0 || max_doc_rows > msim::kBwdRows || dim <= 0) return pl;
     const long long entries_per_doc = (long long)n_pairs * Lq / n_d;
-    if (entries_per_doc < 1024) return 0;                        // the row-range kernel is fine: few entries per document
-    int splits = (4 * cus + n_d - 1) / n_d;                       // ~4 workgroups per CU (16-32 KiB of LDS each)
-    const long long by_work = entries_per_doc / 256;              // at least 256 (pair, token) entries per split
-    if (splits > by_work) splits = (int)by_work;
-    if (splits > 64) splits = 64;
-    return splits < 1 ? 1 : splits;
+    if (entries_per_doc >= 1024) {                                // long lists on average: the dense upstream gradient of ColbertLoss
+        int splits = (4 * cus + n_d - 1) / n_d;                   // ~4 workgroups per CU (16-32 KiB of LDS each)
+        const long long by_work = entries_per_doc / 256;          // at least 256 (pair, token) entries per split
+        if (splits > by_work) splits = (int)by_work;
+        if (splits > 64) splits = 64;
+        pl.mode = 1;
+        pl.splits = splits < 1 ? 1 : splits;
+        pl.bytes = (size_t)pl.splits * n_d * max_doc_rows * dim * sizeof(float);
+    } else if (Lq >= 256) {
+        // few pairs, but each brings a long list to ITS document (the pairwise loss in the symmetric direction: 2B pairs of 780 tokens
+        // over 256 documents -- 195 entries per document on average, 780 or more for the <= 2B documents that have any): the row-range
+        // kernel walked those 780 entries as three rounds of dependent gathers on ONE workgroup per document, 159 us of a 370 us step.
+        // One workgroup per (pair, split of ~64 tokens): every step of the walk is a dependent gather, so few of them per workgroup
+        pl.mode = 2;
+        pl.splits = Lq / 64 > 16 ? 16 : Lq / 64;
+        pl.bytes = (size_t)pl.splits * n_pairs * max_doc_rows * dim * sizeof(float);
+    }
+    if (pl.bytes > ((size_t)256 << 20)) pl = DdPlan{};            // scratch stays bounded: the row-range kernel serves the rest
+    return pl;
 }
 
-template <int DT>
-void launch_dd_dense(const char *Q, const int32_t *d_off, int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc,
-                     const float *g, const int32_t *argmax, float *dD, float *partial, const msim::PairsArgs &a, int dim, int splits,
-                     hipStream_t st) {
-    const int lds = 2 * max_doc_rows * 128 * (int)sizeof(float);  // <= 64 KiB
-    hipLaunchKernelGGL(msim::maxsim_bwd_dd_dense_kernel<DT>, dim3(a.n_d, splits, (dim + 127) / 128), dim3(256), lds, st, Q, d_off,
-                       pairs, order_by_doc, g, argmax, partial, a, dim, max_doc_rows, splits);
-    hipLaunchKernelGGL(msim::maxsim_bwd_dd_sum_kernel, dim3(a.n_d, (max_doc_rows * dim + 255) / 256), dim3(256), 0, st, partial, d_off, dD,
-                       a.n_d, dim, max_doc_rows, splits);
-}
-
-template <bool F16>
-void launch_pairs_bwd(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
-                      const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
-                      const msim::PairsArgs &a, hipStream_t st, float *partial = nullptr, int splits = 0) {
-    constexpr int DT = F16 ? msim::kDtypeF16 : msim::kDtypeBf16;
-    const char *q = reinterpret_cast<const char *>(Q), *d = reinterpret_cast<const char *>(D);
-    if (a.n_q > 0 && a.Lq > 0)
-        hipLaunchKernelGGL(msim::maxsim_bwd_dq_kernel<DT>, dim3((a.n_q * a.Lq + 3) / 4), dim3(256), 0, st, d, d_off, pairs, g, argmax,
-                           dQ, a, msim::kDim * 2);
+// every gradient kernel of one msim_pairs_bwd call; OUT16: dQ / dD in the embeddings' own 16-bit dtype
+template <int DT, bool OUT16>
+void launch_bwd_kernels(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
+                        const int32_t *order_by_doc, const float *g, const int32_t *argmax, void *dQ, void *dD,
+                        const msim::PairsArgs &a, int dim, int cus, hipStream_t st, float *partial, const DdPlan &pl, msim::GScale gs) {
+    const int row_bytes = dim * msim::elem_size<DT>();
+    if (a.n_q > 0 && a.Lq > 0) {
+        // tokens per wave: the pair-range lookup is per wave, so few waves per query once there are more tokens than the chip has waves
+        const long long tokens = (long long)a.n_q * a.Lq;
+        int tpw = (int)((tokens + 4095) / 4096);
+        tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
+        const int chunks = (a.Lq + 4 * tpw - 1) / (4 * tpw);
+        hipLaunchKernelGGL((msim::maxsim_bwd_dq_kernel<DT, OUT16>), dim3((unsigned)a.n_q * chunks), dim3(256), 0, st, D, d_off, pairs, g,
+                           argmax, dQ, a, row_bytes, tpw, gs);
+    }
     const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
-    if (a.n_d > 0 && ry > 0 && splits > 0 && partial)
-        launch_dd_dense<DT>(q, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dD, partial, a, msim::kDim, splits, st);
-    else if (a.n_d > 0 && ry > 0)
-        hipLaunchKernelGGL(msim::maxsim_bwd_dd_kernel<DT>, dim3(a.n_d, ry, 1), dim3(256), 0, st, q, d_off, pairs, order_by_doc, g,
-                           argmax, dD, a, msim::kDim);
+    const int zc = (dim + 127) / 128;
+    if (a.n_d <= 0 || ry <= 0) return;
+    const int splits = pl.splits;
+    if (pl.mode == 2 && partial) {
+        const int lds = 2 * max_doc_rows * 128 * (int)sizeof(float);  // <= 64 KiB
+        hipLaunchKernelGGL(msim::maxsim_bwd_dd_pairs_kernel<DT>, dim3(a.n_pairs, splits, zc), dim3(256), lds, st, Q, d_off, pairs, order_by_doc,
+                           g, argmax, partial, a, dim, max_doc_rows, splits, gs);
+        const int per_wg = 256 * (OUT16 ? 2 : 1);                     // one step per thread
+        hipLaunchKernelGGL((msim::maxsim_bwd_dd_pairsum_kernel<DT, OUT16>), dim3(a.n_d, (max_doc_rows * dim + per_wg - 1) / per_wg), dim3(256), 0,
+                           st, partial, d_off, pairs, order_by_doc, dD, a.n_pairs, dim, max_doc_rows, splits);
+        return;
+    }
+    if (pl.mode == 1 && partial) {
+        const int lds = 2 * max_doc_rows * 128 * (int)sizeof(float);  // <= 64 KiB
+        hipLaunchKernelGGL(msim::maxsim_bwd_dd_dense_kernel<DT>, dim3(a.n_d, splits, zc), dim3(256), lds, st, Q, d_off, pairs, order_by_doc,
+                           g, argmax, partial, a, dim, max_doc_rows, splits, gs);
+        const int per_thread = OUT16 ? 2 : 1;
+        hipLaunchKernelGGL((msim::maxsim_bwd_dd_sum_kernel<DT, OUT16>), dim3(a.n_d, (max_doc_rows * dim + 256 * per_thread - 1) / (256 * per_thread)),
+                           dim3(256), 0, st, partial, d_off, pairs, order_by_doc, dD, a.n_d, a.n_pairs, dim, max_doc_rows, splits);
+        return;
+    }
+    // row ranges per workgroup: about eight workgroups per CU in total (each looks its document's pair range up once)
+    int gy = (8 * cus + a.n_d - 1) / a.n_d;
+    gy = gy < 1 ? 1 : (gy > ry ? ry : gy);
+    hipLaunchKernelGGL((msim::maxsim_bwd_dd_kernel<DT, OUT16>), dim3(a.n_d, gy, zc), dim3(256), 0, st, Q, d_off, pairs, order_by_doc, g,
+                       argmax, dD, a, dim, gs);
 }
 
 // ---------------------------------------------------------------- generic kernels (K1g)
@@ -636,20 +723,6 @@ int generic_pairs_argmax(const char *Q, const char *D, const int32_t *d_off, con
     return MSIM_OK;
 }
 
-template <int DT>
-void generic_pairs_bwd(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
-                       const int32_t *order_by_doc, const float *g, const int32_t *argmax, float *dQ, float *dD,
-                       const msim::PairsArgs &a, int dim, hipStream_t st, float *partial = nullptr, int splits = 0) {
-    if (a.n_q > 0 && a.Lq > 0)
-        hipLaunchKernelGGL(msim::maxsim_bwd_dq_kernel<DT>, dim3((a.n_q * a.Lq + 3) / 4), dim3(256), 0, st, D, d_off, pairs, g, argmax,
-                           dQ, a, dim * msim::elem_size<DT>());
-    const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
-    if (a.n_d > 0 && ry > 0 && splits > 0 && partial)
-        launch_dd_dense<DT>(Q, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dD, partial, a, dim, splits, st);
-    else if (a.n_d > 0 && ry > 0)
-        hipLaunchKernelGGL(msim::maxsim_bwd_dd_kernel<DT>, dim3(a.n_d, ry, (dim + 127) / 128), dim3(256), 0, st, Q, d_off, pairs,
-                           order_by_doc, g, argmax, dD, a, dim);
-}
 
 // ---------------------------------------------------------------- smooth-max (tau * logsumexp) kernels
 int check_smooth(const void *Q, const void *D, const int32_t *d_off, int dtype, int dim, int Lq, float tau) {
@@ -949,6 +1022,8 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
     if ((reinterpret_cast<uintptr_t>(Qt) | reinterpret_cast<uintptr_t>(D)) & 15) return fail(MSIM_EINVAL, "Qt and D must be 16-byte aligned");
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
     if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
+    const int avg_rows = (int)((flags >> 8) & 0xffffu);          // MSIM_FLAG_AVG_ROWS(n): a launch-shape hint, never a result
+    flags &= ~(0xffffu << 8);
     if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
     if (q_off_host[0] != 0) return fail(MSIM_EINVAL, "q_off[0] must be 0");
     for (int i = 0; i < n_q; ++i)
@@ -969,6 +1044,7 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
     c.workspace = workspace;
     c.q_off = q_off;
     c.q_off_host = q_off_host;
+    c.avg_rows = avg_rows;
     return dtype == MSIM_DTYPE_F16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c);
 }
 
@@ -979,6 +1055,8 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
     if (!scores) return fail(MSIM_EINVAL, "null pointer argument");
     if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
     if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores=%lld < n_d=%d", (long long)ld_scores, n_d);
+    const int avg_rows = (int)((flags >> 8) & 0xffffu);          // MSIM_FLAG_AVG_ROWS(n): a launch-shape hint, never a result
+    flags &= ~(0xffffu << 8);
     if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
     {
         const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
@@ -995,6 +1073,7 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
             c.Lq = Lq;
             c.n_d = n_d;
             c.flags = flags;
+    c.avg_rows = avg_rows;
             c.st = static_cast<hipStream_t>(stream);
             return dtype == MSIM_DTYPE_F16 ? panels_dispatch<true>(c) : panels_dispatch<false>(c);
         }
@@ -1019,6 +1098,7 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
         c.Lq = Lq;
         c.n_d = n_d;
         c.flags = flags | msim::kFlagPartial;
+        c.avg_rows = avg_rows;
         c.st = static_cast<hipStream_t>(stream);
         c.workspace = workspace;
         c.seg = kLongSegRows;
@@ -1071,16 +1151,80 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
     c.Lq = Lq;
     c.n_d = n_d;
     c.flags = flags;
+    c.avg_rows = avg_rows;
     c.st = static_cast<hipStream_t>(stream);
     c.workspace = workspace;
     return dtype == MSIM_DTYPE_F16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c);
 }
 
+// ---------------------------------------------------------------- K1t: long queries x short documents, all pairs
+}  // extern "C"
+
+namespace {
+template <bool F16, int U, int DPW>
+int launch_batch_t(const uint16_t *Q, const uint16_t *D, float *scores, int32_t *q_lengths, msim::BatchTArgs a, const DeviceInfo &di,
+                   hipStream_t st) {
+    auto kern = msim::maxsim_batch_t_kernel<F16, U, DPW>;
+    constexpr int lds = 3 * 4 * msim::kSlabBytes;                  // 96 KiB ring
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    a.n_blocks = (a.n_d + 8 * DPW - 1) / (8 * DPW);
+    // page slots per XCD: every page its own slot until the launch holds ~4 workgroups per CU, then the workgroups walk pages
+    int slots_p = (a.n_q + 7) / 8;
+    const int cap = (4 * di.cus / 8 + a.n_blocks - 1) / a.n_blocks;
+    if (slots_p > cap) slots_p = cap < 1 ? 1 : cap;
+    a.slots_p = slots_p;
+    a.n_slots = slots_p * a.n_blocks;
+    hipLaunchKernelGGL(kern, dim3(8 * a.n_slots), dim3(512), lds, st, Q, D, scores, q_lengths, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_t_kernel<%d,%d> launch: %s", U, DPW, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <bool F16>
+int batch_t_dispatch(int units, const uint16_t *Q, const uint16_t *D, float *scores, int32_t *ql, const msim::BatchTArgs &a,
+                     const DeviceInfo &di, hipStream_t st) {
+    if (units <= 1) return launch_batch_t<F16, 1, 8>(Q, D, scores, ql, a, di, st);
+    if (units == 2) return launch_batch_t<F16, 2, 4>(Q, D, scores, ql, a, di, st);
+    if (units == 3) return launch_batch_t<F16, 3, 2>(Q, D, scores, ql, a, di, st);
+    if (units == 4) return launch_batch_t<F16, 4, 2>(Q, D, scores, ql, a, di, st);
+    return launch_batch_t<F16, 8, 1>(Q, D, scores, ql, a, di, st);
+}
+}  // namespace
+
+extern "C" {
+
+int msim_fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim, float *scores,
+                        int64_t ld_scores, int32_t *q_lengths, void *stream) {
+    if (n_q < 0 || n_d < 0 || Lq <= 0 || Ld <= 0) return fail(MSIM_EINVAL, "negative or empty size");
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!Q || !D || !scores) return fail(MSIM_EINVAL, "null pointer argument");
+    if ((dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16) || dim != msim::kDim)
+        return fail(MSIM_EUNSUPPORTED, "msim_fwd_transposed takes bf16 / f16 embeddings of width %d", msim::kDim);
+    if (Ld > 8 * msim::kUnitTok) return fail(MSIM_EUNSUPPORTED, "resident documents of at most %d rows (got %d)", 8 * msim::kUnitTok, Ld);
+    if ((long long)Lq * msim::kRowBytes >= (1ll << 31)) return fail(MSIM_EUNSUPPORTED, "queries of %d rows", Lq);
+    if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores < n_d");
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15) return fail(MSIM_EINVAL, "embeddings must be 16-byte aligned");
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    msim::BatchTArgs a{};
+    a.ld = ld_scores;
+    a.n_q = n_q;
+    a.Lq = Lq;
+    a.n_d = n_d;
+    a.Ld = Ld;
+    const int units = (Ld + msim::kUnitTok - 1) / msim::kUnitTok;
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == MSIM_DTYPE_F16 ? batch_t_dispatch<true>(units, q, d, scores, q_lengths, a, *di, st)
+                                   : batch_t_dispatch<false>(units, q, d, scores, q_lengths, a, *di, st);
+}
+
 // ---------------------------------------------------------------- pair lists (training losses)
 int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off,
-                      const uint8_t *d_clamp0, int n_d, int dim, const int32_t *pairs, int n_pairs,
+                      const uint8_t *d_clamp0, int n_d, int dim, int max_doc_rows, const int32_t *pairs, int n_pairs,
                       float *out_scores, int32_t *out_argmax, void *stream) {
-    if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0) return fail(MSIM_EINVAL, "negative size");
+    if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
     if (n_pairs == 0) return MSIM_OK;
     if (!pairs) return fail(MSIM_EINVAL, "null pointer argument");
     if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
@@ -1089,6 +1233,15 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, 
     const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
+    // long queries x short documents in the tuned dtype / width (pages as queries, the trainer's symmetric direction): transposed form
+    if (dtype != MSIM_DTYPE_F32 && dim == msim::kDim && Lq > kLongSegRows && max_doc_rows > 0 && max_doc_rows <= 4 * msim::kTokTile &&
+        (long long)Lq * msim::kRowBytes < (1ll << 31)) {
+        const int tpd = (max_doc_rows + msim::kTokTile - 1) / msim::kTokTile;
+        return dtype == MSIM_DTYPE_F16
+                   ? pairs_argmax_t_dispatch<true>(tpd, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st)
+                   : pairs_argmax_t_dispatch<false>(tpd, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
+    }
     if (!is_tuned(dtype, dim, Lq)) {
         const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
         const int rb = dim * elem_bytes(dtype);
@@ -1101,7 +1254,6 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, 
                 return generic_pairs_argmax<msim::kDtypeBf16>(qc, dc, d_off, d_clamp0, pairs, out_scores, out_argmax, a, rb, *di, st);
         }
     }
-    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     return dtype == MSIM_DTYPE_F16
                ? pairs_argmax_dispatch<true>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st)
                : pairs_argmax_dispatch<false>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
@@ -1111,13 +1263,13 @@ size_t msim_pairs_bwd_workspace_bytes(int n_q, int Lq, int n_d, int dim, int max
     (void)n_q;
     const DeviceInfo *di = nullptr;
     const int cus = device_info(&di) == MSIM_OK ? di->cus : 256;            // the plan only has to be the same in both calls
-    const int splits = dd_dense_splits(n_pairs, Lq, n_d, max_doc_rows, cus);
-    return splits > 0 && dim > 0 ? (size_t)splits * n_d * max_doc_rows * dim * sizeof(float) : 0;
+    return dd_plan(n_pairs, Lq, n_d, dim, max_doc_rows, cus).bytes;
 }
 
 int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, int n_d, int dim,
                    int max_doc_rows, const int32_t *pairs, const int32_t *order_by_doc, const float *g,
-                   const int32_t *argmax, int n_pairs, float *dQ, float *dD, void *workspace, void *stream) {
+                   const void *g_scale, int g_scale_dtype, const int32_t *argmax, int n_pairs, int out_dtype, void *dQ, void *dD,
+                   void *workspace, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0 || n_pairs < 0 || max_doc_rows < 0) return fail(MSIM_EINVAL, "negative size");
     if (!dQ || !dD) return fail(MSIM_EINVAL, "null pointer argument");
     if (n_pairs > 0 && (!pairs || !order_by_doc || !g || !argmax)) return fail(MSIM_EINVAL, "null pair-list argument");
@@ -1125,44 +1277,51 @@ int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, con
     if ((max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows > 65535)
         return fail(MSIM_EUNSUPPORTED, "max_doc_rows=%d too large", max_doc_rows);
     if (n_d > 0x7fffffff / 2) return fail(MSIM_EUNSUPPORTED, "too many documents");
+    if (out_dtype != MSIM_DTYPE_F32 && out_dtype != dtype)
+        return fail(MSIM_EINVAL, "gradients come out as fp32 or in the embeddings' own dtype (out_dtype %d, dtype %d)", out_dtype, dtype);
+    if (g_scale && g_scale_dtype != MSIM_DTYPE_BF16 && g_scale_dtype != MSIM_DTYPE_F16 && g_scale_dtype != MSIM_DTYPE_F32)
+        return fail(MSIM_EINVAL, "g_scale dtype code %d", g_scale_dtype);
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
     msim::PairsArgs a{n_q, Lq, n_d, n_pairs};
-    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // short documents with long entry lists (the trainer's symmetric direction): the dense dD form, through the caller's scratch
-    int splits = 0;
+    DdPlan pl;
     float *partial = static_cast<float *>(workspace);
     if (partial) {
-        const DeviceInfo *di = nullptr;
-        if (int rc = device_info(&di)) return rc;
-        splits = dd_dense_splits(n_pairs, Lq, n_d, max_doc_rows, di->cus);
+        pl = dd_plan(n_pairs, Lq, n_d, dim, max_doc_rows, di->cus);
         if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
     }
-    if (!is_tuned(dtype, dim, Lq)) {
-        const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
-        if (dtype == MSIM_DTYPE_F32)
-            generic_pairs_bwd<msim::kDtypeF32>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st, partial, splits);
-        else if (dtype == MSIM_DTYPE_F16)
-            generic_pairs_bwd<msim::kDtypeF16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st, partial, splits);
-        else
-            generic_pairs_bwd<msim::kDtypeBf16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, st, partial, splits);
-    } else if (dtype == MSIM_DTYPE_F16)
-        launch_pairs_bwd<true>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st, partial, splits);
-    else
-        launch_pairs_bwd<false>(q, d, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, st, partial, splits);
+    const msim::GScale gs{g_scale, g_scale_dtype};
+    const char *qc = static_cast<const char *>(Q), *dc = static_cast<const char *>(D);
+    const bool out16 = out_dtype != MSIM_DTYPE_F32;
+#define MSIM_BWD(DT, O16) \
+    launch_bwd_kernels<DT, O16>(qc, dc, d_off, max_doc_rows, pairs, order_by_doc, g, argmax, dQ, dD, a, dim, di->cus, st, partial, pl, gs)
+    if (dtype == MSIM_DTYPE_F32) MSIM_BWD(msim::kDtypeF32, false);
+    else if (dtype == MSIM_DTYPE_F16) { if (out16) MSIM_BWD(msim::kDtypeF16, true); else MSIM_BWD(msim::kDtypeF16, false); }
+    else { if (out16) MSIM_BWD(msim::kDtypeBf16, true); else MSIM_BWD(msim::kDtypeBf16, false); }
+#undef MSIM_BWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_pairs_bwd launch: %s", hipGetErrorString(e));
     return MSIM_OK;
 }
 
 // ---------------------------------------------------------------- loss epilogue
-size_t msim_loss_epilogue_workspace_bytes(int B) { return B > 0 ? 16 + (size_t)3 * B * sizeof(float) : 16; }
+// one workgroup reads the whole score matrix when it is small (loss_epilogue_small_kernel): no scratch, no ticket
+static bool epilogue_is_small(int B, int C) { return B > 0 && B <= msim::kEpiSmallRows && (long long)B * C <= (1 << 18); }
+
+size_t msim_loss_epilogue_workspace_bytes(int B, int C) {
+    if (epilogue_is_small(B, C)) return 0;
+    return B > 0 ? 16 + (size_t)3 * B * sizeof(float) : 16;
+}
 
 int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C, const void *Q, int q_dtype, int Lq, int width,
                        int offset, float temperature, int normalize, int filter, float filter_threshold, float filter_factor,
-                       float *G, int32_t *pairs, float *coef, int32_t *order, void *workspace, float *out, void *stream) {
+                       float *G, int32_t *pairs, float *coef, int32_t *order, void *workspace, float *out, void *loss_out,
+                       const int32_t *q_lengths, void *stream) {
     if (B < 0 || C < 0 || Lq < 0 || width <= 0) return fail(MSIM_EINVAL, "negative size");
     if (mode != MSIM_LOSS_PAIRWISE && mode != MSIM_LOSS_INFONCE) return fail(MSIM_EINVAL, "unknown loss mode %d", mode);
-    if (!scores || !Q || !workspace || !out) return fail(MSIM_EINVAL, "null pointer argument");
+    if (!scores || !Q || !out) return fail(MSIM_EINVAL, "null pointer argument");
     if (q_dtype != MSIM_DTYPE_BF16 && q_dtype != MSIM_DTYPE_F16 && q_dtype != MSIM_DTYPE_F32)
         return fail(MSIM_EUNSUPPORTED, "dtype code %d", q_dtype);
     if (B == 0) return fail(MSIM_EINVAL, "empty batch");
@@ -1173,13 +1332,16 @@ int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C, 
         if (C < 2) return fail(MSIM_EINVAL, "the pairwise loss needs at least 2 documents (topk(2))");
         if (!pairs || !coef || !order) return fail(MSIM_EINVAL, "null pair-list output");
     }
-    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
+    const bool small = epilogue_is_small(B, C);
+    if (!small && !workspace) return fail(MSIM_EINVAL, "this batch needs msim_loss_epilogue_workspace_bytes(B, C) bytes of zero-filled scratch");
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
     msim::EpiArgs a;
     a.ld = ld;
     a.B = B;
     a.C = C;
     a.Lq = Lq;
     a.q_elem_bytes = elem_bytes(q_dtype);
+    a.q_is_f16 = q_dtype == MSIM_DTYPE_F16;
     a.q_row_bytes = width * a.q_elem_bytes;
     a.offset = offset;
     a.mode = mode == MSIM_LOSS_PAIRWISE ? msim::kEpiPairwise : msim::kEpiInfoNCE;
@@ -1188,10 +1350,19 @@ int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C, 
     a.inv_T = 1.0f / temperature;
     a.filter_threshold = filter_threshold;
     a.filter_factor = filter_factor;
-    char *ws = static_cast<char *>(workspace);
-    hipLaunchKernelGGL(msim::loss_epilogue_kernel, dim3(B), dim3(msim::kEpiThreads), 0, static_cast<hipStream_t>(stream), scores,
-                       static_cast<const char *>(Q), G, pairs, coef, order, reinterpret_cast<float *>(ws + 16),
-                       reinterpret_cast<unsigned int *>(ws), out, a);
+    if (small) {
+        const int staged = (long long)B * C <= msim::kEpiStageFloats;
+        const int lds = staged ? B * C * (int)sizeof(float) : 0;
+        static std::atomic<int> configured[kMaxDevices];
+        if (int rc = allow_lds(msim::loss_epilogue_small_kernel, msim::kEpiStageFloats * (int)sizeof(float), configured)) return rc;
+        hipLaunchKernelGGL(msim::loss_epilogue_small_kernel, dim3(1), dim3(msim::kEpiSmallThreads), lds, static_cast<hipStream_t>(stream),
+                           scores, static_cast<const char *>(Q), q_lengths, G, pairs, coef, order, out, loss_out, a, staged);
+    } else {
+        char *ws = static_cast<char *>(workspace);
+        hipLaunchKernelGGL(msim::loss_epilogue_kernel, dim3(B), dim3(msim::kEpiThreads), 0, static_cast<hipStream_t>(stream), scores,
+                           static_cast<const char *>(Q), G, pairs, coef, order, reinterpret_cast<float *>(ws + 16),
+                           reinterpret_cast<unsigned int *>(ws), out, loss_out, q_lengths, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "loss_epilogue_kernel launch: %s", hipGetErrorString(e));
     return MSIM_OK;

@@ -1,0 +1,202 @@
+// K1t -- the TRANSPOSED batch kernel for gfx950 (MI355X): long queries against many SHORT documents, all pairs.
+//
+// The reference trainer's symmetric direction (trainer/contrastive_trainer.py:202-206, compute_symetric_loss) calls the loss with the
+// pages as `query_embeddings` [B, 780, 128] and the gathered queries as `doc_embeddings` [C, 32, 128]:
+//     scores[p, c] = sum over the page's rows r of  max over the query's tokens t of  <P[p, r, :], Q[c, t, :]>
+//     (colpali_engine/loss/late_interaction_losses.py:297-298: einsum("bnd,csd->bcns") -> amax(dim=3) -> sum(dim=2))
+// -- the same 52 GFLOP as the forward direction at BASELINE config 5's shape, reduced the other way round.  K1b streams documents and
+// keeps query tokens resident: here that is 256 "documents" of ONE slab each under a 780-token "query" cut into seven pieces, and every
+// 32-row document pays a chunk barrier, a table write and a pass of token sums (104 us for 21 us of MFMA work, rocprofv3, round 5).
+//
+// K1t swaps what streams and what is resident, and the MFMA operand roles with it:
+//   * the PAGE streams through the workgroup's LDS ring exactly like a K1b document (128-row chunks, LDS-DMA, swizzled slab image, one
+//     raw s_barrier per chunk, counted vmcnt);
+//   * the short documents' rows are the RESIDENT operand: a document of Ld <= 16 U rows is U units of 16 rows (16 VGPRs each), a wave
+//     holds DPW = 8 / U whole documents, a block of 8 waves 8 DPW documents;
+//   * v_mfma_f32_16x16x32 with A = the resident rows, B = the streamed page rows: D puts one PAGE ROW per lane column (l & 15) and
+//     four resident rows in the lane's registers, so "max over the document's rows" is an in-lane fold over the document's units and
+//     ONE exchange across the four lane groups (xor 16, xor 32) per (document, 16 page rows) -- and the sum over the page's rows is a
+//     running per-lane sum, folded over the 16 lanes once per page.  No token table, no cross-wave reduction, nothing per document.
+// Determinism: a (page, document) score is summed in an order fixed by the page length alone (row groups of 16 in order, then the
+// xor-8/4/2/1 butterfly): independent of which other documents or pages share the launch.
+#pragma once
+#include <type_traits>
+
+#include "maxsim_batch.hip"
+#include "maxsim_common.hpp"
+#include "maxsim_stream.hip"
+
+namespace msim {
+
+struct BatchTArgs {
+    long long ld;       // leading dimension of scores [n_q, ld]
+    int n_q, Lq;        // streamed side: n_q pages of Lq rows each (a dense box)
+    int n_d, Ld;        // resident side: n_d documents of Ld rows each (a dense box), Ld <= 16 * U
+    int n_blocks;       // document blocks of 8 * DPW documents
+    int n_slots;        // page slots per XCD: the workgroup of (xcd, slot) walks pages xcd + 8 * (slot / n_blocks), then += 8 * slots_p
+    int slots_p;        // page slots per XCD = n_slots / n_blocks
+};
+
+// U   : 16-row units per resident document (Ld <= 16 * U)
+// DPW : documents per wave (U * DPW <= 8 units = 128 operand registers)
+template <bool F16, int U, int DPW>
+__global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
+                                                                float *__restrict__ scores, int32_t *__restrict__ q_lengths, BatchTArgs a) {
+    static_assert(U * DPW <= 8 && U >= 1 && DPW >= 1, "a wave holds at most 8 units");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8;
+    constexpr int kRing = 3;
+    constexpr int kCSlabs = NW / 2;                         // 4 slabs = 128 page rows per chunk
+    constexpr int kCRows = kCSlabs * kSlabRows;
+    constexpr int kCBytes = kCSlabs * kSlabBytes;
+    constexpr int NU = U * DPW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= a.n_slots) return;
+    const int block = slot % a.n_blocks;
+    const int pslot = slot / a.n_blocks;
+    const int doc0 = (block * NW + wave) * DPW;              // this wave's first document
+
+    // ---- the resident rows: unit (d, u) = rows 16 u .. 16 u + 15 of document doc0 + d, as MFMA A operands
+    QueryUnit qu[NU];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = doc0 + d < a.n_d;
+            load_query_unit(qu[d * U + u], D + (size_t)(live ? doc0 + d : 0) * a.Ld * kDim, u * kUnitTok, a.Ld, lane, live);
+        }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < NU; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qu[t].f[ks]));
+
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
+    const int my_lds_off = (wave >> 1) * kSlabBytes + (wave & 1) * 4096;
+    const int my_row_off = (wave >> 1) * kSlabRows + (wave & 1) * 16;
+    // resident rows beyond the document's end (the last unit when Ld is not a multiple of 16) are zero rows in the registers: their
+    // similarities are masked to -inf (a real similarity may be negative)
+    const bool need_mask = a.Ld != U * kUnitTok;            // wave-uniform
+    const int row_lim = a.Ld - 4 * l4;                      // resident row 16 u + 4 l4 + r exists iff 16 u + r < row_lim
+
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // optional by-product: q_lengths[page] = rows of the page whose FIRST component is non-zero -- the `lengths` of
+    // late_interaction_losses.py:296, which the loss epilogue would otherwise collect with one cache line per row on ONE CU (21 us for
+    // 32 pages of 780 rows).  Every row passes through this workgroup's LDS anyway: wave 0 of document block 0 counts.
+    const bool count_here = q_lengths != nullptr && block == 0 && wave == 0;
+    const int first_off = (lane & 31) * kRowBytes + ((lane & 15) << 4);      // chunk 0 of row (lane & 31) in the swizzled slab image
+    int p_slot = 0, c_slot = 0;
+    const int nchunk = (a.Lq + kCRows - 1) / kCRows;
+    for (int page = xcd + 8 * pslot; page < a.n_q; page += 8 * a.slots_p) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)page * a.Lq * kDim), 0, a.Lq * kRowBytes, 0x00020000);
+        int p_ch = 0;
+        auto produce = [&]() {
+            if (p_ch >= nchunk) return;
+            char *dst = smem + p_slot * kCBytes + my_lds_off;
+            const int soff = (p_ch * kCRows + my_row_off) * kRowBytes;       // rows past the page end read as zeros (bounds check)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, 0);
+            p_slot = (p_slot + 1 == kRing) ? 0 : p_slot + 1;
+            ++p_ch;
+        };
+#pragma unroll
+        for (int i = 0; i < kRing - 1; ++i) produce();
+
+        float sum[DPW];
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) sum[d] = 0.0f;
+        int n_real = 0;
+
+        auto slab = [&](int src_lds, auto tail, int rows_left) {
+            constexpr bool kTail = decltype(tail)::value;
+            bf16x8 af[2][kKSteps16];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int ks = 0; ks < kKSteps16; ++ks) af[g][ks] = *reinterpret_cast<const bf16x8 *>(smem + src_lds + rd_off[g][ks]);
+            if (count_here) {      // rows beyond the page end arrived as zeros (bounds-checked descriptor): they count as padding
+                const uint16_t first = *reinterpret_cast<const uint16_t *>(smem + src_lds + first_off);
+                n_real += __popcll(__ballot(lane < 32 && (first & 0x7fffu) != 0));
+            }
+            float x[DPW][2];
+#pragma unroll
+            for (int d = 0; d < DPW; ++d) {
+                float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < kKSteps16; ++ks) {
+                        acc0 = mfma16<F16>(qu[d * U + u].f[ks], af[0][ks], acc0);
+                        acc1 = mfma16<F16>(qu[d * U + u].f[ks], af[1][ks], acc1);
+                    }
+                    if (need_mask && (u + 1) * kUnitTok > a.Ld) {        // a unit that reaches beyond the document (wave-uniform branch)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (u * kUnitTok + r >= row_lim) { acc0[r] = -INFINITY; acc1[r] = -INFINITY; }
+                        }
+                    }
+                    m0 = max3(m0, acc0[0], acc0[1]);
+                    m0 = max3(m0, acc0[2], acc0[3]);
+                    m1 = max3(m1, acc1[0], acc1[1]);
+                    m1 = max3(m1, acc1[2], acc1[3]);
+                }
+                x[d][0] = m0;
+                x[d][1] = m1;
+            }
+            // one exchange across the four lane groups per (document, 16 page rows), behind all of the slab's MFMAs
+#pragma unroll
+            for (int d = 0; d < DPW; ++d)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v = x[d][g];
+                    v = fmaxf(v, __shfl_xor(v, 16));
+                    v = fmaxf(v, __shfl_xor(v, 32));
+                    if constexpr (kTail) v = (16 * g + l16 < rows_left) ? v : 0.0f;   // page rows that do not exist add nothing
+                    sum[d] += v;
+                }
+        };
+
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (p_ch < nchunk) wait_vmcnt<4 * (kRing - 2)>(); else wait_vmcnt<0>();
+            lds_barrier();                  // everyone's share landed; everyone is done reading the previous chunk
+            produce();
+            const int cbuf = c_slot * kCBytes;
+            c_slot = (c_slot + 1 == kRing) ? 0 : c_slot + 1;
+            const int rows_in_chunk = a.Lq - ch * kCRows;
+            const int n_full = rows_in_chunk >= kCRows ? kCSlabs : rows_in_chunk / kSlabRows;
+#pragma unroll 1
+            for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
+            const int rem = rows_in_chunk - n_full * kSlabRows;
+            if (n_full < kCSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem);
+        }
+        // ---- page done: fold the 16 page-row lanes (every lane group holds the same sums), one store per document
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) {
+            float s = sum[d];
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 1);
+            if (lane == 0 && doc0 + d < a.n_d) scores[(size_t)page * a.ld + doc0 + d] = s;
+        }
+        if (count_here && lane == 0) q_lengths[page] = n_real;
+        lds_barrier();                      // the ring is re-filled for the next page only after every wave has read its last chunk
+    }
+}
+
+}  // namespace msim

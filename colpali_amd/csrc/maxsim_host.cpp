@@ -24,6 +24,7 @@
 #include <functional>
 #include <limits>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -194,7 +195,7 @@ void score_range(const HostCall &c, const float *qt, const QueryBlock *blocks, i
                         v16f a = acc[r];
                         if (c.ref_round)               // the reference's 16-bit einsum rounds every similarity before the max
                             for (int l = 0; l < kLanes; ++l) a[l] = c.dtype == MSIM_DTYPE_F16 ? round_f16(a[l]) : round_bf16(a[l]);
-                        m = a > m ? a : m;
+                        m = (a > m) | (a != a) ? a : m;       // max that keeps a NaN similarity, like torch's (and like the clamp below)
                     }
                     tmaxv[tv] = m;
                 }
@@ -399,7 +400,8 @@ int fwd_host_lists(const HostCall &c, int n_threads) {
     for (int d = 0; d < n_d; ++d) rows += c.d_len[d];
     int nt = n_threads < 1 ? 1 : (n_threads > 256 ? 256 : n_threads);
     const double work = (double)rows * (double)total_tok * dim;         // multiply-adds
-    const int by_work = (int)(work / 4e6) + 1;                          // a thread is worth waking for a few million of them
+    const double by_work_d = work / 4e6 + 1.0;                          // a thread is worth waking for a few million of them
+    const int by_work = by_work_d > 256.0 ? 256 : (int)by_work_d;        // clamped in double: the cast of a huge value is undefined
     if (nt > by_work) nt = by_work;
     if (nt > n_d) nt = n_d;
     // contiguous chunks of documents with about the same number of rows each, a few per thread (dynamic assignment evens out
@@ -444,7 +446,7 @@ int check_host(int dtype, int n_q, int n_d, int dim, const float *scores, int64_
 
 extern "C" {
 
-int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0, int n_d,
+static int msim_fwd_host_impl(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0, int n_d,
                   int dim, float *scores, int64_t ld_scores, uint32_t flags, int n_threads) {
     if (Lq < 0) return fail_host(MSIM_EINVAL, "negative size");
     if (int rc = check_host(dtype, n_q, n_d, dim, scores, ld_scores, flags)) return rc;
@@ -464,7 +466,7 @@ int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, cons
                           n_threads);
 }
 
-int msim_fwd_host_lists(int dtype, const void *const *q_ptr, const int64_t *q_rows, int n_q, const void *const *d_ptr,
+static int msim_fwd_host_lists_impl(int dtype, const void *const *q_ptr, const int64_t *q_rows, int n_q, const void *const *d_ptr,
                         const int64_t *d_rows, const uint8_t *d_clamp0, int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags,
                         int n_threads) {
     if (int rc = check_host(dtype, n_q, n_d, dim, scores, ld_scores, flags)) return rc;
@@ -478,7 +480,7 @@ int msim_fwd_host_lists(int dtype, const void *const *q_ptr, const int64_t *q_ro
     return fwd_host_lists(HostCall{dtype, q_ptr, q_rows, n_q, d_ptr, d_rows, d_clamp0, n_d, dim, scores, ld_scores, rr}, n_threads);
 }
 
-int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n_b, int dim, float *out, int64_t ld_out, uint32_t flags,
+static int msim_sim_matrix_host_impl(int dtype, const void *A, int n_a, const void *B, int n_b, int dim, float *out, int64_t ld_out, uint32_t flags,
                          int n_threads) {
     auto fail = [](int code, const char *msg) {
         strncpy(g_host_err, msg, sizeof(g_host_err) - 1);
@@ -495,7 +497,8 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
     std::vector<float> af((size_t)n_a * dim + 16);
     for (size_t i = 0; i < (size_t)n_a * dim; ++i) af[i] = widen(A, dtype, i);
     int nt = n_threads < 1 ? 1 : (n_threads > 256 ? 256 : n_threads);
-    const int by_work = (int)((double)n_a * n_b * dim / 4e6) + 1;
+    const double by_work_d = (double)n_a * n_b * dim / 4e6 + 1.0;
+    const int by_work = by_work_d > 256.0 ? 256 : (int)by_work_d;
     if (nt > by_work) nt = by_work;
     const int groups = (n_b + kRows - 1) / kRows;
     const int n_chunks = nt <= 1 ? 1 : (4 * nt < groups ? 4 * nt : groups);
@@ -509,6 +512,73 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
     };
     HostPool::get().run(n_chunks, nt, body);
     return MSIM_OK;
+}
+
+}  // extern "C"
+
+// Copies bytes [lo, hi) of the VIRTUAL concatenation of n host buffers -- buffer i holds image bytes prefix[i] .. prefix[i + 1] - 1 at
+// src[i] -- to dst (dst[0] = image byte lo), on the persistent pool, the range cut into equal BYTE shares (not buffer shares).
+// The drop-in's upload path (colpali_amd/corpus.py): a thousand per-page host tensors (README.md:121-126) go through a bounded pinned
+// staging buffer chunk by chunk; one call per chunk, no per-call thread start (msim_host_gather spawned eight std::threads per
+// 32 MiB chunk: about as long as the copy itself), no Python loop over the pages.
+static int host_gather_range_impl(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads) {
+    if (n < 0 || lo < 0 || hi < lo) return fail_host(MSIM_EINVAL, "bad range");
+    if (hi == lo || n == 0) return MSIM_OK;
+    if (!dst || !src || !prefix) return fail_host(MSIM_EINVAL, "null pointer argument");
+    if (hi > prefix[n]) return fail_host(MSIM_EINVAL, "range beyond the image");
+    const int64_t total = hi - lo;
+    int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    const int64_t by_bytes = total >> 21;                                      // at least ~2 MiB per thread
+    if (nt > by_bytes) nt = by_bytes < 1 ? 1 : (int)by_bytes;
+    char *d = static_cast<char *>(dst);
+    const std::function<void(int)> body = [&](int part) {
+        const int64_t a = lo + total * part / nt, b = lo + total * (part + 1) / nt;
+        if (a >= b) return;
+        int64_t i0 = 0, i1 = n;                                                // the buffer that holds image byte a
+        while (i0 < i1) {
+            const int64_t mid = (i0 + i1) >> 1;
+            if (prefix[mid + 1] <= a) i0 = mid + 1; else i1 = mid;
+        }
+        for (int64_t i = i0, pos = a; pos < b; ++i) {
+            const int64_t end = prefix[i + 1] < b ? prefix[i + 1] : b;
+            if (end > pos) memcpy(d + (pos - lo), static_cast<const char *>(src[i]) + (pos - prefix[i]), (size_t)(end - pos));
+            pos = end > pos ? end : pos;
+        }
+    };
+    HostPool::get().run(nt, nt, body);
+    return MSIM_OK;
+}
+
+extern "C" {
+
+// nothing may unwind across the C ABI (through ctypes that terminates the process): allocation failures become an error code
+#define MSIM_HOST_GUARD(call)                                              \
+    try {                                                                  \
+        return call;                                                       \
+    } catch (const std::bad_alloc &) {                                     \
+        return fail_host(MSIM_ELAUNCH, "out of host memory");              \
+    } catch (...) {                                                        \
+        return fail_host(MSIM_ELAUNCH, "unexpected C++ exception");        \
+    }
+
+int msim_fwd_host(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0, int n_d,
+                  int dim, float *scores, int64_t ld_scores, uint32_t flags, int n_threads) {
+    MSIM_HOST_GUARD(msim_fwd_host_impl(dtype, Q, n_q, Lq, D, d_off, d_clamp0, n_d, dim, scores, ld_scores, flags, n_threads))
+}
+
+int msim_fwd_host_lists(int dtype, const void *const *q_ptr, const int64_t *q_rows, int n_q, const void *const *d_ptr,
+                        const int64_t *d_rows, const uint8_t *d_clamp0, int n_d, int dim, float *scores, int64_t ld_scores, uint32_t flags,
+                        int n_threads) {
+    MSIM_HOST_GUARD(msim_fwd_host_lists_impl(dtype, q_ptr, q_rows, n_q, d_ptr, d_rows, d_clamp0, n_d, dim, scores, ld_scores, flags, n_threads))
+}
+
+int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n_b, int dim, float *out, int64_t ld_out, uint32_t flags,
+                         int n_threads) {
+    MSIM_HOST_GUARD(msim_sim_matrix_host_impl(dtype, A, n_a, B, n_b, dim, out, ld_out, flags, n_threads))
+}
+
+int msim_host_gather_range(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads) {
+    MSIM_HOST_GUARD(host_gather_range_impl(dst, src, prefix, n, lo, hi, n_threads))
 }
 
 }  // extern "C"

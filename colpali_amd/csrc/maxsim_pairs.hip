@@ -28,9 +28,12 @@ struct PairsArgs {
     int n_q, Lq, n_d, n_pairs;
 };
 
-// One wave per pair (4 pairs per workgroup, wave-private LDS ring as in K1s).
+// WPP = 1: one wave per pair (4 pairs per workgroup, wave-private LDS ring as in K1s) -- the throughput form for long pair lists.
+// WPP = 4: one WORKGROUP per pair, wave w takes slabs w, w + 4, ... of the document and the four (max, arg-max) sets are combined
+// through LDS (lower row wins a tie: the first maximum) -- the latency form for short lists: the pairwise loss recomputes the routing
+// of 2B = 64 pairs, and one wave walking 25 slabs one LDS-DMA round trip at a time took 20 us of a 150 us step (rocprofv3, round 5).
 // TPQ = ceil(Lq / 32) token tiles of the pair's query live in registers.
-template <int TPQ, bool F16>
+template <int TPQ, bool F16, int WPP = 1>
 __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
                                                                   const uint16_t *__restrict__ D,
                                                                   const int32_t *__restrict__ d_off,
@@ -39,12 +42,16 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
                                                                   float *__restrict__ out_scores,      // [n_pairs] or null
                                                                   int32_t *__restrict__ out_argmax,    // [n_pairs, Lq] or null
                                                                   PairsArgs a) {
+    static_assert(WPP == 1 || WPP == 4, "one wave or one workgroup per pair");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *ring = smem + wave * (kPairsRing * kSlabBytes);
-    const int gw = blockIdx.x * 4 + wave;
-    const int GW = gridDim.x * 4;
+    float *comb_m = reinterpret_cast<float *>(smem + 4 * kPairsRing * kSlabBytes);        // WPP = 4: [4][TPQ * 32]
+    int *comb_a = reinterpret_cast<int *>(comb_m + 4 * TPQ * kTokTile);
+    const int gw = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    const int GW = WPP == 1 ? gridDim.x * 4 : gridDim.x;
+    const int s_first = WPP == 1 ? 0 : wave;
 
     const int l16 = lane & 15, l4 = lane >> 4;
     int src_off[4];
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
 
     for (int p = gw; p < a.n_pairs; p += GW) {
         const int q = pairs[2 * p], c = pairs[2 * p + 1];
-        if (q < 0 || q >= a.n_q || c < 0 || c >= a.n_d) continue;   // caller error: leave the outputs untouched
+        if (q < 0 || q >= a.n_q || c < 0 || c >= a.n_d) continue;   // caller error: leave the outputs untouched (uniform per workgroup for WPP = 4)
         // ---- query fragments of this pair
         bf16x8 qf[TPQ][kKSteps];
 #pragma unroll
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
         const int nslab = (len + kSlabRows - 1) / kSlabRows;
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * kDim), 0, len * kRowBytes, 0x00020000);
-        int p_s = 0, p_slot = 0, c_slot = 0;
+        int p_s = s_first, p_slot = 0, c_slot = 0;
         auto produce = [&]() -> bool {
             if (p_s >= nslab) return false;
             char *dst = ring + p_slot * kSlabBytes;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
             for (int i = 0; i < 8; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
             p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
-            ++p_s;
+            p_s += WPP;
             return true;
         };
 #pragma unroll
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
 #pragma unroll
         for (int t = 0; t < TPQ; ++t) { m[t] = -INFINITY; am[t] = -1; }
 
-        for (int s = 0; s < nslab; ++s) {
+        for (int s = s_first; s < nslab; s += WPP) {
             if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
             const char *src = ring + c_slot * kSlabBytes;
             c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
@@ -130,20 +137,172 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
             const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c;
             clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
         }
-        float total = 0.0f;
+        float v_t[TPQ];
+        int a_t[TPQ];
 #pragma unroll
         for (int t = 0; t < TPQ; ++t) {
             const float om = __shfl_xor(m[t], 32);
             const int oam = __shfl_xor(am[t], 32);
-            float v = m[t];
-            int arg = am[t];
-            if (om > v || (om == v && (unsigned)oam < (unsigned)arg)) { v = om; arg = oam; }
+            v_t[t] = m[t];
+            a_t[t] = am[t];
+            if (om > v_t[t] || (om == v_t[t] && (unsigned)oam < (unsigned)a_t[t])) { v_t[t] = om; a_t[t] = oam; }
+        }
+        if constexpr (WPP > 1) {
+            // the four waves' (max, row) per token through LDS; wave 0 keeps the largest value, the lowest row among equals
+            if (lane < 32) {
+#pragma unroll
+                for (int t = 0; t < TPQ; ++t) {
+                    comb_m[wave * (TPQ * kTokTile) + t * kTokTile + lane] = v_t[t];
+                    comb_a[wave * (TPQ * kTokTile) + t * kTokTile + lane] = a_t[t];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int t = 0; t < TPQ; ++t) {
+                    float v = -INFINITY;
+                    int arg = -1;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float ov = comb_m[w * (TPQ * kTokTile) + t * kTokTile + (lane & 31)];
+                        const int oa = comb_a[w * (TPQ * kTokTile) + t * kTokTile + (lane & 31)];
+                        if (ov > v || (ov == v && (unsigned)oa < (unsigned)arg)) { v = ov; arg = oa; }
+                    }
+                    v_t[t] = v;
+                    a_t[t] = arg;
+                }
+            }
+            __syncthreads();                                  // the table is free for the workgroup's next pair
+            if (wave != 0) continue;
+        }
+        float total = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+            float v = v_t[t];
+            int arg = a_t[t];
             if (clamp && !(v >= 0.0f)) { v = 0.0f; arg = -1; }   // the reference's zero padding row wins
             const int tok = t * kTokTile + (lane & 31);
             if (out_argmax != nullptr && lane < 32 && tok < a.Lq) out_argmax[(size_t)p * a.Lq + tok] = arg;
             total += half_wave_sum(v);
         }
         if (out_scores != nullptr && lane == 0) out_scores[p] = total;
+    }
+}
+
+// ---- the TRANSPOSED pair kernel: long queries against short documents -- the trainer's symmetric direction
+// (trainer/contrastive_trainer.py:202-206: a 780-token page as `query_embeddings`, a 32-token query as `doc_embeddings`).  The long
+// side streams (the query's tokens, 32 per slab, through the same wave-private LDS ring and swizzle), the short side is resident
+// (the document's rows, TPD tiles of 32, as the A operand): D[doc row][token] puts one TOKEN per lane column and 16 document rows
+// in its registers, so "max over the document's rows" is the same in-lane fold as everywhere else, finished per slab: every slab
+// yields 32 finished (max, arg-max) results, nothing is carried across slabs.  One workgroup per pair, wave w takes slabs w, w + 4, ...
+// (the results are per token: no cross-wave combine except the score sum, in wave order).  Until round 5 these pairs went to the
+// generic kernel (fragment-shaped global loads, one wave per pair): 53 us for the 64 pairs of the pairwise loss.
+template <int TPD, bool F16>
+__global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_t_kernel(const uint16_t *__restrict__ Q,
+                                                                    const uint16_t *__restrict__ D,
+                                                                    const int32_t *__restrict__ d_off,
+                                                                    const uint8_t *__restrict__ clamp0,
+                                                                    const int32_t *__restrict__ pairs,   // [n_pairs, 2]
+                                                                    float *__restrict__ out_scores,      // [n_pairs] or null
+                                                                    int32_t *__restrict__ out_argmax,    // [n_pairs, Lq] or null
+                                                                    PairsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wave * (kPairsRing * kSlabBytes);
+    float *wave_sum = reinterpret_cast<float *>(smem + 4 * kPairsRing * kSlabBytes);      // [4]
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+    const int nslab = (a.Lq + kSlabRows - 1) / kSlabRows;
+
+    for (int p = blockIdx.x; p < a.n_pairs; p += gridDim.x) {
+        const int q = pairs[2 * p], c = pairs[2 * p + 1];
+        if (q < 0 || q >= a.n_q || c < 0 || c >= a.n_d) continue;   // caller error: leave the outputs untouched
+        const int r0 = d_off[c];
+        const int len = d_off[c + 1] - r0;                          // <= 32 * TPD (the host checked max_doc_rows)
+        // ---- the document's rows: resident A operands
+        bf16x8 df[TPD][kKSteps];
+#pragma unroll
+        for (int t = 0; t < TPD; ++t) {
+            const int row = t * kTokTile + (lane & 31);
+            const bool valid = row < len;
+            const uint16_t *dp = D + ((size_t)r0 + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                bf16x8 v = *reinterpret_cast<const bf16x8 *>(dp + ks * 16);
+                df[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int t = 0; t < TPD; ++t)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(df[t][ks]));
+        bool clamp = false;
+        if (clamp0 != nullptr) {
+            const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c;
+            clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+        }
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)q * a.Lq * kDim), 0, a.Lq * kRowBytes, 0x00020000);
+        int p_s = wave, p_slot = 0, c_slot = 0;
+        auto produce = [&]() -> bool {
+            if (p_s >= nslab) return false;
+            char *dst = ring + p_slot * kSlabBytes;
+            const int soff = p_s * kSlabBytes;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
+            p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
+            p_s += 4;
+            return true;
+        };
+#pragma unroll
+        for (int i = 0; i < kPairsRing - 1; ++i) produce();
+        float total = 0.0f;
+        for (int s = wave; s < nslab; s += 4) {
+            if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
+            const char *src = ring + c_slot * kSlabBytes;
+            c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
+            bf16x8 sf[kKSteps];
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) sf[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+            float m = -INFINITY;
+            int am = -1;
+#pragma unroll
+            for (int t = 0; t < TPD; ++t) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(df[t][ks], sf[ks], acc);
+                // document rows are visited in increasing order inside a lane, strict '>' keeps the first maximum
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = t * kTokTile + acc_row(r, lane);
+                    const float v = (row < len) ? acc[r] : -INFINITY;
+                    if (v > m) { m = v; am = row; }
+                }
+            }
+            const float om = __shfl_xor(m, 32);
+            const int oam = __shfl_xor(am, 32);
+            if (om > m || (om == m && (unsigned)oam < (unsigned)am)) { m = om; am = oam; }
+            if (clamp && !(m >= 0.0f)) { m = 0.0f; am = -1; }       // the reference's zero padding row wins
+            const int tok = s * kSlabRows + (lane & 31);
+            const bool live = tok < a.Lq;
+            if (out_argmax != nullptr && lane < 32 && live) out_argmax[(size_t)p * a.Lq + tok] = am;
+            total += live ? m : 0.0f;                               // both halves hold the same value: summed over 32 lanes below
+        }
+        if (out_scores != nullptr) {
+            const float wsum = half_wave_sum(total);                 // lanes 0..31: the sum over this wave's tokens
+            __syncthreads();                                         // the previous pair's table has been read
+            if (lane == 0) wave_sum[wave] = wsum;
+            __syncthreads();
+            if (threadIdx.x == 0) out_scores[p] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
+        }
     }
 }
 

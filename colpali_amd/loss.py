@@ -30,7 +30,7 @@ from .scoring import maxsim_scores
 def _dense_corpus(d: torch.Tensor) -> PackedCorpus:
     """View a dense [C, Ld, width] tensor as a packed corpus (no copy; zero rows stay physical rows)."""
     C, Ld, _ = d.shape
-    offsets = torch.arange(C + 1, dtype=torch.int32, device=d.device) * Ld
+    offsets = torch.arange(0, (C + 1) * Ld, Ld, dtype=torch.int32, device=d.device) if Ld else torch.zeros(C + 1, dtype=torch.int32, device=d.device)   # one launch
     return PackedCorpus(blob=d.view(C * Ld, d.shape[2]), offsets=offsets, clamp0=None,
                         lengths=torch.full((C,), Ld, dtype=torch.int64))
 
@@ -55,6 +55,25 @@ def _widen(x: torch.Tensor) -> torch.Tensor:
     return x if width == x.shape[-1] else F.pad(x, (0, width - x.shape[-1]))
 
 
+def _box_scores(qc: torch.Tensor, dc: torch.Tensor, corpus: PackedCorpus, want_lengths: bool = False):
+    """fp32 [B, C] MaxSim scores of two dense boxes (with `want_lengths`: a tuple (scores, int32 [B] token counts of the queries or
+    None) -- the transposed kernel counts them while it streams the query rows).  Long queries against short documents (the trainer's symmetric direction,
+    trainer/contrastive_trainer.py:202-206: pages [B, 780, 128] as queries, queries [C, 32, 128] as documents; bf16 / f16, width 128)
+    take the transposed kernel (msim_fwd_transposed: the long side streams, the short side is resident); everything else msim_fwd."""
+    B, Lq, width = qc.shape
+    C, Ld, _ = dc.shape
+    if qc.dtype in (torch.bfloat16, torch.float16) and width == 128 and Lq > 128 and 0 < Ld <= 128 and B > 0 and C > 0:
+        scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)
+        lengths = torch.empty((B,), dtype=torch.int32, device=qc.device) if want_lengths else None
+        with torch.cuda.device(qc.device):
+            rc = _lib.lib().msim_fwd_transposed(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), C, Ld, width, _lib.ptr(scores),
+                                                C, _lib.ptr(lengths), _lib.current_stream_handle(qc.device))
+        _lib.check(rc, "msim_fwd_transposed")
+        return (scores, lengths) if want_lengths else scores
+    scores = maxsim_scores(qc, corpus)
+    return (scores, None) if want_lengths else scores
+
+
 class _MaxSim(torch.autograd.Function):
     """scores[b, c] = sum_n max_s <Q[b,n], D[c,s]> with a recompute backward.
 
@@ -72,7 +91,7 @@ class _MaxSim(torch.autograd.Function):
             _, argmax = maxsim_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, qc.device), scores_out=scores)
             ctx.save_for_backward(qc, dc, corpus.offsets, argmax)
             return scores
-        scores = maxsim_scores(qc, corpus)
+        scores = _box_scores(qc, dc, corpus)
         ctx.save_for_backward(qc, dc, corpus.offsets, None)
         return scores
 
@@ -80,8 +99,7 @@ class _MaxSim(torch.autograd.Function):
     def backward(ctx, grad_scores: torch.Tensor):
         qc, dc, offsets, argmax = ctx.saved_tensors
         dq, dd = maxsim_backward(qc, dc, offsets, grad_scores, argmax_all=argmax)
-        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
-                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
+        return (dq if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None)
 
 
 def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pairs: torch.Tensor,
@@ -96,15 +114,17 @@ def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
     scores = (scores_out if scores_out is not None else torch.empty((n_pairs,), dtype=torch.float32, device=dev)) if want_scores else None
     argmax = torch.empty((n_pairs, Lq), dtype=torch.int32, device=dev) if want_argmax else None
     with torch.cuda.device(dev):
+        # dc is the dense [C, Ld, width] box: every document has Ld rows (the bound only selects the kernel: long queries against
+        # short documents -- the trainer's symmetric direction -- take the transposed pair kernel)
         rc = L.msim_pairs_argmax(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), None, C,
-                                 dim, _lib.ptr(pairs), n_pairs, _lib.ptr(scores), _lib.ptr(argmax),
-                                 _lib.current_stream_handle(dev))
+                                 dim, int(dc.shape[1]) if dc.dim() == 3 else 0, _lib.ptr(pairs), n_pairs, _lib.ptr(scores),
+                                 _lib.ptr(argmax), _lib.current_stream_handle(dev))
     _lib.check(rc, "msim_pairs_argmax")
     return scores, argmax
 
 
 def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor, argmax_all=None):
-    """(dQ fp32 [B,Lq,width], dD fp32 [C,Ld,width]) for upstream dLoss/dscores [B, C].  Every (query, doc) pair is a pair of
+    """(dQ [B,Lq,width], dD [C,Ld,width], in the embeddings' dtype) for upstream dLoss/dscores [B, C].  Every (query, doc) pair is a pair of
     the list (zero gradients contribute zero): no data-dependent count, hence no host synchronisation.  `argmax_all`: the
     [B*C, Lq] routing in row-major order when the forward kept it; otherwise it is recomputed here (one pass of the
     arg-max pair kernel, about the cost of the forward).  The losses whose gradient is 2-sparse per query (pairwise) do not
@@ -123,21 +143,34 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
     return _pairs_backward(qc, dc, offsets, pairs, _all_pairs_order(B, C, dev), gp, argmax_all)
 
 
-def _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax):
-    """msim_pairs_bwd: (dQ, dD) fp32 for a pair list sorted by query with its by-document permutation and routing."""
+def _scale_arg(g_scale):
+    """(pointer, dtype code) of an optional device scalar the backward kernels multiply every pair's gradient by -- autograd's
+    upstream gradient of the loss, taken as it arrives (0-dim, any of the three dtypes) instead of a `coef * grad` launch."""
+    if g_scale is None:
+        return None, 0
+    if g_scale.dtype not in (torch.bfloat16, torch.float16, torch.float32) or g_scale.numel() != 1:
+        g_scale = g_scale.reshape(-1)[:1].to(torch.float32)
+    return g_scale, _lib.dtype_code(g_scale.dtype)
+
+
+def _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax, g_scale=None):
+    """msim_pairs_bwd: (dQ, dD) IN THE EMBEDDINGS' DTYPE (one rounding of the fp32 sums inside the kernels: no cast launches, half
+    the bytes written) for a pair list sorted by query with its by-document permutation and routing; `g_scale`: see _scale_arg."""
     L = _lib.lib()
     B, Lq, dim = qc.shape
     C, Ld, _ = dc.shape
     dev = qc.device
-    dq = torch.empty((B, Lq, dim), dtype=torch.float32, device=dev)
-    dd = torch.empty((C, Ld, dim), dtype=torch.float32, device=dev)
+    dq = torch.empty((B, Lq, dim), dtype=qc.dtype, device=dev)
+    dd = torch.empty((C, Ld, dim), dtype=dc.dtype, device=dev)
+    gs, gs_code = _scale_arg(g_scale)
+    code = _lib.dtype_code(qc.dtype)
     with torch.cuda.device(dev):
         # scratch of the dense dD form (short documents, long entry lists: the trainer's symmetric direction), per call
         ws_bytes = L.msim_pairs_bwd_workspace_bytes(B, Lq, C, dim, Ld, pairs.shape[0])
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
-        rc = L.msim_pairs_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
-                              _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), pairs.shape[0],
-                              _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws), _lib.current_stream_handle(dev))
+        rc = L.msim_pairs_bwd(code, _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), C, dim, Ld,
+                              _lib.ptr(pairs), _lib.ptr(order), _lib.ptr(gp), _lib.ptr(gs), gs_code, _lib.ptr(argmax), pairs.shape[0],
+                              code, _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws), _lib.current_stream_handle(dev))
     _lib.check(rc, "msim_pairs_bwd")
     return dq, dd
 
@@ -160,8 +193,7 @@ class _MaxSimPairs(torch.autograd.Function):
         order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
         _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
         dq, dd = _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax)
-        return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
-                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None, None)
+        return (dq if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None)
 
 
 def _check_pairs(pairs: torch.Tensor, B: int, C: int) -> None:
@@ -335,12 +367,13 @@ def maxsim_smooth_paired(query_embeddings: torch.Tensor, doc_embeddings: torch.T
     return _MaxSimPairsSmooth.apply(_widen32(query_embeddings), _widen32(doc_embeddings), pairs, float(tau))
 
 
-def _epilogue_workspace(B: int, device: torch.device) -> torch.Tensor:
-    """Zero-filled scratch of msim_loss_epilogue (its ticket counter and per-row terms: cross-workgroup state of ONE launch).
+def _epilogue_workspace(B: int, C: int, device: torch.device):
+    """Zero-filled scratch of msim_loss_epilogue (its ticket counter and per-row terms: cross-workgroup state of ONE launch), or
+    None for the batches one workgroup handles without any (B <= 1024, B * C <= 262 144: BASELINE config 5 among them).
     Allocated per call -- about 12 * B bytes from the caching allocator, capturable -- so two launches in flight (other
     streams, threads, replays of captured graphs) can never share a ticket (round-2 advisor finding)."""
-    need = _lib.lib().msim_loss_epilogue_workspace_bytes(B)
-    return torch.zeros((max(need, 16),), dtype=torch.uint8, device=device)
+    need = _lib.lib().msim_loss_epilogue_workspace_bytes(B, C)
+    return torch.zeros((need,), dtype=torch.uint8, device=device) if need else None
 
 
 MODE_PAIRWISE, MODE_INFONCE = 0, 1
@@ -357,7 +390,7 @@ class _FusedInBatchLoss(torch.autograd.Function):
     `stats` (returned for the caller's bound check) = [loss, min, max of the normalised scores]."""
 
     @staticmethod
-    def forward(ctx, q, d, mode, offset, temperature, normalize, filtering, filter_threshold, filter_factor, smooth, tau):
+    def forward(ctx, q, d, mode, offset, temperature, normalize, filtering, filter_threshold, filter_factor, smooth, tau, loss_in_dtype):
         L = _lib.lib()
         qc, dc = q.contiguous(), d.contiguous()
         corpus = _dense_corpus(dc)
@@ -365,7 +398,7 @@ class _FusedInBatchLoss(torch.autograd.Function):
         C = dc.shape[0]
         dev = qc.device
         need_grad = any(ctx.needs_input_grad[:2])
-        aux = None                                  # InfoNCE + gradients: [B*C, Lq] routing (hard max) or logsumexp (smooth max)
+        aux = q_lengths = None                      # InfoNCE + gradients: [B*C, Lq] routing (hard max) or logsumexp (smooth max)
         if mode == MODE_INFONCE and need_grad:
             scores = torch.empty((B, C), dtype=torch.float32, device=dev)
             if smooth:
@@ -379,7 +412,7 @@ class _FusedInBatchLoss(torch.autograd.Function):
                                        tau, _lib.ptr(scores), max(C, 1), _lib.current_stream_handle(dev))
             _lib.check(rc, "msim_smooth_fwd")
         else:
-            scores = maxsim_scores(qc, corpus)
+            scores, q_lengths = _box_scores(qc, dc, corpus, want_lengths=True)
         stats = torch.empty((3,), dtype=torch.float32, device=dev)
         G = pairs = coef = order = None
         if mode == MODE_PAIRWISE:
@@ -388,39 +421,43 @@ class _FusedInBatchLoss(torch.autograd.Function):
             order = torch.empty((2 * B,), dtype=torch.int32, device=dev)
         elif need_grad:
             G = torch.empty((B, C), dtype=torch.float32, device=dev)
-        ws = _epilogue_workspace(B, dev)
+        ws = _epilogue_workspace(B, C, dev)
+        # the loss in the embeddings' dtype straight from the kernel (what the reference returns); fp32 when the caller wants that
+        # (autocast): then it is a copy of the statistics' first entry
+        loss = torch.empty((), dtype=qc.dtype, device=dev) if loss_in_dtype else None
         with torch.cuda.device(dev):
             rc = L.msim_loss_epilogue(mode, _lib.ptr(scores), C, B, C, _lib.ptr(qc), _lib.dtype_code(qc.dtype), Lq, width, offset,
                                       float(temperature), int(normalize), int(filtering), float(filter_threshold),
                                       float(filter_factor), _lib.ptr(G), _lib.ptr(pairs), _lib.ptr(coef), _lib.ptr(order),
-                                      _lib.ptr(ws), _lib.ptr(stats), _lib.current_stream_handle(dev))
+                                      _lib.ptr(ws), _lib.ptr(stats), _lib.ptr(loss), _lib.ptr(q_lengths), _lib.current_stream_handle(dev))
         _lib.check(rc, "msim_loss_epilogue")
         ctx.mode, ctx.smooth, ctx.tau = mode, smooth, tau
         ctx.save_for_backward(qc, dc, corpus.offsets, G, pairs, coef, order, aux)
         ctx.mark_non_differentiable(stats)
-        return stats[0].clone(), stats                 # the loss as a tensor of its own (not a view of the statistics buffer)
+        if loss is None:
+            loss = stats[0].clone()                    # the loss as a tensor of its own (not a view of the statistics buffer)
+        return loss, stats
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_stats):
         qc, dc, offsets, G, pairs, coef, order, aux = ctx.saved_tensors
         B, C = qc.shape[0], dc.shape[0]
-        up = grad_loss.to(torch.float32)
         if ctx.mode == MODE_PAIRWISE:
-            gp = coef * up
             if ctx.smooth:
-                dq, dd = _smooth_backward(qc, dc, offsets, pairs, gp, ctx.tau, order=order)
+                dq, dd = _smooth_backward(qc, dc, offsets, pairs, coef * grad_loss.to(torch.float32), ctx.tau, order=order)
             else:
+                # the upstream gradient goes into the kernels as the device scalar it is; gradients come out in the embeddings' dtype
                 _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
-                dq, dd = _pairs_backward(qc, dc, offsets, pairs, order, gp, argmax)
+                dq, dd = _pairs_backward(qc, dc, offsets, pairs, order, coef, argmax, g_scale=grad_loss)
         else:
-            gp = (G * up).reshape(-1)
             all_pairs, all_order = _all_pairs(B, C, qc.device), _all_pairs_order(B, C, qc.device)
             if ctx.smooth:
+                gp = (G * grad_loss.to(torch.float32)).reshape(-1)
                 dq, dd = _smooth_backward(qc, dc, offsets, all_pairs, gp, ctx.tau, lse=aux, order=all_order)
             else:
-                dq, dd = _pairs_backward(qc, dc, offsets, all_pairs, all_order, gp, aux)
+                dq, dd = _pairs_backward(qc, dc, offsets, all_pairs, all_order, G.reshape(-1), aux, g_scale=grad_loss)
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
-                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None) + (None,) * 9
+                dd.to(dc.dtype) if ctx.needs_input_grad[1] else None) + (None,) * 10
 
 
 def _autocast_inputs(q: torch.Tensor, d: torch.Tensor):
@@ -587,13 +624,14 @@ class ColbertModule(torch.nn.Module):
         if mode == MODE_PAIRWISE and C < 2:
             raise RuntimeError("selected index k out of range")          # what scores.topk(2, dim=1) raises (:310)
         widen = _widen32 if self.use_smooth_max else _widen
+        out_dtype = _loss_dtype(query_embeddings)
         loss, stats = _FusedInBatchLoss.apply(widen(q), widen(d), mode, int(offset), float(self.temperature),
                                               bool(self.normalize_scores), bool(self.pos_aware_negative_filtering),
                                               float(self.filter_threshold), float(self.filter_factor),
-                                              bool(self.use_smooth_max), float(self.tau))
+                                              bool(self.use_smooth_max), float(self.tau), out_dtype == q.dtype)
         if self.normalize_scores:
             self._report_bounds(stats)
-        return loss.to(_loss_dtype(query_embeddings))
+        return loss.to(out_dtype)
 
     # -- shared front end of every in-batch loss: lengths, fused MaxSim, optional normalisation / filtering
     def _inbatch_scores(self, query_embeddings, doc_embeddings, offset, dense_grad=False):

@@ -15,7 +15,8 @@ from typing import List, Optional, Union
 import torch
 
 from . import _lib
-from .corpus import PackedCorpus, PackedQueries, _check_embeddings, _widen, pack_passages, pack_queries
+from .corpus import (PackedCorpus, PackedQueries, _check_embeddings, _staging, _widen, block_clamp0, copy_stream, host_list_image,
+                     pack_passages, pack_queries)
 
 logger = logging.getLogger(__name__)
 
@@ -161,6 +162,8 @@ def maxsim_scores(queries: Union[torch.Tensor, PackedQueries], corpus: PackedCor
     elif out.shape != (n_q, n) or out.dtype != torch.float32 or out.stride(1) != 1:
         raise ValueError("out must be fp32 [n_q, n] with unit inner stride")
     flags = _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0
+    if n:       # launch-shape hint (include/maxsim.h: MSIM_FLAG_AVG_ROWS): the average document length, which the host side knows
+        flags |= min(65535, max(1, int(corpus.lengths.sum()) // n)) << 8
     ld = out.stride(0) if n_q > 1 else max(n, 1)
     if flat:
         with torch.cuda.device(queries.device):
@@ -213,6 +216,11 @@ def score_multi_vector(
         return scores
     dev = _require_gpu(device)
     q = pack_queries(qs, dev)
+    if not isinstance(ps, torch.Tensor):
+        scores = _score_host_list_pipelined(q, ps, dev, batch_size, ref_rounding)
+        if scores is not None:
+            assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+            return scores
     cols = []
     for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
         corpus = pack_passages(ps[lo:hi], dev, batch_size=batch_size)
@@ -220,6 +228,101 @@ def score_multi_vector(
         del corpus
     scores = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
     assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+    return scores.to(torch.float32)
+
+
+TIMELINE = None        # bench.py / tools set this to a list: (label, time.perf_counter()) stamps of the drop-in call's phases
+
+
+def _stamp(label: str) -> None:
+    if TIMELINE is not None:
+        import time
+
+        TIMELINE.append((label, time.perf_counter()))
+
+
+_PIPE_RANGE_BYTES = 48 << 20      # passage sub-ranges of about this size are scored while the next ones upload
+
+
+def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_rounding: bool) -> Optional[torch.Tensor]:
+    """The drop-in call as evaluators make it -- a Python list of per-page HOST tensors (README.md:121-126) -- as one pipeline:
+
+        one pass of checks -> [native gather of chunk k+1 into pinned memory | H2D of chunk k on a copy stream | MaxSim of the passage
+        sub-ranges that have arrived, on the caller's stream] -> one D2H of the [n_q, n_p] matrix.
+
+    The corpus is a 264 MB PCIe upload at BASELINE config 2's geometry (1000 pages x 1030 patches): the call's floor is that upload
+    (4.7 ms at the 57 GB/s this host's pinned H2D reaches); checks, gather and the kernels hide under it.  Sub-ranges are cut at
+    multiples of `batch_size`, and the clamp0 flags come from the same blocking, so every passage keeps the block mates the reference
+    pads it with (processing_utils.py:175-178): results are bit-identical to scoring the packed corpus in one launch.  Returns None
+    for inputs this road does not take (a tensor that is not on the host; a corpus above the device budget; rows that need zero
+    columns appended): the caller's general path serves those."""
+    import numpy as np
+
+    _stamp("begin")
+    info = host_list_image(ps)
+    if info is None:
+        return None
+    keep, srcs, rows, dim, dtype = info
+    if q.dtype != dtype:
+        raise RuntimeError(f"expected queries and passages of one dtype, got {q.dtype} and {dtype}")
+    if _lib.kernel_width(dim, dtype) != dim:
+        return None
+    n = len(keep)
+    row_bytes = dim * keep[0].element_size()
+    prefix = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(rows * row_bytes, out=prefix[1:])
+    total = int(prefix[n])
+    total_rows = total // row_bytes
+    if total == 0 or total > _corpus_budget_bytes(dev) or total_rows >= 2**31:
+        return None
+    lengths = torch.from_numpy(rows)
+    flags = block_clamp0(lengths, batch_size)
+    if bool((lengths == 0).any()):
+        for j in range(0, n, batch_size):          # an all-empty block makes the reference's max() over an empty dim raise
+            if int(lengths[j: j + batch_size].max()) == 0:
+                raise RuntimeError("max(): Expected reduction dim 3 to have non-zero size.")
+    n_q = len(q)
+    q_dim = q.tokens.shape[1] if isinstance(q, PackedQueries) else q.shape[2]
+    if q_dim != dim:
+        raise RuntimeError(f"queries have embedding width {q_dim}, the corpus {dim}")
+    _stamp("checked")
+    main = torch.cuda.current_stream(dev)
+    side = copy_stream(dev)
+    with torch.cuda.device(dev):
+        blob = torch.empty((total_rows, dim), dtype=dtype, device=dev)
+        off_host = torch.zeros(n + 1, dtype=torch.int32)
+        off_host[1:] = torch.from_numpy((prefix[1:] // row_bytes).astype(np.int32))
+        offsets = off_host.to(dev, non_blocking=True)
+        clamp0 = flags.to(dev, non_blocking=True) if bool(flags.any()) else None
+        out = torch.empty((n_q, n), dtype=torch.float32, device=dev)
+        side.wait_stream(main)                       # the blob's memory may still be in use by earlier work of the caller's stream
+        # passage sub-ranges: whole blocks of `batch_size`, about _PIPE_RANGE_BYTES each, at most eight
+        n_blocks = (n + batch_size - 1) // batch_size
+        n_sub = max(1, min(n_blocks, 8, total // _PIPE_RANGE_BYTES))
+        cuts = sorted({min(n, ((n_blocks * i + n_sub - 1) // n_sub) * batch_size) for i in range(1, n_sub + 1)} | {n})
+        state = [0, 0]                               # first passage not yet scored, next cut
+
+        def score_arrived(bytes_done: int) -> None:
+            while state[1] < len(cuts) and int(prefix[cuts[state[1]]]) <= bytes_done:
+                lo, hi = state[0], cuts[state[1]]
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+                if hi > lo:
+                    # the WHOLE blob with the sub-range's slice of the absolute row offsets: nothing is re-based, the kernels only touch
+                    # rows of passages lo .. hi-1, which have arrived
+                    part = PackedCorpus(blob=blob, offsets=offsets[lo:hi + 1], clamp0=None if clamp0 is None else clamp0[lo:hi],
+                                        lengths=lengths[lo:hi])
+                    maxsim_scores(q, part, ref_rounding=ref_rounding, out=out[:, lo:hi])
+                state[0] = hi
+                state[1] += 1
+
+        _staging.upload_image(srcs, prefix, n, blob.view(torch.uint8).view(-1), side, on_chunk=score_arrived)
+        _stamp("issued")
+        scores = out.cpu()
+        blob.record_stream(side)                       # written on the copy stream: its memory is not reused before that stream is done
+        _stamp("done")
+    del keep
     return scores.to(torch.float32)
 
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 17
+#define MSIM_ABI_VERSION 18
 
 /* error codes */
 #define MSIM_OK 0
@@ -68,6 +68,11 @@ extern "C" {
                                        contraction in the embeddings' own dtype: every similarity rounded to
                                        that dtype before the max, the token sum rounded to it
                                        (processing_utils.py:179 evaluated on bf16 / fp16 tensors) */
+
+#define MSIM_FLAG_AVG_ROWS(n) ((uint32_t)((n) < 0 ? 0 : ((n) > 65535 ? 65535 : (n))) << 8)
+                                    /* optional launch-shape hint for msim_fwd / msim_fwd_ragged: the average number of rows per document
+                                       (the row offsets live on the device; the launch plan is made on the host).  Only the number of
+                                       document ranges the corpus is cut into depends on it -- speed, never a score.  0 = unknown. */
 
 int msim_abi_version(void);
 const char *msim_last_error(void);
@@ -155,6 +160,20 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
                     uint32_t flags, void *workspace, void *stream);
 
 /*
+ * The same scores for two DENSE BOXES when the queries are long and the documents short -- the symmetric direction of the reference
+ * trainer (trainer/contrastive_trainer.py:202-206, compute_symetric_loss: the pages as query_embeddings [B, 780, 128], the gathered
+ * queries as doc_embeddings [C, 32, 128]; late_interaction_losses.py:297-298):
+ *     scores[q, c] = sum_{i < Lq} max_{j < Ld} <Q[q, i, :], D[c, j, :]>
+ * Q [n_q, Lq, 128], D [n_d, Ld, 128] (bf16 | f16, Ld <= 128; every row of a box takes part, zero padding rows included, as in the
+ * reference), scores fp32 [n_q, ld_scores].  The long side streams, the short side is resident (kernel K1t, maxsim_batch_t.hip):
+ * msim_fwd gives the same numbers up to fp32 summation order, 2-3 x slower on this shape (a 32-row document is one slab).
+ * q_lengths: NULL, or int32 [n_q] that receives, as a by-product of streaming every query row, the number of rows of query q whose
+ * first component is non-zero -- the `lengths` of late_interaction_losses.py:296, which msim_loss_epilogue accepts ready-made.
+ */
+int msim_fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim,
+                        float *scores, int64_t ld_scores, int32_t *q_lengths, void *stream);
+
+/*
  * Packing queries into the flat layout: rows that are entirely zero (the model's padded positions,
  * modeling_colpali.py:72 / modeling_colqwen2.py:69; byte-wise test) are dropped, the others keep their order.
  *   msim_query_compact        device: box [n_q, Lq, row_bytes] (row_bytes a multiple of 16, Lq <= 4096).  counts != NULL:
@@ -182,10 +201,16 @@ int msim_host_gather_nonzero_rows(void *dst, const void *const *src, const int64
  * and the forward of the paired contractions "bnd,bsd->bns" / "bnd,blsd->blns" (:235-238, :381-384).
  * pairs: int32 [n_pairs, 2] = (query index, document index).
  * out_scores: fp32 [n_pairs] or NULL; out_argmax: int32 [n_pairs, Lq] or NULL.
+ * max_doc_rows: an upper bound of the longest document's rows, or 0 = unknown.  It only selects the kernel: queries of more than
+ * 128 tokens against documents of at most 128 rows (bf16 / f16, dim 128: the trainer's symmetric direction,
+ * trainer/contrastive_trainer.py:202-206 -- pages as query_embeddings, queries as doc_embeddings) take the transposed pair
+ * kernel (the long side streams, the short side is resident); with 0 they take the generic kernel (same results up to ties'
+ * first-maximum rule, which both follow).  Short lists (<= 1024 pairs) are worked on by one workgroup per pair, long ones by one
+ * wave per pair.
  */
 int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq,
                       const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
-                      int n_d, int dim,
+                      int n_d, int dim, int max_doc_rows,
                       const int32_t *pairs, int n_pairs,
                       float *out_scores, int32_t *out_argmax, void *stream);
 
@@ -197,13 +222,17 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq,
  * i.e. what autograd produces for einsum -> amax -> sum
  * (late_interaction_losses.py:297-298) restricted to the pairs whose upstream gradient is
  * non-zero (for ColbertPairwiseCELoss, :309-313, two per query).
- * dQ fp32 [n_q, Lq, dim] and dD fp32 [total_rows, dim] are fully overwritten (rows without a
- * contribution are set to 0).  Deterministic: no floating-point atomics.
+ * dQ [n_q, Lq, dim] and dD [total_rows, dim] are fully overwritten (rows without a contribution are set to 0), as fp32
+ * (out_dtype = MSIM_DTYPE_F32) or in the embeddings' own dtype (out_dtype = dtype: one rounding of the fp32 sum -- what autograd's
+ * `.to(dtype)` would do in a launch of its own).  Deterministic: no floating-point atomics.
+ * g_scale: NULL, or a DEVICE scalar (g_scale_dtype: bf16 / f16 / f32) every g[p] is multiplied by -- the loss' upstream gradient as
+ * autograd hands it over (a 0-dim tensor), folded into the kernels instead of a `coef * grad` launch in front of them.
  * `pairs` must be sorted by query index; `order_by_doc` is a permutation of 0..n_pairs-1 that
  * sorts the pairs by document index (stable); `max_doc_rows` >= the longest document.
  * `workspace`: msim_pairs_bwd_workspace_bytes() bytes of 16-byte aligned device scratch (contents irrelevant), or NULL.  It is
  * non-zero when short documents (<= 64 rows) collect long entry lists -- the symmetric direction of the reference trainer
- * (trainer/contrastive_trainer.py:202-206: pages as query_embeddings, queries as doc_embeddings): every document's pair list
+ * (trainer/contrastive_trainer.py:202-206: pages as query_embeddings, queries as doc_embeddings), dense upstream gradients or
+ * queries of 256 tokens and more: every document's pair list
  * is then split over several workgroups whose partial sums are added in split order (still deterministic, still no atomics).
  * NULL is legal and only selects the one-workgroup-per-row-range form (the same values up to fp32 summation order).
  */
@@ -211,8 +240,9 @@ size_t msim_pairs_bwd_workspace_bytes(int n_q, int Lq, int n_d, int dim, int max
 int msim_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
                    const void *D, const int32_t *d_off, int n_d, int dim, int max_doc_rows,
                    const int32_t *pairs, const int32_t *order_by_doc,
-                   const float *g, const int32_t *argmax, int n_pairs,
-                   float *dQ, float *dD, void *workspace, void *stream);
+                   const float *g, const void *g_scale, int g_scale_dtype,
+                   const int32_t *argmax, int n_pairs,
+                   int out_dtype, void *dQ, void *dD, void *workspace, void *stream);
 
 /*
  * Smooth-max late interaction (training losses constructed with use_smooth_max=True):
@@ -259,17 +289,23 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
  *   INFONCE   G fp32 [B, ld] = dLoss/dscores (dense).
  * Q [B, Lq, width] are the query embeddings (q_dtype as in msim_fwd): lengths[b] = number of tokens whose first component is
  * non-zero.  out fp32 [3] = loss, min and max of the normalised scores (the reference prints when they leave [-tol, 1+tol]).
- * workspace: msim_loss_epilogue_workspace_bytes(B) bytes, 16-byte aligned, ZERO-FILLED once by the caller before its first use
- * (the call leaves it ready for the next one); one workspace per stream.  offset + B <= C.
+ * q_lengths: NULL (the token counts are taken from Q here), or int32 [B] = lengths[b] ready-made (msim_fwd_transposed's by-product:
+ * for 780-token "queries" -- the trainer's symmetric direction -- counting them here means one cache line per token on one CU).
+ * loss_out: NULL, or one element of q_dtype that receives the loss rounded to the embeddings' dtype (what the reference's forward
+ * returns: bf16 in -> bf16 scalar) -- no cast launch behind the kernel.
+ * workspace: msim_loss_epilogue_workspace_bytes(B, C) bytes, 16-byte aligned, ZERO-FILLED once by the caller before its first use
+ * (the call leaves it ready for the next one); one workspace per stream.  0 bytes (workspace may be NULL) for small batches --
+ * B <= 1024 and B * C <= 262 144, BASELINE config 5's 32 x 256 among them: one workgroup reads the whole score matrix, one wave per
+ * row, and keeps the per-row terms in LDS; larger ones run one workgroup per row and a ticket.  offset + B <= C.
  */
 #define MSIM_LOSS_PAIRWISE 0
 #define MSIM_LOSS_INFONCE 1
-size_t msim_loss_epilogue_workspace_bytes(int B);
+size_t msim_loss_epilogue_workspace_bytes(int B, int C);
 int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C,
                        const void *Q, int q_dtype, int Lq, int width, int offset,
                        float temperature, int normalize, int filter, float filter_threshold, float filter_factor,
                        float *G, int32_t *pairs, float *coef, int32_t *order,
-                       void *workspace, float *out, void *stream);
+                       void *workspace, float *out, void *loss_out, const int32_t *q_lengths, void *stream);
 
 /*
  * Embedding head: the last three lines of every Col* model forward, producing the scorer's corpus format.
@@ -364,6 +400,11 @@ int msim_pool_reduce(int dtype, const void *E, const int32_t *d_off, int n_pages
  * issued from python threads fight over the interpreter lock (70 ms stalls in a 10 ms call were measured).
  */
 int msim_host_gather(void *dst, const void *const *src, const int64_t *dst_off, const int64_t *nbytes, int64_t n, int n_threads);
+/* The same for a BYTE RANGE of the image: buffer i holds image bytes prefix[i] .. prefix[i+1]-1 (prefix: n + 1 non-decreasing numbers);
+ * bytes [lo, hi) of the image are copied to dst (dst[0] = image byte lo), cut into equal byte shares over a persistent pool of native
+ * threads (no thread is started per call).  The upload path sends the image through a bounded pinned staging buffer chunk by chunk:
+ * one call per chunk, nothing per page on the Python side. */
+int msim_host_gather_range(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -263,15 +263,23 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
         pairs = torch.empty((2 * B, 2), dtype=torch.int32, device=dev)
         coef = torch.empty((2 * B,), dtype=torch.float32, device=dev)
         order = torch.empty((2 * B,), dtype=torch.int32, device=dev)
-        ws = torch.zeros((L.msim_loss_epilogue_workspace_bytes(B),), dtype=torch.uint8, device=dev)
+        assert L.msim_loss_epilogue_workspace_bytes(B, C) == 0      # a small batch: one workgroup, no scratch (NULL is legal)
         out = torch.empty((3,), dtype=torch.float32, device=dev)
-        for rep in range(2):                          # twice on the same workspace: the ticket counter resets itself
+        loss16 = torch.full((), float("nan"), dtype=torch.bfloat16, device=dev)
+        lens32 = lengths.to(torch.int32).contiguous()
+        for rep in range(2):                          # the token counts taken from Q, then handed over ready-made: the same results
             rc = L.msim_loss_epilogue(mode, raw.data_ptr(), C, B, C, Q.data_ptr(), 0, Lq, 128, offset, T, int(norm), int(filt), 0.95, 0.5,
-                                      G.data_ptr(), pairs.data_ptr(), coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(),
-                                      torch.cuda.current_stream().cuda_stream)
+                                      G.data_ptr(), pairs.data_ptr(), coef.data_ptr(), order.data_ptr(), None, out.data_ptr(),
+                                      loss16.data_ptr(), lens32.data_ptr() if rep else None, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, L.msim_last_error()
+            if rep == 0:
+                torch.cuda.synchronize()
+                first = (float(out[0]), coef.clone(), pairs.clone(), G.clone())
+        torch.cuda.synchronize()
+        assert float(out[0]) == first[0] and torch.equal(coef, first[1]) and torch.equal(pairs, first[2]) and torch.equal(G, first[3])
         torch.cuda.synchronize()
         assert abs(float(out[0]) - float(want.detach())) <= 1e-5 * abs(float(want.detach())) + 1e-6, (mode, T, norm, filt)
+        assert float(loss16) == float(out[0].to(torch.bfloat16))          # the loss in the embeddings' dtype: one rounding
         if mode == 0:
             got = torch.zeros((B, C), dtype=torch.float32, device=dev)
             got.index_put_((pairs[:, 0].long(), pairs[:, 1].long()), coef, accumulate=True)
@@ -299,9 +307,54 @@ def test_loss_epilogue_matches_the_torch_expression_on_adversarial_scores(amd):
         assert abs(float(out[1]) - float(want_lo)) < 1e-5
     # argument checks
     assert L.msim_loss_epilogue(0, raw.data_ptr(), C, B, C, Q.data_ptr(), 0, Lq, 128, C - B + 1, 1.0, 0, 0, 0.95, 0.5, None, pairs.data_ptr(),
-                                coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(), None) == -1
+                                coef.data_ptr(), order.data_ptr(), None, out.data_ptr(), None, None, None) == -1
     assert L.msim_loss_epilogue(0, raw.data_ptr(), 1, 1, 1, Q.data_ptr(), 0, Lq, 128, 0, 1.0, 0, 0, 0.95, 0.5, None, pairs.data_ptr(),
-                                coef.data_ptr(), order.data_ptr(), ws.data_ptr(), out.data_ptr(), None) == -1
+                                coef.data_ptr(), order.data_ptr(), None, out.data_ptr(), None, None, None) == -1
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_loss_epilogue_large_batch_form_equals_the_small_batch_form_row_by_row(amd, mode):
+    """B * C above 262 144 scores: one workgroup per row + the ticket (zero-filled scratch, reusable) instead of the one-workgroup
+    form.  Both run the same per-row code: the pair list / G of the first rows of a large batch must equal what the small form
+    emits for those rows scored alone with the same 1 / B weighting, and the loss must equal the torch expression."""
+    import torch.nn.functional as F
+
+    L = amd._lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    B, C, Lq, offset, T = 520, 610, 8, 37, 0.5
+    Q = torch.randn(B, Lq, 128, generator=g).to(torch.bfloat16).to(dev)
+    raw = (torch.rand(B, C, generator=g) * 8 + 1).to(dev).contiguous()
+    need = L.msim_loss_epilogue_workspace_bytes(B, C)
+    assert need > 0
+    G = torch.zeros((B, C), dtype=torch.float32, device=dev)
+    pairs = torch.empty((2 * B, 2), dtype=torch.int32, device=dev)
+    coef = torch.empty((2 * B,), dtype=torch.float32, device=dev)
+    order = torch.empty((2 * B,), dtype=torch.int32, device=dev)
+    out = torch.empty((3,), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (mode, raw.data_ptr(), C, B, C, Q.data_ptr(), 0, Lq, 128, offset, T, 1, 1, 0.95, 0.5, G.data_ptr(), pairs.data_ptr(),
+            coef.data_ptr(), order.data_ptr())
+    assert L.msim_loss_epilogue(*args, None, out.data_ptr(), None, None, st) == -1           # this size needs its scratch
+    ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
+    for _ in range(2):                                                               # twice on the same scratch: the ticket resets itself
+        assert L.msim_loss_epilogue(*args, ws.data_ptr(), out.data_ptr(), None, None, st) == 0, L.msim_last_error()
+    torch.cuda.synchronize()
+    s = raw / (Q[:, :, 0] != 0).sum(dim=1).unsqueeze(1)
+    idx = torch.arange(B, device=dev)
+    lim = 0.95 * s[idx, idx + offset].unsqueeze(1)
+    m = s > lim
+    m[idx, idx + offset] = False
+    s = s * torch.where(m, 0.5, 1.0)
+    if mode == 0:
+        pos = s.diagonal(offset=offset)
+        top2 = s.topk(2, dim=1).values
+        want = F.softplus((torch.where(top2[:, 0] == pos, top2[:, 1], top2[:, 0]) - pos) / T).mean()
+        docs = pairs[:, 1].long()
+        assert torch.equal(order.long(), torch.sort(docs, stable=True).indices)
+    else:
+        want = F.cross_entropy(s / T, idx + offset)
+    assert abs(float(out[0]) - float(want)) <= 1e-5 * abs(float(want)) + 1e-6
 
 
 def test_probe_mfma_runs_and_validates_arguments(amd):

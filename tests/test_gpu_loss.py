@@ -573,7 +573,7 @@ def test_dense_dd_form_equals_the_row_range_form_and_the_float64_scatter(amd, dt
         nbytes = lib.msim_pairs_bwd_workspace_bytes(B, Lq, C, 128, Ld, B * C)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device) if use_ws else None
         rc = lib.msim_pairs_bwd(_lib.dtype_code(dtype), _lib.ptr(q), B, Lq, _lib.ptr(d), _lib.ptr(offsets), C, 128, Ld, _lib.ptr(pairs),
-                                _lib.ptr(order), _lib.ptr(gp), _lib.ptr(argmax), B * C, _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws),
+                                _lib.ptr(order), _lib.ptr(gp), None, 0, _lib.ptr(argmax), B * C, 2, _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws),
                                 _lib.current_stream_handle(q.device))
         _lib.check(rc, "msim_pairs_bwd")
         outs.append((dq.cpu(), dd.cpu()))
@@ -589,3 +589,143 @@ def test_dense_dd_form_equals_the_row_range_form_and_the_float64_scatter(amd, dt
     for dq, dd in outs:
         assert torch.isfinite(dd).all()
         assert float((dd.double() - want).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("shape", [(6, 11, 32, 300), (5, 9, 780, 32), (3, 4, 45, 70)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gradients_in_the_embedding_dtype_with_the_upstream_scalar_folded_in(amd, shape, dtype):
+    """msim_pairs_bwd(out_dtype = dtype, g_scale = a device scalar): dQ / dD leave the kernels in the embeddings' own 16-bit dtype
+    with every pair's gradient multiplied by the scalar -- what `(coef * grad).to(fp32)` -> kernels -> `.to(dtype)` did in five
+    launches.  Against the fp32 outputs of the same call without the scalar: out16 == round(fp32 * scale) up to the one product
+    that is now formed before the sum (1 ulp of the 16-bit result), for the row-range dD form, the dense form (long queries, short
+    documents) and documents that receive nothing (rows of zeros)."""
+    from colpali_amd import _lib, loss as L_
+
+    B, C, Lq, Ld = shape
+    g = torch.Generator().manual_seed(11 + Lq)
+    q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1).to(dtype).cuda()
+    d = torch.nn.functional.normalize(torch.randn(C, Ld, 128, generator=g), dim=-1).to(dtype).cuda()
+    # a sparse pair list sorted by query: two documents per query, some documents never named
+    docs = torch.stack([torch.arange(B) % (C - 2), (torch.arange(B) * 3 + 1) % (C - 2)], 1).sort(dim=1).values
+    pairs = torch.stack([torch.arange(B).repeat_interleave(2), docs.reshape(-1)], 1).to(torch.int32).cuda().contiguous()
+    order = torch.sort(pairs[:, 1].long(), stable=True).indices.to(torch.int32).contiguous()
+    gp = torch.randn(2 * B, generator=g).cuda()
+    offsets = L_._dense_corpus(d).offsets
+    _, argmax = L_.maxsim_pairs(q, d, offsets, pairs, want_scores=False)
+    lib = _lib.lib()
+    code = _lib.dtype_code(dtype)
+    nbytes = lib.msim_pairs_bwd_workspace_bytes(B, Lq, C, 128, Ld, 2 * B)
+    assert (nbytes > 0) == (Ld <= 64 and Lq >= 256)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=q.device)
+
+    def run(out_dtype, scale):
+        dq = torch.full((B, Lq, 128), float("nan"), dtype=out_dtype, device=q.device)
+        dd = torch.full((C, Ld, 128), float("nan"), dtype=out_dtype, device=q.device)
+        rc = lib.msim_pairs_bwd(code, _lib.ptr(q), B, Lq, _lib.ptr(d), _lib.ptr(offsets), C, 128, Ld, _lib.ptr(pairs), _lib.ptr(order),
+                                _lib.ptr(gp), _lib.ptr(scale), _lib.dtype_code(scale.dtype) if scale is not None else 0, _lib.ptr(argmax),
+                                2 * B, 2 if out_dtype == torch.float32 else code, _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws if nbytes else None),
+                                _lib.current_stream_handle(q.device))
+        _lib.check(rc, "msim_pairs_bwd")
+        return dq, dd
+
+    dq32, dd32 = run(torch.float32, None)
+    for scale in (torch.tensor(0.375, dtype=dtype, device=q.device), torch.tensor(-2.5, dtype=torch.float32, device=q.device)):
+        dq16, dd16 = run(dtype, scale)
+        for got, ref in ((dq16, dq32), (dd16, dd32)):
+            want = ref * float(scale)
+            assert got.dtype == dtype and torch.isfinite(got.float()).all()
+            ulp = torch.exp2(torch.floor(torch.log2(want.abs().clamp_min(1e-30))) - (7 if dtype == torch.bfloat16 else 10))
+            # + fp32 noise of the terms themselves (hits of opposite sign that nearly cancel leave a residue far below their size)
+            assert bool(((got.float() - want).abs() <= ulp + 1e-6 * float(want.abs().max())).all())
+        untouched = torch.ones(C, dtype=torch.bool)
+        untouched[pairs[:, 1].long().cpu()] = False
+        assert bool((dd16[untouched.cuda()] == 0).all())
+    with pytest.raises(ValueError):                      # fp32 embeddings have no 16-bit output; a foreign out dtype is refused
+        rc = lib.msim_pairs_bwd(code, _lib.ptr(q), B, Lq, _lib.ptr(d), _lib.ptr(offsets), C, 128, Ld, _lib.ptr(pairs), _lib.ptr(order),
+                                _lib.ptr(gp), None, 0, _lib.ptr(argmax), 2 * B, 1 - code, _lib.ptr(dq32), _lib.ptr(dd32), None,
+                                _lib.current_stream_handle(q.device))
+        _lib.check(rc, "msim_pairs_bwd")
+
+
+@pytest.mark.parametrize("n_pairs", [7, 64, 1500])
+@pytest.mark.parametrize("Lq,Ld", [(32, 780), (100, 33), (780, 32), (300, 70), (200, 128)])
+def test_pair_kernels_in_every_form_agree_with_the_float64_similarities(amd, n_pairs, Lq, Ld):
+    """msim_pairs_argmax: one workgroup per pair (<= 1024 pairs), one wave per pair (more), and the transposed kernel (queries of more
+    than 128 tokens against documents of at most 128 rows: the trainer's symmetric direction) -- scores within 1e-5 of float64, the
+    routing a row that attains the maximum (to fp32 noise), -1 never (no clamp0 here); ragged documents through the packed layout."""
+    from colpali_amd import _lib
+
+    g = torch.Generator().manual_seed(Lq * 7 + Ld + n_pairs)
+    n_q, n_d = 5, 9
+    q = torch.nn.functional.normalize(torch.randn(n_q, Lq, 128, generator=g), dim=-1).to(torch.bfloat16)
+    q[1, : Lq // 3] = 0                                                    # left padding rows
+    lens = torch.randint(max(1, Ld // 2), Ld + 1, (n_d,), generator=g)
+    lens[0] = Ld
+    rows = [torch.nn.functional.normalize(torch.randn(int(n), 128, generator=g), dim=-1).to(torch.bfloat16) for n in lens]
+    blob = torch.cat(rows).cuda()
+    off = torch.zeros(n_d + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0)
+    pairs = torch.stack([torch.sort(torch.randint(0, n_q, (n_pairs,), generator=g)).values, torch.randint(0, n_d, (n_pairs,), generator=g)], 1).to(torch.int32)
+    lib = _lib.lib()
+    qd, offd, pd = q.cuda(), off.cuda(), pairs.cuda().contiguous()
+    scores = torch.full((n_pairs,), float("nan"), device="cuda")
+    argmax = torch.full((n_pairs, Lq), -7, dtype=torch.int32, device="cuda")
+    rc = lib.msim_pairs_argmax(0, _lib.ptr(qd), n_q, Lq, _lib.ptr(blob), _lib.ptr(offd), None, n_d, 128, Ld, _lib.ptr(pd), n_pairs,
+                               _lib.ptr(scores), _lib.ptr(argmax), _lib.current_stream_handle(qd.device))
+    _lib.check(rc, "msim_pairs_argmax")
+    scores, argmax = scores.cpu(), argmax.cpu().long()
+    q64 = q.double()
+    checked = set()
+    for p in range(n_pairs):
+        b, c = int(pairs[p, 0]), int(pairs[p, 1])
+        sim = q64[b] @ rows[c].double().t()                                 # [Lq, len]
+        want = sim.max(dim=1).values
+        assert abs(float(scores[p]) - float(want.sum())) <= 1e-5 * max(1.0, abs(float(want.sum())))
+        if (b, c) in checked:
+            continue
+        checked.add((b, c))
+        am = argmax[p]
+        assert int(am.min()) >= 0 and int(am.max()) < int(lens[c])
+        assert float((sim.gather(1, am[:, None])[:, 0] - want).abs().max()) <= 2e-6
+        zero_rows = q[b].abs().sum(-1) == 0
+        assert bool((am[zero_rows] == 0).all())                              # all-equal similarities: the first row wins
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n_q,Lq,n_d,Ld", [(32, 780, 256, 32), (3, 129, 5, 1), (7, 300, 70, 40), (2, 1000, 9, 128), (5, 200, 33, 70),
+                                           (9, 131, 300, 16), (1, 4097, 3, 48)])
+def test_transposed_forward_kernel_against_float64(amd, dtype, n_q, Lq, n_d, Ld):
+    """msim_fwd_transposed (K1t: the long side streams, the short documents are resident -- the trainer's symmetric direction,
+    contrastive_trainer.py:202-206) against a float64 einsum -> amax -> sum on the same 16-bit values: within 1e-5, for every unit
+    count (1, 2, 3, 4, 8 units of 16 rows; lengths that are not multiples of 16: the register rows beyond the document are masked to
+    -inf, so a document whose similarities are ALL negative must not see a 0), zero padding rows inside the boxes (they do take part,
+    as in the reference), page tails that are not multiples of 32 / 128 rows, more documents than one block, and against msim_fwd on
+    the same boxes (fp32 summation order apart)."""
+    from colpali_amd import _lib
+
+    g = torch.Generator().manual_seed(n_q * 1000 + Lq + Ld)
+    q = torch.nn.functional.normalize(torch.randn(n_q, Lq, 128, generator=g), dim=-1)
+    d = torch.nn.functional.normalize(torch.randn(n_d, Ld, 128, generator=g), dim=-1)
+    q[0, : Lq // 4] = 0                                       # left padding rows of a page
+    if n_d > 2 and Ld > 2:
+        d[1, : Ld // 2] = 0                                   # left padding rows of a query-as-document
+        d[2] = -q[min(1, n_q - 1), :Ld] if Lq >= Ld else d[2]  # every similarity with that page's own rows strongly negative
+    q, d = q.to(dtype).cuda(), d.to(dtype).cuda()
+    lib = _lib.lib()
+    got = torch.full((n_q, n_d + 3), float("nan"), device="cuda")
+    lens = torch.full((n_q,), -1, dtype=torch.int32, device="cuda")
+    rc = lib.msim_fwd_transposed(_lib.dtype_code(dtype), _lib.ptr(q), n_q, Lq, _lib.ptr(d), n_d, Ld, 128, _lib.ptr(got), n_d + 3,
+                                 _lib.ptr(lens), _lib.current_stream_handle(q.device))
+    _lib.check(rc, "msim_fwd_transposed")
+    assert torch.equal(lens.cpu(), (q[:, :, 0] != 0).sum(dim=1).to(torch.int32).cpu())      # late_interaction_losses.py:296, as a by-product
+    assert torch.isnan(got[:, n_d:]).all()                    # nothing beyond the n_d columns is written
+    want = torch.einsum("bnd,csd->bcns", q.double().cpu(), d.double().cpu()).amax(dim=3).sum(dim=2)
+    err = (got[:, :n_d].double().cpu() - want).abs() / want.abs().clamp_min(1.0)
+    assert float(err.max()) <= 1e-5, float(err.max())
+    from colpali_amd import loss as L_
+
+    other = amd.maxsim_scores(q, L_._dense_corpus(d))          # K1b on 128-token pieces (or the generic kernel): the same scores
+    assert float(((other - got[:, :n_d]).abs() / want.abs().clamp_min(1.0).cuda()).max()) <= 1e-5
+    # refused shapes
+    assert lib.msim_fwd_transposed(_lib.dtype_code(dtype), _lib.ptr(q), n_q, Lq, _lib.ptr(d), n_d, 129, 128, _lib.ptr(got), n_d + 3, None, None) == -2
+    assert lib.msim_fwd_transposed(2, _lib.ptr(q), n_q, Lq, _lib.ptr(d), n_d, Ld, 128, _lib.ptr(got), n_d + 3, None, None) == -2

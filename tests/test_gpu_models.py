@@ -147,3 +147,143 @@ def test_corpus_from_a_patched_model_scores_like_the_reference_road(patched):
     got = colpali_amd.score_multi_vector(qs, ps, device=DEV).numpy()
     want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps])
     assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)) <= 1e-5
+
+
+def _require_inductor():
+    """The compile tests need a working inductor (Triton code generation for gfx950) on this box: probe it on a trivial function and
+    skip -- not fail -- where the stock toolchain itself is unusable (that is not this repository's code)."""
+    import torch._dynamo as dynamo
+
+    try:
+        dynamo.reset()
+        x = torch.arange(64, device=DEV, dtype=torch.float32)
+        y = torch.compile(lambda t: torch.sin(t) * 2 + 1, backend="inductor")(x)
+        assert torch.allclose(y, torch.sin(x) * 2 + 1, atol=1e-5)
+    except Exception as e:      # noqa: BLE001
+        pytest.skip(f"torch.compile(backend='inductor') does not work on this box: {type(e).__name__}: {str(e)[:200]}")
+    finally:
+        dynamo.reset()
+
+
+def test_patched_model_under_torch_compile_inductor_dynamic(patched):
+    """trainer/colmodel_torch_training.py:57-63: `torch.compile(model, backend="inductor", dynamic=True)`.  While dynamo traces, the
+    wrapper steps aside (colpali_amd/models.py): the reference's own lines are what inductor compiles -- forward equal to the eager
+    unpatched model to the model dtype's rounding on two batch shapes, one graph, no graph break, no recompilation storm, a working
+    backward; outside compilation the same patched class still runs the fused head."""
+    import torch._dynamo as dynamo
+    from torch._dynamo.utils import counters
+
+    _require_inductor()
+    model, cls = tiny_colpali()
+    model = model.to(DEV, torch.bfloat16).train()
+    b1, b2 = text_batch(device=DEV), text_batch(B=3, S=21, seed=9, device=DEV)
+    with torch.no_grad():
+        want1, want2 = model(**b1), model(**b2)
+    colpali_amd.patch_colpali_engine(scorer=False, losses=False, models=True)
+    calls = []
+    real = M.embedding_head
+    M.embedding_head = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        dynamo.reset()
+        counters.clear()
+        compiled = torch.compile(model, backend="inductor", dynamic=True)
+        with torch.no_grad():
+            got1, got2 = compiled(**b1), compiled(**b2)
+        assert calls == [], "the fused head ran inside a compiled forward"
+        for got, want in ((got1, want1), (got2, want2)):
+            # inductor fuses the norm / divide / mask lines in fp32 and rounds once where eager rounds three times: two bf16 ulps
+            assert float((got.float() - want.float()).abs().max()) <= 2 * 2.0**-8
+        assert sum(counters["graph_break"].values()) == 0, dict(counters["graph_break"])
+        assert counters["stats"]["unique_graphs"] <= 2, dict(counters["stats"])        # dynamic=True: at most one re-trace for the second shape
+        y = compiled(**b1)
+        (y.float() ** 2).sum().backward()
+        assert model.custom_text_proj.weight.grad is not None and float(model.custom_text_proj.weight.grad.float().abs().max()) > 0
+        with torch.no_grad():
+            eager = model(**b1)                       # the same patched class outside compilation: the fused head
+        assert calls == [1]
+        assert one_ulp_close(eager, want1, torch.bfloat16)[0]
+    finally:
+        M.embedding_head = real
+        dynamo.reset()
+
+
+def test_patched_model_under_distributed_data_parallel(patched):
+    """trainer/colmodel_torch_training.py:57-59 wraps the model in DistributedDataParallel before compiling it: DDP calls
+    `module.forward`, i.e. the wrapper -- the fused head runs, its backward feeds DDP's gradient hooks (a 1-rank nccl group)."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        model, cls = tiny_colpali()
+        model = model.to(DEV, torch.bfloat16).train()
+        batch = text_batch(device=DEV)
+        G = torch.randn(5, 37, 128, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(torch.bfloat16)
+        model.zero_grad(set_to_none=True)
+        (model(**batch).float() * G.float()).sum().backward()
+        want = model.custom_text_proj.weight.grad.float().clone()
+        colpali_amd.patch_colpali_engine(scorer=False, losses=False, models=True)
+        calls = []
+        real = M.embedding_head
+        M.embedding_head = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+            model.zero_grad(set_to_none=True)
+            (ddp(**batch).float() * G.float()).sum().backward()
+        finally:
+            M.embedding_head = real
+        assert calls == [1], "the fused head did not run under DDP"
+        got = model.custom_text_proj.weight.grad.float()
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-6
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_lora_wrapped_projection_keeps_the_reference_lines_on_the_gpu(patched):
+    """scripts/configs/qwen2/train_colqwen2_model.yaml:62 puts a LoRA adapter on `custom_text_proj`: no longer a plain nn.Linear, so the
+    fused head (which reads `.weight` only) must not run -- eager and compiled -- and the adapter's term must be in the output."""
+    import torch._dynamo as dynamo
+
+    class LoraLinear(torch.nn.Module):
+        def __init__(self, base):
+            super().__init__()
+            self.base_layer = base
+            self.lora_A = torch.nn.Linear(base.in_features, 4, bias=False)
+            self.lora_B = torch.nn.Linear(4, base.out_features, bias=False)
+
+        def forward(self, x):
+            return self.base_layer(x) + self.lora_B(self.lora_A(x)) * 2.0
+
+    _require_inductor()
+    model, cls = tiny_colpali()
+    torch.manual_seed(3)
+    model.custom_text_proj = LoraLinear(model.custom_text_proj)
+    model = model.to(DEV, torch.bfloat16)
+    batch = text_batch(device=DEV)
+    with torch.no_grad():
+        want = model(**batch)
+    colpali_amd.patch_colpali_engine(scorer=False, losses=False, models=True)
+    calls = []
+    real = M.embedding_head
+    M.embedding_head = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            assert torch.equal(model(**batch), want)
+            dynamo.reset()
+            got = torch.compile(model, backend="inductor", dynamic=True)(**batch)
+        assert float((got.float() - want.float()).abs().max()) <= 2 * 2.0**-8
+        assert calls == []
+    finally:
+        M.embedding_head = real
+        dynamo.reset()
