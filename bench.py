@@ -197,6 +197,7 @@ def cpu_baseline(q_len, doc_len):
         "sample": f"{n_q} queries x {n_d} docs ({q_len}x128 vs {doc_len}x128), reference blocking batch_size=128, "
                   f"best of 2, torch CPU einsum/max/sum; bf16 inputs {best['bf16']:.0f} pairs/s, fp32 inputs {best['fp32']:.0f} pairs/s",
         "host_cpus": os.cpu_count(), "torch_num_threads": torch.get_num_threads(),
+        "cpus_the_container_grants": amd._lib.effective_cpus(),       # affinity and cgroup CPU quota (cpu.max): what `cores` can really use
     }
 
 
@@ -561,6 +562,8 @@ def loss_step_numbers(amd, dev):
                 for sname, step in (("forward_direction", lambda m=mod: one(m)), ("both_directions", lambda m=mod: both(m))):
                     for _ in range(3):
                         step()
+                    for t in leaves:                 # what the step itself allocates at its peak, gradients included: nothing of a
+                        t.grad = None                # previous step alive when the baseline is taken
                     torch.cuda.synchronize()
                     torch.cuda.reset_peak_memory_stats()
                     base = torch.cuda.memory_allocated()
@@ -1081,6 +1084,14 @@ def main():
     import colpali_amd as amd
 
     amd._lib.lib()  # fail loudly if the HIP library is missing
+    # torch sizes its intra-op pool by the host's CPU count (128 threads on a 256-CPU box) -- not by what the container may use
+    # (cgroup cpu.max: 16 CPUs per 100 ms on the GPU boxes).  128 OpenMP threads spinning behind any CPU-side torch op run that quota
+    # dry and the kernel freezes the WHOLE process for the rest of the period: HIP-event kernel times of single launches came out
+    # 5-10 x too long in this file's regimes (the launch sat between two event records while the host was frozen), and the drop-in
+    # call stalled 70-90 ms in one call out of four (rounds 1-4; profiles/r05_logs/dropin_stalls.log).  Use what is granted.
+    granted = amd._lib.effective_cpus()
+    if torch.get_num_threads() > granted:
+        torch.set_num_threads(granted)
     corpus = make_shard(args.docs, args.doc_len, dev, seed=1234 + rank)
     corpus.id_base = rank * args.docs
     q = make_queries(args.nq, args.q_len, dev, seed=99)
@@ -1203,11 +1214,6 @@ def main():
         out["dropin_from_host_lists"] = dropin_numbers(amd)
         out["embed_and_score_1k_pages"] = embed_and_score_numbers(amd, dev)
         out["resident_colqwen2_page_geometry"] = ragged_docs_numbers(amd, dev, args.topk)
-        if os.environ.get("BENCH_LOSS", "1") != "0":
-            try:
-                out["loss_step_config5"] = loss_step_numbers(amd, dev)                 # BASELINE config 5
-            except Exception as e:
-                out["loss_step_config5"] = {"error": f"{type(e).__name__}: {e}"}
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
@@ -1251,6 +1257,12 @@ def main():
         out["roofline"]["power"]["kernel_ms_on_zeros"] = rz["kernel_ms"]
         del zero_corpus
     out["regimes"] = regimes
+    out["host_threads"] = {"torch_num_threads": torch.get_num_threads(), "cpus_the_container_grants": granted, "host_cpus": os.cpu_count()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("BENCH_LOSS", "1") != "0":
+        try:
+            out["loss_step_config5"] = loss_step_numbers(amd, dev)                 # BASELINE config 5 (after the timed regimes: its float64
+        except Exception as e:                                                     # oracle is a minute of CPU work)
+            out["loss_step_config5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("BENCH_VLM", "1") != "0":
         for key, family in (("embed_and_score_1k_pages_vlm_in_the_loop", "colpali"),              # BASELINE config 2
                             ("embed_and_score_1k_pages_vlm_in_the_loop_colqwen2", "colqwen2")):     # BASELINE config 3

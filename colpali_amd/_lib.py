@@ -191,6 +191,33 @@ class StreamConstCache:
         return len(self._d)
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: the scheduler affinity AND the container's CPU quota (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`).  A GPU box reports 256 CPUs and grants 16: native thread counts taken from
+    os.cpu_count() / torch.get_num_threads() (128 there) run the quota dry, and the kernel then freezes the whole process for the
+    rest of the 100 ms period (round 5: profiles/r05_logs/dropin_stalls.log)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 

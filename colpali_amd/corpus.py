@@ -35,14 +35,24 @@ def block_clamp0(lengths: torch.Tensor, batch_size: int) -> torch.Tensor:
     """
     if batch_size <= 0:
         raise ValueError("batch_size must be positive")
-    n = lengths.numel()
-    lengths = lengths.to(torch.int64).cpu()
+    # numpy on purpose: a torch CPU op on this path (repeat_interleave / max over a dim) wakes torch's whole intra-op pool -- 128
+    # OpenMP threads on the GPU box, each spinning ~5 ms after the parallel region: 700 ms of CPU time per 9 ms call, which ran the
+    # container's CPU quota (cgroup cpu.max: 16 CPUs per 100 ms) dry and froze the process for the rest of the period.  That was the
+    # "70-90 ms stall in one call out of four" of rounds 1-4 (profiles/r05_logs/dropin_stalls.log: nr_throttled +1 in every slow call)
+    import numpy as np
+
+    ln = lengths.detach().to("cpu").numpy().astype(np.int64, copy=False)
+    n = ln.size
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.uint8)
     if batch_size >= n:                   # one block (and no padding to a multiple of a huge batch_size)
-        return (lengths < (lengths.max() if n else 0)).to(torch.uint8)
-    pad = (-n) % batch_size
-    padded = torch.cat([lengths, lengths.new_full((pad,), -1)]) if pad else lengths
-    block_max = padded.view(-1, batch_size).max(dim=1).values.repeat_interleave(batch_size)[:n]
-    return (lengths < block_max).to(torch.uint8)
+        flags = ln < ln.max()
+    else:
+        pad = (-n) % batch_size
+        padded = np.concatenate([ln, np.full((pad,), -1, dtype=np.int64)]) if pad else ln
+        block_max = np.repeat(padded.reshape(-1, batch_size).max(axis=1), batch_size)[:n]
+        flags = ln < block_max
+    return torch.from_numpy(flags.astype(np.uint8))
 
 
 @dataclass
@@ -83,7 +93,7 @@ def _widen(x: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(x, (0, width - x.shape[-1]))
 
 
-_COPY_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))
+_COPY_THREADS = max(1, min(8, _lib_mod.effective_cpus() // 2))      # half of what the container grants, at most 8
 # pinned host memory per staging buffer = two halves that alternate: while one half is on its way to the GPU the passages of the
 # next chunk are memcpy'd into the other, so a call costs max(host memcpy, PCIe upload) instead of their sum -- 32 MiB per half
 # is large enough for both to run at full speed and small enough for a 264 MB corpus (1000 ColPali pages) to overlap almost fully
@@ -385,31 +395,41 @@ def _flat_from_host_list(qs: Sequence[torch.Tensor], dim: int, device: torch.dev
     if total == 0:
         tokens.zero_()
     else:
+        # through the bounded pinned halves of the queries' staging buffer (two halves, an event each: a query set of any size pins
+        # STAGING_BYTES of host memory, never its own size -- round-4 advisor finding)
         st = _staging_q
-        with st.lock:
-            nbytes = total * row_bytes
-            if st.buf is None or st.buf.numel() < nbytes:
-                for ev in st.events:
-                    if ev is not None:
-                        ev.synchronize()
-                st.buf = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, pin_memory=True)
-                st.events = [None, None]
-            for ev in st.events:
-                if ev is not None:
-                    ev.synchronize()          # the previous upload has left the buffer
-            dst_row = np.ascontiguousarray(off[:-1])
-            if compact:
-                rc = L.msim_host_gather_nonzero_rows(st.buf.data_ptr(), srcs.ctypes.data, rows.ctypes.data, row_bytes,
-                                                     dst_row.ctypes.data, n, _COPY_THREADS)
-            else:
-                dst_off, nb = dst_row * row_bytes, rows * row_bytes
-                rc = L.msim_host_gather(st.buf.data_ptr(), srcs.ctypes.data, dst_off.ctypes.data, nb.ctypes.data, n, _COPY_THREADS)
-            if rc != 0:
-                raise RuntimeError(f"host query gather failed: {L.msim_last_error().decode()}")
-            tokens.view(torch.uint8).view(-1)[:nbytes].copy_(st.buf[:nbytes], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
-            st.events = [ev, None]
+        stream = torch.cuda.current_stream(device)
+        dst_bytes = tokens.view(torch.uint8).view(-1)
+        if not compact:
+            prefix = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(rows * row_bytes, out=prefix[1:])
+            st.upload_image(srcs, prefix, n, dst_bytes[:total * row_bytes], stream)
+        else:
+            with st.lock:
+                half = st._halves(total * row_bytes)
+                base = st.buf.data_ptr()
+                g0 = 0
+                while g0 < n:                         # groups of whole queries whose compacted rows fit one half (a query is <= 256 KiB)
+                    g1 = g0 + 1
+                    while g1 < n and (off[g1 + 1] - off[g0]) * row_bytes <= half:
+                        g1 += 1
+                    nb = int(off[g1] - off[g0]) * row_bytes
+                    if nb:
+                        h = st.next_half
+                        st.next_half ^= 1
+                        if st.events[h] is not None:
+                            st.events[h].synchronize()          # the previous upload has left this half
+                        dst_row = np.ascontiguousarray(off[g0:g1] - off[g0])
+                        rc = L.msim_host_gather_nonzero_rows(base + h * half, srcs[g0:g1].ctypes.data, rows[g0:g1].ctypes.data, row_bytes,
+                                                             dst_row.ctypes.data, g1 - g0, _COPY_THREADS)
+                        if rc != 0:
+                            raise RuntimeError(f"host query gather failed: {L.msim_last_error().decode()}")
+                        lo = int(off[g0]) * row_bytes
+                        dst_bytes[lo:lo + nb].copy_(st.buf[h * half: h * half + nb], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        st.events[h] = ev
+                    g0 = g1
     del keep
     return PackedQueries(tokens=tokens, offsets=offsets_host.to(device, non_blocking=True), offsets_host=offsets_host)
 

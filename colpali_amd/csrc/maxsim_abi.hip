@@ -506,8 +506,9 @@ template <int TPQ, bool F16, int WPP>
 int launch_pairs_argmax(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                         const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                         const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ, F16, WPP>;
-    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes + (WPP > 1 ? 4 * TPQ * msim::kTokTile * 8 : 0);
+    constexpr int RING = WPP > 1 ? 4 : msim::kPairsRing;      // the latency form keeps three slabs in flight per wave
+    auto kern = msim::maxsim_pairs_argmax_kernel<TPQ, F16, WPP, RING>;
+    constexpr int lds = 4 * RING * msim::kSlabBytes + (WPP > 1 ? 4 * TPQ * msim::kTokTile * 8 : 0);
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     const int wg_needed = WPP > 1 ? a.n_pairs : (a.n_pairs + 3) / 4;
@@ -548,8 +549,8 @@ template <int TPD, bool F16>
 int launch_pairs_argmax_t(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                           const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                           const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_pairs_argmax_t_kernel<TPD, F16>;
-    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes + 16;
+    auto kern = msim::maxsim_pairs_argmax_t_kernel<TPD, F16, 4>;
+    constexpr int lds = 4 * 4 * msim::kSlabBytes + 16;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     const int wg_cap = 4 * di.cus * (di.lds_per_cu / lds);        // a few rounds of resident workgroups; the kernel strides beyond

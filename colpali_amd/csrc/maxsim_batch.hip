@@ -107,10 +107,13 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     if (sub > 1) { qblock = slot % a.n_qblocks; range = xcd * sub + slot / a.n_qblocks; }
     else         { qblock = slot;               range = xcd; }
     if (qblock >= a.n_qblocks || range >= a.n_ranges) return;
+    // the range's documents: two searches of the row offsets, by the whole wave (64 probes per round: 2 dependent loads for 256
+    // documents, 3 for 125 000, instead of 8 / 17 -- per workgroup, in front of everything else: part of the fixed cost of a
+    // one-page-per-workgroup launch, tools/fixed_overhead.py)
     const long long total_rows = d_off[a.n_d];
-    const int d_lo = lower_bound_doc(d_off, a.n_d, (total_rows * range) / a.n_ranges);
-    const int d_hi = (range + 1 == a.n_ranges) ? a.n_d
-                                                : lower_bound_doc(d_off, a.n_d, (total_rows * (range + 1)) / a.n_ranges);
+    const int want_lo = (int)((total_rows * range) / a.n_ranges), want_hi = (int)((total_rows * (range + 1)) / a.n_ranges);
+    const int d_lo = lower_bound_wave(a.n_d, want_lo, lane, [&](int k) { return d_off[k]; });
+    const int d_hi = (range + 1 == a.n_ranges) ? a.n_d : lower_bound_wave(a.n_d, want_hi, lane, [&](int k) { return d_off[k]; });
     int *const my_prog = a.convoy ? a.convoy + (size_t)range * a.n_qblocks : nullptr;    // this range's counters, one per query block
     if (d_lo >= d_hi) {
         if (my_prog && threadIdx.x == 0) __hip_atomic_store(my_prog + qblock, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -129,32 +132,6 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     const int n_units = (n_tok + kUnitTok - 1) / kUnitTok;
     const int my_nu = wave < n_units ? (n_units - 1 - wave) / kB1Waves + 1 : 0;   // units of this wave (wave-uniform)
     QueryUnit qu[MAXU];
-#pragma unroll
-    for (int t = 0; t < MAXU; ++t)
-        load_query_unit(qu[t], Qt + (size_t)tok0 * kDim, (wave + kB1Waves * t) * kUnitTok, n_tok, lane, t < my_nu);
-    // the reduction after every document: 8 lanes per query, query j of the block in lanes 8j .. 8j+7 of the workgroup
-    // (the token range of the query waits in LDS next to the table, written by the lanes that read it back: the slab loop of the
-    // ten-unit form has no two registers to spare)
-    int *const rtab = reinterpret_cast<int *>(tokmax + kB1Waves * MAXU * kUnitTok * 16);
-    {
-        const int rq = threadIdx.x >> 3;
-        if (rq < qb_n) {
-            const int s = flat_qoff(a.fq, qb0 + rq) - tok0, e = flat_qoff(a.fq, qb0 + rq + 1) - tok0;
-            rtab[2 * rq] = s;
-            rtab[2 * rq + 1] = e;
-        }
-    }
-    wait_vmcnt<0>();
-#pragma unroll
-    for (int t = 0; t < MAXU; ++t)
-#pragma unroll
-        for (int ks = 0; ks < kKSteps16; ++ks) {
-            // ten units: eight of them live in AGPRs (MFMA srcB reads either file); left alone hipcc keeps 128 VGPRs and shuffles
-            // the rest through v_accvgpr copies inside the slab loop
-            if (MAXU > 8 && t >= 2) asm volatile("" : "+a"(qu[t].f[ks]));
-            else asm volatile("" : "+v"(qu[t].f[ks]));
-        }
-
     // ---- per-lane address constants (same slab image as K1s)
     const int l16 = lane & 15, l4 = lane >> 4;
     int src_off[4];
@@ -202,6 +179,35 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
 
 #pragma unroll
     for (int i = 0; i < kBatchRing - 1; ++i) produce();
+
+    // ---- the block's units, loaded BEHIND the first chunks' LDS-DMA requests (both in flight together: the ring fill used to wait
+    // for the block's 256 KiB of query operands to arrive first)
+#pragma unroll
+    for (int t = 0; t < MAXU; ++t)
+        load_query_unit(qu[t], Qt + (size_t)tok0 * kDim, (wave + kB1Waves * t) * kUnitTok, n_tok, lane, t < my_nu);
+    // the reduction after every document: 8 lanes per query, query j of the block in lanes 8j .. 8j+7 of the workgroup
+    // (the token range of the query waits in LDS next to the table, written by the lanes that read it back: the slab loop of the
+    // ten-unit form has no two registers to spare)
+    int *const rtab = reinterpret_cast<int *>(tokmax + kB1Waves * MAXU * kUnitTok * 16);
+    {
+        const int rq = threadIdx.x >> 3;
+        if (rq < qb_n) {
+            const int s = flat_qoff(a.fq, qb0 + rq) - tok0, e = flat_qoff(a.fq, qb0 + rq + 1) - tok0;
+            rtab[2 * rq] = s;
+            rtab[2 * rq + 1] = e;
+        }
+    }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < MAXU; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) {
+            // ten units: eight of them live in AGPRs (MFMA srcB reads either file); left alone hipcc keeps 128 VGPRs and shuffles
+            // the rest through v_accvgpr copies inside the slab loop
+            if (MAXU > 8 && t >= 2) asm volatile("" : "+a"(qu[t].f[ks]));
+            else asm volatile("" : "+v"(qu[t].f[ks]));
+        }
+
 
     const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
     const bool round_total = ref_bf16 && !(a.flags & kFlagPartial);

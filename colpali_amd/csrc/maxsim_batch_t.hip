@@ -59,21 +59,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
     const int pslot = slot / a.n_blocks;
     const int doc0 = (block * NW + wave) * DPW;              // this wave's first document
 
-    // ---- the resident rows: unit (d, u) = rows 16 u .. 16 u + 15 of document doc0 + d, as MFMA A operands
-    QueryUnit qu[NU];
-#pragma unroll
-    for (int d = 0; d < DPW; ++d)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool live = doc0 + d < a.n_d;
-            load_query_unit(qu[d * U + u], D + (size_t)(live ? doc0 + d : 0) * a.Ld * kDim, u * kUnitTok, a.Ld, lane, live);
-        }
-    wait_vmcnt<0>();
-#pragma unroll
-    for (int t = 0; t < NU; ++t)
-#pragma unroll
-        for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qu[t].f[ks]));
-
+    QueryUnit qu[NU];           // the resident rows (loaded below, behind the first page's first LDS-DMA requests)
     const int l16 = lane & 15, l4 = lane >> 4;
     int src_off[4];
 #pragma unroll
@@ -99,23 +85,39 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
     const int first_off = (lane & 31) * kRowBytes + ((lane & 15) << 4);      // chunk 0 of row (lane & 31) in the swizzled slab image
     int p_slot = 0, c_slot = 0;
     const int nchunk = (a.Lq + kCRows - 1) / kCRows;
-    for (int page = xcd + 8 * pslot; page < a.n_q; page += 8 * a.slots_p) {
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)page * a.Lq * kDim), 0, a.Lq * kRowBytes, 0x00020000);
-        int p_ch = 0;
-        auto produce = [&]() {
-            if (p_ch >= nchunk) return;
-            char *dst = smem + p_slot * kCBytes + my_lds_off;
-            const int soff = (p_ch * kCRows + my_row_off) * kRowBytes;       // rows past the page end read as zeros (bounds check)
+    int page = xcd + 8 * pslot;
+    if (page >= a.n_q) return;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)page * a.Lq * kDim), 0, a.Lq * kRowBytes, 0x00020000);
+    int p_ch = 0;
+    auto produce = [&]() {
+        if (p_ch >= nchunk) return;
+        char *dst = smem + p_slot * kCBytes + my_lds_off;
+        const int soff = (p_ch * kCRows + my_row_off) * kRowBytes;       // rows past the page end read as zeros (bounds check)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, 0);
-            p_slot = (p_slot + 1 == kRing) ? 0 : p_slot + 1;
-            ++p_ch;
-        };
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, 0);
+        p_slot = (p_slot + 1 == kRing) ? 0 : p_slot + 1;
+        ++p_ch;
+    };
 #pragma unroll
-        for (int i = 0; i < kRing - 1; ++i) produce();
+    for (int i = 0; i < kRing - 1; ++i) produce();            // the first page's ring fill ...
 
+    // ---- ... and BEHIND it (both in flight together) the resident rows: unit (d, u) = rows 16 u .. 16 u + 15 of document doc0 + d,
+    // as MFMA A operands
+#pragma unroll
+    for (int d = 0; d < DPW; ++d)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = doc0 + d < a.n_d;
+            load_query_unit(qu[d * U + u], D + (size_t)(live ? doc0 + d : 0) * a.Ld * kDim, u * kUnitTok, a.Ld, lane, live);
+        }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < NU; ++t)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) asm volatile("" : "+v"(qu[t].f[ks]));
+
+    for (;;) {
         float sum[DPW];
 #pragma unroll
         for (int d = 0; d < DPW; ++d) sum[d] = 0.0f;
@@ -195,7 +197,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
             if (lane == 0 && doc0 + d < a.n_d) scores[(size_t)page * a.ld + doc0 + d] = s;
         }
         if (count_here && lane == 0) q_lengths[page] = n_real;
+        page += 8 * a.slots_p;
+        if (page >= a.n_q) break;
         lds_barrier();                      // the ring is re-filled for the next page only after every wave has read its last chunk
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)page * a.Lq * kDim), 0, a.Lq * kRowBytes, 0x00020000);
+        p_ch = 0;
+#pragma unroll
+        for (int i = 0; i < kRing - 1; ++i) produce();
     }
 }
 

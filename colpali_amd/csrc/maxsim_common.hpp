@@ -102,6 +102,24 @@ __device__ __forceinline__ uint32_t scalar_load_u32(uint64_t addr) {
     return v;
 }
 
+// first index k in [0, n) with key(k) >= v (key non-decreasing), searched by the whole wave: 64 probes per round,
+// so 8192 pairs take 3 rounds of one load each instead of 13 dependent loads
+template <class KeyFn>
+__device__ __forceinline__ int lower_bound_wave(int n, int v, int lane, KeyFn key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + lane * step;
+        const bool below = idx < hi && key(idx) < v;
+        const int cnt = __popcll(__ballot(below));          // probes 0 .. cnt-1 are below v, probe cnt (if any) is not
+        if (cnt == 0) break;
+        const int nhi = lo + cnt * step;
+        lo = lo + (cnt - 1) * step + 1;
+        hi = nhi < hi ? nhi : hi;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
 // C/D layout of v_mfma_f32_32x32x16_bf16: lane holds column (lane & 31) and the 16 rows
 //   row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }

@@ -33,8 +33,10 @@ struct PairsArgs {
 // through LDS (lower row wins a tie: the first maximum) -- the latency form for short lists: the pairwise loss recomputes the routing
 // of 2B = 64 pairs, and one wave walking 25 slabs one LDS-DMA round trip at a time took 20 us of a 150 us step (rocprofv3, round 5).
 // TPQ = ceil(Lq / 32) token tiles of the pair's query live in registers.
-template <int TPQ, bool F16, int WPP = 1>
-__global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
+// RING: slabs in each wave's private ring.  2 keeps two workgroups on a CU (the throughput form); the latency forms (few workgroups, each
+// wave waiting for its own LDS-DMA round trips) take 4: three slabs in flight instead of one.
+template <int TPQ, bool F16, int WPP = 1, int RING = kPairsRing>
+__global__ __launch_bounds__(256, (RING > 2 ? 1 : 2)) void maxsim_pairs_argmax_kernel(const uint16_t *__restrict__ Q,
                                                                   const uint16_t *__restrict__ D,
                                                                   const int32_t *__restrict__ d_off,
                                                                   const uint8_t *__restrict__ clamp0,
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *ring = smem + wave * (kPairsRing * kSlabBytes);
-    float *comb_m = reinterpret_cast<float *>(smem + 4 * kPairsRing * kSlabBytes);        // WPP = 4: [4][TPQ * 32]
+    char *ring = smem + wave * (RING * kSlabBytes);
+    float *comb_m = reinterpret_cast<float *>(smem + 4 * RING * kSlabBytes);        // WPP = 4: [4][TPQ * 32]
     int *comb_a = reinterpret_cast<int *>(comb_m + 4 * TPQ * kTokTile);
     const int gw = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     const int GW = WPP == 1 ? gridDim.x * 4 : gridDim.x;
@@ -96,22 +98,29 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
-            p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
+            p_slot = (p_slot + 1 == RING) ? 0 : p_slot + 1;
             p_s += WPP;
             return true;
         };
 #pragma unroll
-        for (int i = 0; i < kPairsRing - 1; ++i) produce();
+        for (int i = 0; i < RING - 1; ++i) produce();
 
+        // nothing left to request: slab s has landed once at most the (requested - consumed - 1) later slabs are still in flight
+        auto wait_tail = [&](int next_req, int cur) {
+            const int behind = (next_req - cur) / WPP - 1;       // slabs requested after `cur`
+            if (RING > 2 && behind >= 2) wait_vmcnt<16>();
+            else if (RING > 2 && behind == 1) wait_vmcnt<8>();
+            else wait_vmcnt<0>();
+        };
         float m[TPQ];
         int am[TPQ];
 #pragma unroll
         for (int t = 0; t < TPQ; ++t) { m[t] = -INFINITY; am[t] = -1; }
 
         for (int s = s_first; s < nslab; s += WPP) {
-            if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
+            if (produce()) wait_vmcnt<8 * (RING - 1)>(); else wait_tail(p_s, s);
             const char *src = ring + c_slot * kSlabBytes;
-            c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
+            c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
             bf16x8 af[kKSteps];
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
@@ -197,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_kernel(const uint1
 // yields 32 finished (max, arg-max) results, nothing is carried across slabs.  One workgroup per pair, wave w takes slabs w, w + 4, ...
 // (the results are per token: no cross-wave combine except the score sum, in wave order).  Until round 5 these pairs went to the
 // generic kernel (fragment-shaped global loads, one wave per pair): 53 us for the 64 pairs of the pairwise loss.
-template <int TPD, bool F16>
-__global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_t_kernel(const uint16_t *__restrict__ Q,
+template <int TPD, bool F16, int RING = 4>
+__global__ __launch_bounds__(256, (RING > 2 ? 1 : 2)) void maxsim_pairs_argmax_t_kernel(const uint16_t *__restrict__ Q,
                                                                     const uint16_t *__restrict__ D,
                                                                     const int32_t *__restrict__ d_off,
                                                                     const uint8_t *__restrict__ clamp0,
@@ -209,8 +218,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_t_kernel(const uin
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *ring = smem + wave * (kPairsRing * kSlabBytes);
-    float *wave_sum = reinterpret_cast<float *>(smem + 4 * kPairsRing * kSlabBytes);      // [4]
+    char *ring = smem + wave * (RING * kSlabBytes);
+    float *wave_sum = reinterpret_cast<float *>(smem + 4 * RING * kSlabBytes);      // [4]
     const int l16 = lane & 15, l4 = lane >> 4;
     int src_off[4];
 #pragma unroll
@@ -258,17 +267,24 @@ __global__ __launch_bounds__(256, 2) void maxsim_pairs_argmax_t_kernel(const uin
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
-            p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
+            p_slot = (p_slot + 1 == RING) ? 0 : p_slot + 1;
             p_s += 4;
             return true;
         };
 #pragma unroll
-        for (int i = 0; i < kPairsRing - 1; ++i) produce();
+        for (int i = 0; i < RING - 1; ++i) produce();
         float total = 0.0f;
         for (int s = wave; s < nslab; s += 4) {
-            if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
+            if (produce()) {
+                wait_vmcnt<8 * (RING - 1)>();
+            } else {
+                const int behind = (p_s - s) / 4 - 1;             // slabs requested after this one (nothing more can be requested)
+                if (RING > 2 && behind >= 2) wait_vmcnt<16>();
+                else if (RING > 2 && behind == 1) wait_vmcnt<8>();
+                else wait_vmcnt<0>();
+            }
             const char *src = ring + c_slot * kSlabBytes;
-            c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
+            c_slot = (c_slot + 1 == RING) ? 0 : c_slot + 1;
             bf16x8 sf[kKSteps];
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) sf[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);

@@ -128,12 +128,16 @@ class ShardedRetriever:
 
             self.dist = dist_mod
 
-    def search(self, queries, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
-        """queries (replicated on every rank): a `PackedQueries`, a list of [len_i, 128] tensors, or a [n_q, Lq, 128] tensor -- the
-        last two are packed into the flat layout first (zero padding rows dropped: they add exactly 0 and would only cost MFMA work;
-        one small D2H of the per-query counts for a device tensor)."""
+    def search(self, queries, k: int = 10, compact: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """queries (replicated on every rank): a `PackedQueries`, a list of [len_i, 128] tensors, or a [n_q, Lq, 128] tensor.
+        A host list is packed into the flat layout (ragged lengths, zero rows dropped on the way into the staging buffer).  A dense
+        DEVICE tensor is scored as it stands unless `compact=True`: dropping its zero padding rows needs the per-query counts on the
+        host (one small D2H + a synchronisation), which would make a call that is otherwise fully asynchronous and hipGraph-capturable
+        block the host (round-4 advisor finding).  Callers with heavily padded query boxes pass `compact=True`, or pack once with
+        `pack_queries` and hand the `PackedQueries` over; the scores are the same either way (a zero row adds exactly 0)."""
         if self._score is maxsim_scores and not isinstance(queries, PackedQueries):
-            queries = pack_queries(queries, self.shard.device)
+            dense_on_device = isinstance(queries, torch.Tensor) and queries.device.type == "cuda"
+            queries = pack_queries(queries, self.shard.device, compact=compact or not dense_on_device)
         scores = self._score(queries, self.shard)
         return shard_topk(scores, k, self.shard.id_base, self.world, self.dist, self.group, self._select,
                           force_collective=self.force_collective)
@@ -155,7 +159,7 @@ class ExactMaxSimIndex:
         q = queries_embeddings.to(device=dev, dtype=self.retriever.shard.blob.dtype).contiguous()
         if q.dim() != 3:
             raise ValueError("queries_embeddings must be [n_queries, query_length, dim]")
-        top_s, top_i = self.retriever.search(q, k=top_k)
+        top_s, top_i = self.retriever.search(q, k=top_k, compact=True)     # padded blocks from get_topk_plaid: the result is read back anyway
         top_s, top_i = top_s.cpu().tolist(), top_i.cpu().tolist()
         return [[(int(i), float(s)) for s, i in zip(row_s, row_i) if i >= 0] for row_s, row_i in zip(top_s, top_i)]
 

@@ -424,3 +424,34 @@ def test_long_query_scratch_is_bounded_by_scoring_the_queries_in_groups(amd, mon
     grouped = amd.maxsim_scores(q, corpus).cpu()
     assert torch.equal(whole, grouped)
     assert close(whole.numpy(), _oracle(qs, ps, 128))
+
+
+@pytest.mark.parametrize("batch_size", [128, 64])
+def test_pipelined_dropin_from_host_lists_is_bit_identical_to_one_launch_over_the_packed_corpus(amd, batch_size):
+    """score_multi_vector from a Python list of host page tensors is a pipeline (scoring.py:_score_host_list_pipelined): the corpus
+    goes up in chunks on a copy stream and passage SUB-RANGES (whole blocks of `batch_size`) are scored while the next ones upload.
+    The result must be the bits of ONE launch over the packed corpus -- clamp0 from the same blocking, ragged pages, enough bytes for
+    several sub-ranges (> 96 MB) -- and within 1e-5 of the oracle on a sample."""
+    import numpy as np
+
+    from colpali_amd import scoring
+    from oracle import maxsim_oracle as mo
+
+    g = torch.Generator().manual_seed(77 + batch_size)
+    lens = torch.randint(200, 1031, (700,), generator=g).tolist()
+    ps = [torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16) for n in lens]
+    qs = [torch.nn.functional.normalize(torch.randn(int(n), 128, generator=g), dim=-1).to(torch.bfloat16)
+          for n in torch.randint(8, 41, (37,), generator=g)]
+    assert sum(p.numel() * 2 for p in ps) > 2 * scoring._PIPE_RANGE_BYTES
+    got = amd.score_multi_vector(qs, ps, batch_size=batch_size, device="cuda:0")
+    dev = torch.device("cuda:0")
+    want = amd.maxsim_scores(amd.pack_queries(qs, dev), amd.pack_passages(ps, dev, batch_size=batch_size)).cpu()
+    assert got.dtype == torch.float32 and got.device.type == "cpu" and torch.equal(got, want)
+    again = amd.score_multi_vector(qs, ps, batch_size=batch_size, device="cuda:0")        # the staging halves alternate across calls
+    assert torch.equal(again, got)
+    pick = [0, 3, 127, 128, 350, 699]
+    ref = mo.score_multi_vector([q.float().numpy() for q in qs[:5]], [ps[i].float().numpy() for i in pick], batch_size=1)
+    # (the sample is scored without block mates, i.e. un-clamped: compare the pages that are the longest of their real block)
+    long_enough = [k for k, i in enumerate(pick) if lens[i] == max(lens[(i // batch_size) * batch_size:(i // batch_size + 1) * batch_size])]
+    for k in long_enough:
+        assert np.max(np.abs(got[:5, pick[k]].numpy() - ref[:, k]) / np.maximum(np.abs(ref[:, k]), 1.0)) <= 1e-5

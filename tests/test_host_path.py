@@ -168,3 +168,49 @@ def test_the_reference_scorer_tests_pass_on_a_host_without_a_gpu():
                           "-c", os.devnull, os.path.join(suite, "test_processing_utils.py")],
                          capture_output=True, text=True, env=env, cwd=suite, timeout=600)
     assert res.returncode == 0 and "2 passed" in res.stdout, (res.stdout + res.stderr)[-3000:]
+
+
+def test_host_gather_range_copies_any_byte_range_of_the_virtual_concatenation():
+    """msim_host_gather_range (the upload path's gather: bytes [lo, hi) of the concatenation of the caller's page tensors into one half
+    of the pinned staging buffer, equal byte shares over a persistent pool): any range, any thread count, empty buffers in between."""
+    import ctypes
+
+    import numpy as np
+
+    from colpali_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    sizes = [int(x) for x in rng.integers(0, 300_000, size=57)]
+    sizes[5] = sizes[20] = 0
+    sizes[33] = 9_000_001                               # one buffer larger than several shares
+    bufs = [rng.integers(0, 256, size=n, dtype=np.uint8) for n in sizes]
+    whole = np.concatenate(bufs)
+    srcs = np.asarray([b.ctypes.data if b.size else 0 for b in bufs], dtype=np.uint64)
+    prefix = np.zeros(len(bufs) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=prefix[1:])
+    total = int(prefix[-1])
+    for lo, hi in ((0, total), (1, total - 1), (123_457, 5_000_000), (total - 10, total), (prefix[33] + 17, prefix[34] - 5), (40, 40)):
+        lo, hi = int(lo), int(hi)
+        for threads in (1, 3, 8, 64):
+            dst = np.full(hi - lo + 16, 0xAB, dtype=np.uint8)
+            rc = L.msim_host_gather_range(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), lo, hi, threads)
+            assert rc == 0
+            assert np.array_equal(dst[: hi - lo], whole[lo:hi]) and (dst[hi - lo:] == 0xAB).all()
+    dst = np.zeros(16, dtype=np.uint8)
+    assert L.msim_host_gather_range(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), 0, total + 1, 2) == -1
+    assert L.msim_host_gather_range(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), 5, 4, 2) == -1
+
+
+def test_thread_counts_follow_what_the_container_grants():
+    """_lib.effective_cpus(): affinity and cgroup CPU quota, never more than the host reports (a GPU box shows 256 CPUs and grants 16:
+    native thread counts taken from the host's count ran the quota dry and froze the process -- profiles/r05_logs/dropin_stalls.log)."""
+    import os
+
+    from colpali_amd import _lib, corpus, scoring
+
+    n = _lib.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert n <= len(os.sched_getaffinity(0))
+    assert 1 <= corpus._COPY_THREADS <= max(1, n // 2) or corpus._COPY_THREADS == 1
+    assert scoring._host_threads() <= max(n, int(os.environ.get("COLPALI_AMD_HOST_THREADS", "0")))
