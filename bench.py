@@ -127,6 +127,33 @@ def ragged_docs_numbers(amd, dev, topk):
     return out
 
 
+def short_docs_numbers(amd, dev):
+    """The resident path on SHORT documents (round-4 review, weak 8): a token-pooled corpus -- pool factor 3 of a 1030-patch page
+    (README.md:225, compression/token_pooling) = 343 rows -- and 64-row documents, 8 GiB of rows each, in the HBM-bound and the
+    MFMA-bound regime.  K1b pays one chunk barrier, one table write and one pass of token sums per document: the numbers show what
+    that costs (the structural fix -- several documents per chunk -- is not built)."""
+    out = {}
+    for name, doc_len in (("pooled_343_rows", 343), ("64_rows", 64)):
+        n_docs = (8 << 30) // (doc_len * 256)
+        corpus = make_shard(n_docs, doc_len, dev, seed=5)
+        leg = {"docs": n_docs, "doc_len": doc_len}
+        for qname, lens in (("4_queries_x_32", [32] * 4), ("1000_queries_x_32", [32] * 1000), ("1000_queries_ragged_12_48", parse_regime("1000xr12-48", 32)[1])):
+            q = amd.pack_queries(make_query_list(lens, seed=sum(lens) + doc_len), dev)
+            scores = torch.empty((len(lens), n_docs), dtype=torch.float32, device=dev)
+            amd.maxsim_scores(q, corpus, out=scores)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            for a, b in evs:
+                a.record(); amd.maxsim_scores(q, corpus, out=scores); b.record()
+            torch.cuda.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in evs)[1]
+            r = regime_numbers(len(lens), 32, n_docs, doc_len, ms, q_tokens=sum(lens))
+            leg[qname] = {"kernel_ms": ms, "bound": r["bound"], "frac": r["frac"], "hbm_gbs": r["hbm_gbs"], "mfma_tflops": r["mfma_tflops"]}
+            del scores
+        out[name] = leg
+        del corpus
+    return out
+
+
 def make_queries(n_q, q_len, device, seed):
     g = torch.Generator().manual_seed(seed)
     q = torch.nn.functional.normalize(torch.randn(n_q, q_len, 128, generator=g), dim=-1).to(torch.bfloat16)
@@ -860,7 +887,7 @@ def forced_collective_numbers(amd, q, corpus, topk, dev, steps=5):
             dist.destroy_process_group()
 
 
-def pmc_traffic(n_q, n_docs, doc_len):
+def pmc_traffic(n_q, n_docs, doc_len, q_tokens=None):
     """HBM bytes per launch measured with rocprofv3 PMC counters for this exact workload (committed under
     profiles/ by tools/summarize_profile.py; FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section), else None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -870,7 +897,11 @@ def pmc_traffic(n_q, n_docs, doc_len):
         table = json.load(open(path))
     except Exception:
         return None
-    return table.get(f"nq{n_q}_docs{n_docs}_len{doc_len}")
+    q_tokens = n_q * 32 if q_tokens is None else q_tokens
+    hit = table.get(f"nq{n_q}_tok{q_tokens}_docs{n_docs}_len{doc_len}")
+    if hit is None and q_tokens == n_q * 32:
+        hit = table.get(f"nq{n_q}_docs{n_docs}_len{doc_len}")
+    return hit
 
 
 def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg, q_tokens=None):
@@ -887,7 +918,7 @@ def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg, q_tokens=None):
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
     else:
         roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
-    roof.update({"traffic": pmc_traffic(n_q, n_docs, doc_len),
+    roof.update({"traffic": pmc_traffic(n_q, n_docs, doc_len, q_tokens),
                  "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this workload; not re-measured in this run)",
                  "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
                  "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops,
@@ -1214,6 +1245,7 @@ def main():
         out["dropin_from_host_lists"] = dropin_numbers(amd)
         out["embed_and_score_1k_pages"] = embed_and_score_numbers(amd, dev)
         out["resident_colqwen2_page_geometry"] = ragged_docs_numbers(amd, dev, args.topk)
+        out["resident_short_documents"] = short_docs_numbers(amd, dev)
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []
@@ -1235,7 +1267,8 @@ def main():
                         "pairs_per_s": nq * args.docs * world * steps / d,
                         "pairs_per_s_per_32_real_tokens": nq * args.docs * world * steps / d * (sum(lens) / (32.0 * nq)),
                         "ms_per_step": d / steps * 1e3, "kernel_ms": r["kernel_ms"], "bound": r["bound"],
-                        "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"]})
+                        "frac": r["frac"], "hbm_gbs_per_gpu": r["hbm_gbs"], "mfma_tflops_per_gpu": r["mfma_tflops"],
+                        "traffic": r["traffic"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]})
         if ceil_m and r["bound"] == "mfma":
             regimes[-1]["ratio_to_registers_only_probe"] = r["mfma_tflops"] / ceil_m["registers_only_tflops"]
         if world == 1 and os.environ.get("BENCH_POWER_SAMPLE", "1") != "0":

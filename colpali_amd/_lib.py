@@ -106,6 +106,8 @@ def lib() -> ctypes.CDLL:
     L.msim_host_gather_range.restype = i32
     L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.msim_pairs_argmax.restype = i32
+    L.msim_allpairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, vp, vp]
+    L.msim_allpairs_argmax.restype = i32
     L.msim_pairs_bwd.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
     L.msim_pairs_bwd.restype = i32
     L.msim_pairs_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32]

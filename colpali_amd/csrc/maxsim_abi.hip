@@ -520,6 +520,34 @@ int launch_pairs_argmax(const uint16_t *Q, const uint16_t *D, const int32_t *d_o
     return MSIM_OK;
 }
 
+template <int TPQ1, int GQ, bool F16>
+int launch_allpairs_argmax(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0, float *out_scores,
+                           long long ld, int32_t *out_argmax, const msim::PairsArgs &a, const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_allpairs_argmax_kernel<TPQ1, GQ, F16>;
+    constexpr int lds = 4 * msim::kPairsRing * msim::kSlabBytes;
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    const long long work = (long long)((a.n_q + GQ - 1) / GQ) * a.n_d;
+    const long long wg_needed = (work + 3) / 4;
+    const int wg_cap = di.cus * (di.lds_per_cu / lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(wg_needed < wg_cap ? wg_needed : wg_cap)), dim3(256), lds, st, Q, D, d_off, clamp0, out_scores, ld,
+                       out_argmax, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_allpairs_argmax_kernel<%d,%d> launch: %s", TPQ1, GQ, hipGetErrorString(e));
+    return MSIM_OK;
+}
+
+template <bool F16>
+int allpairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0, float *out_scores,
+                             long long ld, int32_t *out_argmax, const msim::PairsArgs &a, const DeviceInfo &di, hipStream_t st) {
+    switch (tpq) {
+        case 1: return launch_allpairs_argmax<1, 4, F16>(Q, D, d_off, clamp0, out_scores, ld, out_argmax, a, di, st);
+        case 2: return launch_allpairs_argmax<2, 2, F16>(Q, D, d_off, clamp0, out_scores, ld, out_argmax, a, di, st);
+        case 3: return launch_allpairs_argmax<3, 1, F16>(Q, D, d_off, clamp0, out_scores, ld, out_argmax, a, di, st);
+        default: return launch_allpairs_argmax<4, 1, F16>(Q, D, d_off, clamp0, out_scores, ld, out_argmax, a, di, st);
+    }
+}
+
 // short pair lists (the 2B pairs of the pairwise loss): one workgroup per pair, four waves sharing the document (latency);
 // long lists: one wave per pair (throughput)
 constexpr int kPairsSplitMax = 1024;
@@ -1258,6 +1286,27 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, 
     return dtype == MSIM_DTYPE_F16
                ? pairs_argmax_dispatch<true>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st)
                : pairs_argmax_dispatch<false>(tpq, q, d, d_off, d_clamp0, pairs, out_scores, out_argmax, a, *di, st);
+}
+
+int msim_allpairs_argmax(int dtype, const void *Q, int n_q, int Lq, const void *D, const int32_t *d_off, const uint8_t *d_clamp0,
+                         int n_d, int dim, float *out_scores, int64_t ld_scores, int32_t *out_argmax, void *stream) {
+    if (n_q < 0 || n_d < 0 || Lq <= 0) return fail(MSIM_EINVAL, "negative size");
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!out_scores && !out_argmax) return fail(MSIM_EINVAL, "nothing to compute");
+    if (out_scores && ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores < n_d");
+    if (int rc = check_common(Q, D, d_off, dtype, dim, Lq)) return rc;
+    if (!is_tuned(dtype, dim, Lq))
+        return fail(MSIM_EUNSUPPORTED, "msim_allpairs_argmax takes bf16 / f16 embeddings of width %d and queries of at most %d tokens "
+                    "(list the pairs and call msim_pairs_argmax otherwise)", msim::kDim, 4 * msim::kTokTile);
+    if ((long long)n_q * n_d > 0x7fffffffLL) return fail(MSIM_EUNSUPPORTED, "more than 2^31 pairs");
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+    msim::PairsArgs a{n_q, Lq, n_d, n_q * n_d};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
+    return dtype == MSIM_DTYPE_F16 ? allpairs_argmax_dispatch<true>(tpq, q, d, d_off, d_clamp0, out_scores, ld_scores, out_argmax, a, *di, st)
+                                   : allpairs_argmax_dispatch<false>(tpq, q, d, d_off, d_clamp0, out_scores, ld_scores, out_argmax, a, *di, st);
 }
 
 size_t msim_pairs_bwd_workspace_bytes(int n_q, int Lq, int n_d, int dim, int max_doc_rows, int n_pairs) {

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
         p_slot = (p_slot + 1 == kRing) ? 0 : p_slot + 1;
         ++p_ch;
     };
-#pragma unroll
-    for (int i = 0; i < kRing - 1; ++i) produce();            // the first page's ring fill ...
+    produce();                                                  // the first page's ring fill (two chunks ahead) ...
+    produce();
 
     // ---- ... and BEHIND it (both in flight together) the resident rows: unit (d, u) = rows 16 u .. 16 u + 15 of document doc0 + d,
     // as MFMA A operands
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
         lds_barrier();                      // the ring is re-filled for the next page only after every wave has read its last chunk
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)page * a.Lq * kDim), 0, a.Lq * kRowBytes, 0x00020000);
         p_ch = 0;
-#pragma unroll
-        for (int i = 0; i < kRing - 1; ++i) produce();
+        static_assert(kRing == 3, "two chunks are requested ahead");
+        produce();
+        produce();
     }
 }
 

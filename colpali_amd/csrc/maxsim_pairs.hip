@@ -198,6 +198,133 @@ __global__ __launch_bounds__(256, (RING > 2 ? 1 : 2)) void maxsim_pairs_argmax_k
     }
 }
 
+// ---- ALL (query, document) pairs with the routing: the forward of the in-batch losses whose upstream gradient is dense (ColbertLoss,
+// ColbertSigmoidLoss: late_interaction_losses.py:152-164, :444-465), which keeps the per-token arg-max for the backward.  Through the
+// pair-list kernel above every one of the B x C pairs streamed ITS document for ITS query: 32 queries x 256 pages = 8192 streams of
+// 200 KB, 1.6 GB out of L2 for 51 MB of pages (98 us, rocprofv3 round 5).  Here a wave takes GQ queries at once (GQ x TPQ1 <= 4 token
+// tiles in registers) and walks ONE document for all of them: a quarter of the traffic at Lq = 32, the same MFMAs; scores and routing
+// leave in the layout of the row-major all-pairs list, scores[q, c] and argmax[(q * n_d + c), token].
+template <int TPQ1, int GQ, bool F16>
+__global__ __launch_bounds__(256, 2) void maxsim_allpairs_argmax_kernel(const uint16_t *__restrict__ Q,
+                                                                     const uint16_t *__restrict__ D,
+                                                                     const int32_t *__restrict__ d_off,
+                                                                     const uint8_t *__restrict__ clamp0,
+                                                                     float *__restrict__ out_scores,      // [n_q, ld] or null
+                                                                     long long ld,
+                                                                     int32_t *__restrict__ out_argmax,    // [n_q * n_d, Lq] or null
+                                                                     PairsArgs a) {
+    constexpr int TPQ = TPQ1 * GQ;                         // token tiles a wave holds
+    static_assert(TPQ <= 4, "at most four 32-token tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wave * (kPairsRing * kSlabBytes);
+    const int n_groups = (a.n_q + GQ - 1) / GQ;
+    const int n_work = n_groups * a.n_d;                   // (query group, document), document-major inside a group
+    const int gw = blockIdx.x * 4 + wave, GW = gridDim.x * 4;
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src_off[j] = l4 * kRowBytes + (((l16 ^ l4) ^ (j << 2)) << 4);
+    int rd_off[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) rd_off[ks] = slab_swizzled_off(lane & 31, 2 * ks + (lane >> 5));
+
+    int cur_group = -1;
+    bf16x8 qf[TPQ][kKSteps];
+    for (int w = gw; w < n_work; w += GW) {
+        const int g = w / a.n_d, c = w - g * a.n_d;
+        if (g != cur_group) {                               // (at BASELINE config 5's size every wave has exactly one work item)
+#pragma unroll
+            for (int t = 0; t < TPQ; ++t) {
+                const int q = g * GQ + t / TPQ1, row = (t % TPQ1) * kTokTile + (lane & 31);
+                const bool valid = q < a.n_q && row < a.Lq;
+                const uint16_t *qp = Q + ((size_t)(valid ? q : 0) * a.Lq + (valid ? row : 0)) * kDim + (lane >> 5) * 8;
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8 *>(qp + ks * 16);
+                    qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+            cur_group = g;
+        }
+        wait_vmcnt<0>();   // the query fragments; also retires every LDS-DMA / store of the previous work item
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t)
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+
+        const int r0 = d_off[c];
+        const int len = d_off[c + 1] - r0;
+        const int nslab = (len + kSlabRows - 1) / kSlabRows;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * kDim), 0, len * kRowBytes, 0x00020000);
+        int p_s = 0, p_slot = 0, c_slot = 0;
+        auto produce = [&]() -> bool {
+            if (p_s >= nslab) return false;
+            char *dst = ring + p_slot * kSlabBytes;
+            const int soff = p_s * kSlabBytes;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MSIM_LDS(dst + i * 1024), 16, src_off[i & 3], soff + i * 1024, 0, 0);
+            p_slot = (p_slot + 1 == kPairsRing) ? 0 : p_slot + 1;
+            ++p_s;
+            return true;
+        };
+        produce();
+        float m[TPQ];
+        int am[TPQ];
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) { m[t] = -INFINITY; am[t] = -1; }
+        for (int s = 0; s < nslab; ++s) {
+            if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
+            const char *src = ring + c_slot * kSlabBytes;
+            c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
+            bf16x8 af[kKSteps];
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) af[ks] = *reinterpret_cast<const bf16x8 *>(src + rd_off[ks]);
+            const int row0 = s * kSlabRows;
+#pragma unroll
+            for (int t = 0; t < TPQ; ++t) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) acc = mfma32<F16>(af[ks], qf[t][ks], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                  // rows in increasing order inside a lane: strict '>' keeps the first maximum
+                    const int row = row0 + acc_row(r, lane);
+                    const float v = (row < len) ? acc[r] : -INFINITY;
+                    if (v > m[t]) { m[t] = v; am[t] = row; }
+                }
+            }
+        }
+        bool clamp = false;
+        if (clamp0 != nullptr) {
+            const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c;
+            clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+        }
+#pragma unroll
+        for (int j = 0; j < GQ; ++j) {
+            const int q = g * GQ + j;
+            float total = 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < TPQ1; ++tt) {
+                const int t = j * TPQ1 + tt;
+                const float om = __shfl_xor(m[t], 32);
+                const int oam = __shfl_xor(am[t], 32);
+                float v = m[t];
+                int arg = am[t];
+                if (om > v || (om == v && (unsigned)oam < (unsigned)arg)) { v = om; arg = oam; }
+                if (clamp && !(v >= 0.0f)) { v = 0.0f; arg = -1; }   // the reference's zero padding row wins
+                const int tok = tt * kTokTile + (lane & 31);
+                if (out_argmax != nullptr && q < a.n_q && lane < 32 && tok < a.Lq)
+                    out_argmax[((size_t)q * a.n_d + c) * a.Lq + tok] = arg;
+                total += half_wave_sum(v);
+            }
+            if (out_scores != nullptr && q < a.n_q && lane == 0) out_scores[(size_t)q * ld + c] = total;
+        }
+    }
+}
+
 // ---- the TRANSPOSED pair kernel: long queries against short documents -- the trainer's symmetric direction
 // (trainer/contrastive_trainer.py:202-206: a 780-token page as `query_embeddings`, a 32-token query as `doc_embeddings`).  The long
 // side streams (the query's tokens, 32 per slab, through the same wave-private LDS ring and swizzle), the short side is resident

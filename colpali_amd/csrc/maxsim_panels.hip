@@ -233,10 +233,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
     if (sub > 1) { qblock = slot % a.n_qblocks; range = xcd * sub + slot / a.n_qblocks; }
     else         { qblock = slot;               range = xcd; }
     if (qblock >= a.n_qblocks || range >= a.n_ranges) return;
-    const long long total_rows = d_off[a.n_d];
-    const int d_lo = lower_bound_doc(d_off, a.n_d, (total_rows * range) / a.n_ranges);
+    const long long row0 = d_off[0], total_rows = (long long)d_off[a.n_d] - row0;     // d_off may be a slice of absolute offsets
+    const int d_lo = lower_bound_doc(d_off, a.n_d, row0 + (total_rows * range) / a.n_ranges);
     const int d_hi = (range + 1 == a.n_ranges) ? a.n_d
-                                                : lower_bound_doc(d_off, a.n_d, (total_rows * (range + 1)) / a.n_ranges);
+                                                : lower_bound_doc(d_off, a.n_d, row0 + (total_rows * (range + 1)) / a.n_ranges);
     if (d_lo >= d_hi) return;
 
     static_assert(NT >= 1 && NT <= 2 && NT % TPQ == 0, "a wave holds whole queries");

@@ -88,7 +88,7 @@ class _MaxSim(torch.autograd.Function):
         B, C = qc.shape[0], dc.shape[0]
         if dense_grad and any(ctx.needs_input_grad[:2]) and B * C > 0:
             scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)   # returned as is (not a view: callers modify it in place)
-            _, argmax = maxsim_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, qc.device), scores_out=scores)
+            _, argmax = maxsim_all_pairs(qc, dc, corpus.offsets, scores_out=scores)
             ctx.save_for_backward(qc, dc, corpus.offsets, argmax)
             return scores
         scores = _box_scores(qc, dc, corpus)
@@ -123,6 +123,25 @@ def maxsim_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, pair
     return scores, argmax
 
 
+def maxsim_all_pairs(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, want_scores: bool = True, scores_out=None):
+    """MaxSim scores [B, C] (optional) and the arg-max routing [(b * C + c), Lq] of EVERY (query, doc) pair -- the forward of the
+    losses whose upstream gradient is dense.  bf16 / f16 embeddings of width 128 with Lq <= 128 take msim_allpairs_argmax (a wave scores
+    up to four queries against one document: a document is streamed once per group of queries, not once per pair); everything else the
+    pair-list kernel over the row-major all-pairs list (same outputs, same layout)."""
+    B, Lq, dim = qc.shape
+    C = offsets.numel() - 1
+    dev = qc.device
+    if not (qc.dtype in (torch.bfloat16, torch.float16) and dim == 128 and Lq <= 128 and B * C > 0):
+        return maxsim_pairs(qc, dc, offsets, _all_pairs(B, C, dev), want_scores=want_scores, scores_out=scores_out)
+    scores = (scores_out if scores_out is not None else torch.empty((B, C), dtype=torch.float32, device=dev)) if want_scores else None
+    argmax = torch.empty((B * C, Lq), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().msim_allpairs_argmax(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), _lib.ptr(offsets), None, C, dim,
+                                             _lib.ptr(scores), C, _lib.ptr(argmax), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_allpairs_argmax")
+    return scores, argmax
+
+
 def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, grad_scores: torch.Tensor, argmax_all=None):
     """(dQ [B,Lq,width], dD [C,Ld,width], in the embeddings' dtype) for upstream dLoss/dscores [B, C].  Every (query, doc) pair is a pair of
     the list (zero gradients contribute zero): no data-dependent count, hence no host synchronisation.  `argmax_all`: the
@@ -138,7 +157,7 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
         return (torch.zeros(qc.shape, dtype=torch.float32, device=dev), torch.zeros(dc.shape, dtype=torch.float32, device=dev))
     pairs = _all_pairs(B, C, dev)
     if argmax_all is None:
-        _, argmax_all = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
+        _, argmax_all = maxsim_all_pairs(qc, dc, offsets, want_scores=False)
     gp = grad_scores.to(torch.float32).reshape(-1).contiguous()
     return _pairs_backward(qc, dc, offsets, pairs, _all_pairs_order(B, C, dev), gp, argmax_all)
 
@@ -404,7 +423,7 @@ class _FusedInBatchLoss(torch.autograd.Function):
             if smooth:
                 _, aux = smooth_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, dev), tau, scores_out=scores)
             else:
-                _, aux = maxsim_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, dev), scores_out=scores)
+                _, aux = maxsim_all_pairs(qc, dc, corpus.offsets, scores_out=scores)
         elif smooth:
             scores = torch.empty((B, C), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):

@@ -322,32 +322,11 @@ def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_ro
 
         _staging.upload_image(srcs, prefix, n, blob.view(torch.uint8).view(-1), side, on_chunk=score_arrived)
         _stamp("issued")
-        scores = _result_to_host(out)
+        scores = out.cpu()
         blob.record_stream(side)                       # written on the copy stream: its memory is not reused before that stream is done
         _stamp("done")
     del keep
     return scores
-
-
-_result_pin = {}
-_result_lock = __import__("threading").Lock()
-
-
-def _result_to_host(out: torch.Tensor) -> torch.Tensor:
-    """The [n_q, n_p] fp32 result as a new CPU tensor.  Through a reusable PINNED buffer: a D2H copy into pageable memory goes through
-    the runtime's own bounce buffer and costs a few hundred microseconds more than the 400 KB are worth at the end of a 7 ms call."""
-    n = out.numel()
-    if n == 0 or n * 4 > (64 << 20):
-        return out.cpu()
-    key = out.device.index
-    with _result_lock:                                  # one buffer per device: concurrent callers take turns for the ~0.1 ms
-        pin = _result_pin.get(key)
-        if pin is None or pin.numel() < n:
-            pin = _result_pin[key] = torch.empty((max(n, 1 << 18),), dtype=torch.float32, pin_memory=True)
-        view = pin[:n].view(out.shape)
-        view.copy_(out, non_blocking=True)
-        torch.cuda.current_stream(out.device).synchronize()
-        return view.clone()
 
 
 def _corpus_budget_bytes(dev: torch.device) -> int:

@@ -215,6 +215,17 @@ int msim_pairs_argmax(int dtype, const void *Q, int n_q, int Lq,
                       float *out_scores, int32_t *out_argmax, void *stream);
 
 /*
+ * The same for ALL n_q x n_d pairs (the row-major all-pairs list without the list): scores [n_q, ld_scores] and
+ * out_argmax [(q * n_d + c), Lq] -- the forward of the in-batch losses whose upstream gradient is dense (ColbertLoss :152-164,
+ * ColbertSigmoidLoss :444-465), which keep the routing for the backward.  A wave scores up to four queries (<= 128 tokens in all)
+ * against one document, so a document is streamed once per GROUP of queries instead of once per pair.  bf16 / f16, dim 128, Lq <= 128
+ * (MSIM_EUNSUPPORTED otherwise: list the pairs and call msim_pairs_argmax).  Either output may be NULL.
+ */
+int msim_allpairs_argmax(int dtype, const void *Q, int n_q, int Lq,
+                         const void *D, const int32_t *d_off, const uint8_t *d_clamp0, int n_d, int dim,
+                         float *out_scores, int64_t ld_scores, int32_t *out_argmax, void *stream);
+
+/*
  * Backward of the contraction for a sparse set of (q, c) pairs with upstream gradient
  * g[p] = dLoss/dscores[q_p, c_p]:
  *     dQ[q, i, :]        = sum_p g[p] * D[d_off[c_p] + argmax[p, i], :]

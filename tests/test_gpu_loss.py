@@ -729,3 +729,39 @@ def test_transposed_forward_kernel_against_float64(amd, dtype, n_q, Lq, n_d, Ld)
     # refused shapes
     assert lib.msim_fwd_transposed(_lib.dtype_code(dtype), _lib.ptr(q), n_q, Lq, _lib.ptr(d), n_d, 129, 128, _lib.ptr(got), n_d + 3, None, None) == -2
     assert lib.msim_fwd_transposed(2, _lib.ptr(q), n_q, Lq, _lib.ptr(d), n_d, Ld, 128, _lib.ptr(got), n_d + 3, None, None) == -2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,Lq,Ld", [(32, 256, 32, 780), (5, 9, 32, 100), (7, 11, 40, 300), (3, 5, 96, 64), (2, 3, 128, 33), (9, 4, 7, 50)])
+def test_all_pairs_kernel_equals_the_pair_list_kernel_on_the_all_pairs_list(amd, dtype, B, C, Lq, Ld):
+    """msim_allpairs_argmax (a wave scores up to four queries against one document) against msim_pairs_argmax on the row-major
+    all-pairs list: the same routing, the same scores to fp32 summation order (the per-token maxima are identical, the token sums run
+    in the same order) -- every tile count (1..4 tiles per query: 4 / 2 / 1 / 1 queries per wave), query counts that do not fill a
+    group, left-padded queries, ragged documents through the packed layout."""
+    from colpali_amd import _lib, loss as L_
+
+    g = torch.Generator().manual_seed(B * 100 + Lq)
+    q = torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=g), dim=-1)
+    q[0, : Lq // 3] = 0
+    q = q.to(dtype).cuda()
+    lens = torch.randint(max(1, Ld // 2), Ld + 1, (C,), generator=g)
+    blob = torch.cat([torch.nn.functional.normalize(torch.randn(int(n), 128, generator=g), dim=-1) for n in lens]).to(dtype).cuda()
+    off = torch.zeros(C + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0)
+    off = off.cuda()
+    lib = _lib.lib()
+    code = _lib.dtype_code(dtype)
+    pairs = L_._all_pairs(B, C, q.device)
+    s_ref = torch.empty((B * C,), dtype=torch.float32, device="cuda")
+    a_ref = torch.empty((B * C, Lq), dtype=torch.int32, device="cuda")
+    _lib.check(lib.msim_pairs_argmax(code, _lib.ptr(q), B, Lq, _lib.ptr(blob), _lib.ptr(off), None, C, 128, 0, _lib.ptr(pairs), B * C,
+                                     _lib.ptr(s_ref), _lib.ptr(a_ref), _lib.current_stream_handle(q.device)), "msim_pairs_argmax")
+    s_got = torch.full((B, C + 2), float("nan"), device="cuda")
+    a_got = torch.full((B * C, Lq), -7, dtype=torch.int32, device="cuda")
+    _lib.check(lib.msim_allpairs_argmax(code, _lib.ptr(q), B, Lq, _lib.ptr(blob), _lib.ptr(off), None, C, 128, _lib.ptr(s_got), C + 2,
+                                        _lib.ptr(a_got), _lib.current_stream_handle(q.device)), "msim_allpairs_argmax")
+    assert torch.equal(a_got, a_ref)
+    assert torch.isnan(s_got[:, C:]).all()
+    assert float((s_got[:, :C].reshape(-1) - s_ref).abs().max()) <= 1e-5 * float(s_ref.abs().max().clamp_min(1.0))
+    assert lib.msim_allpairs_argmax(code, _lib.ptr(q), B, 129, _lib.ptr(blob), _lib.ptr(off), None, C, 128, _lib.ptr(s_got), C + 2,
+                                    _lib.ptr(a_got), None) == -2

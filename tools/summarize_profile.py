@@ -101,15 +101,21 @@ def main(src, dst_prefix):
     if bench:
         out["bench_line_under_trace"] = bench
         cfg = bench["config"]
-        regs = [(cfg["n_queries"], bench["roofline"]["kernel_ms"])] + [(r["n_queries"], r["kernel_ms"]) for r in bench.get("regimes", [])]
-        for nq, ms in regs:
+        regs = [(cfg["n_queries"], cfg["n_queries"] * cfg.get("q_len", 32), bench["roofline"]["kernel_ms"])] + \
+               [(r["n_queries"], r.get("q_tokens", r["n_queries"] * 32), r["kernel_ms"]) for r in bench.get("regimes", [])]
+        for nq, ntok, ms in regs:
             cands = [e for e in out["clusters"] if "maxsim_" in e["kernel"] and "hbm_read_bytes_per_launch" in e
                      and abs(e["mean_ms"] - ms) / ms < 0.2]
             if cands:
                 e = min(cands, key=lambda e: abs(e["mean_ms"] - ms))
                 tot = e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch_uncalibrated", 0.0)
-                table[f"nq{nq}_docs{cfg['docs_per_gpu']}_len{cfg['doc_len']}"] = tot
+                # keyed by queries AND real query tokens (1000 x 32, 1000 x 40 and a ragged 1000-query batch are different launches);
+                # the uniform 32-token regimes keep the older short key as well
+                table[f"nq{nq}_tok{ntok}_docs{cfg['docs_per_gpu']}_len{cfg['doc_len']}"] = tot
+                if ntok == nq * 32:
+                    table[f"nq{nq}_docs{cfg['docs_per_gpu']}_len{cfg['doc_len']}"] = tot
                 e["matched_bench_regime_n_queries"] = nq
+                e["matched_bench_regime_q_tokens"] = ntok
     with open(traffic_path, "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     with open(dst_prefix + "_summary.json", "w") as f:
