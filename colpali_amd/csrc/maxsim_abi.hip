@@ -502,11 +502,10 @@ size_t flat_workspace_bytes(const HostQ &hq, int n_q) {
     return (!plan.stream && plan.n_blocks() > 1) ? kFwdWorkspaceBytes : 0;
 }
 
-template <int TPQ, bool F16, int WPP>
+template <int TPQ, bool F16, int WPP, int RING = msim::kPairsRing>
 int launch_pairs_argmax(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                         const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                         const DeviceInfo &di, hipStream_t st) {
-    constexpr int RING = WPP > 1 ? 4 : msim::kPairsRing;      // the latency form keeps three slabs in flight per wave
     auto kern = msim::maxsim_pairs_argmax_kernel<TPQ, F16, WPP, RING>;
     constexpr int lds = 4 * RING * msim::kSlabBytes + (WPP > 1 ? 4 * TPQ * msim::kTokTile * 8 : 0);
     static std::atomic<int> configured[kMaxDevices];
@@ -556,6 +555,14 @@ template <bool F16>
 int pairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                           const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                           const DeviceInfo &di, hipStream_t st) {
+    if (a.n_pairs <= di.cus) {       // every pair's workgroup is resident at once: a deep ring (three slabs in flight per wave) costs nothing
+        switch (tpq) {
+            case 1: return launch_pairs_argmax<1, F16, 4, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            case 2: return launch_pairs_argmax<2, F16, 4, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            case 3: return launch_pairs_argmax<3, F16, 4, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            default: return launch_pairs_argmax<4, F16, 4, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        }
+    }
     if (a.n_pairs <= kPairsSplitMax) {
         switch (tpq) {
             case 1: return launch_pairs_argmax<1, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
@@ -573,12 +580,12 @@ int pairs_argmax_dispatch(int tpq, const uint16_t *Q, const uint16_t *D, const i
 }
 
 // long queries against short documents (the trainer's symmetric direction): the transposed pair kernel, one workgroup per pair
-template <int TPD, bool F16>
+template <int TPD, bool F16, int RING>
 int launch_pairs_argmax_t(const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                           const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                           const DeviceInfo &di, hipStream_t st) {
-    auto kern = msim::maxsim_pairs_argmax_t_kernel<TPD, F16, 4>;
-    constexpr int lds = 4 * 4 * msim::kSlabBytes + 16;
+    auto kern = msim::maxsim_pairs_argmax_t_kernel<TPD, F16, RING>;
+    constexpr int lds = 4 * RING * msim::kSlabBytes + 16;
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
     const int wg_cap = 4 * di.cus * (di.lds_per_cu / lds);        // a few rounds of resident workgroups; the kernel strides beyond
@@ -593,10 +600,19 @@ template <bool F16>
 int pairs_argmax_t_dispatch(int tpd, const uint16_t *Q, const uint16_t *D, const int32_t *d_off, const uint8_t *clamp0,
                             const int32_t *pairs, float *out_scores, int32_t *out_argmax, const msim::PairsArgs &a,
                             const DeviceInfo &di, hipStream_t st) {
+    // few pairs (the pairwise loss' 2B): every workgroup resident at once, a 4-slab ring per wave hides the LDS-DMA round trips;
+    // many (dense upstream gradients: B x C pairs): the 2-slab ring keeps two workgroups on a CU
+    if (a.n_pairs <= di.cus) {
+        switch (tpd) {
+            case 1: return launch_pairs_argmax_t<1, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            case 2: return launch_pairs_argmax_t<2, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+            default: return launch_pairs_argmax_t<4, F16, 4>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        }
+    }
     switch (tpd) {
-        case 1: return launch_pairs_argmax_t<1, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
-        case 2: return launch_pairs_argmax_t<2, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
-        default: return launch_pairs_argmax_t<4, F16>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 1: return launch_pairs_argmax_t<1, F16, 2>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        case 2: return launch_pairs_argmax_t<2, F16, 2>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
+        default: return launch_pairs_argmax_t<4, F16, 2>(Q, D, d_off, clamp0, pairs, out_scores, out_argmax, a, di, st);
     }
 }
 
