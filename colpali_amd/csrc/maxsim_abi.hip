@@ -341,6 +341,20 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
         p.maxu = sh[1];
         return MSIM_OK;
     }
+#ifdef MSIM_AB
+    // measurement builds only (round 5, short documents): several blocks on the FOUR-wave form -- two workgroups per CU, 64-row chunks,
+    // one covering the other's per-document barriers -- instead of the eight-wave form (MSIM_BATCH_NW=4 with more than 40 units)
+    if (forced == 4) {
+        std::vector<int> b4;
+        if (fill_blocks(hq, n_q, 4, 8, b4)) {
+            balance_blocks(hq, n_q, 4, 8, b4);
+            p.nw = 4;
+            p.maxu = 8;
+            p.blk_q0.swap(b4);
+            return MSIM_OK;
+        }
+    }
+#endif
     std::vector<int> b8, b10;
     if (!fill_blocks(hq, n_q, 8, 8, b8)) {
         if (!fill_blocks(hq, n_q, 8, 10, b10))
@@ -490,6 +504,9 @@ int fwd_dispatch(const FwdCall &c) {
     }
 #endif
     if (plan.nw == 2) return launch_batch<F16, 2, 4, 2, 8>(c, plan);
+#ifdef MSIM_AB
+    if (plan.nw == 4 && plan.maxu == 8 && !single) return launch_batch<F16, 4, 3, 0, 8>(c, plan);
+#endif
     if (plan.nw == 4) return plan.maxu == 10 ? launch_batch<F16, 4, 3, 2, 10>(c, plan) : launch_batch<F16, 4, 3, 2, 8>(c, plan);
     if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10>(c, plan) : launch_batch<F16, 8, 3, 0, 10>(c, plan);
     return single ? launch_batch<F16, 8, 3, 2, 8>(c, plan) : launch_batch<F16, 8, 3, 0, 8>(c, plan);
