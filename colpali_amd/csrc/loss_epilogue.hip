@@ -271,6 +271,67 @@ __global__ __launch_bounds__(kEpiThreads) void loss_epilogue_kernel(const float 
     }
 }
 
+// The pairwise row on HALF a wave (32 lanes, the small-batch kernel: 32 rows at a time on 16 waves) in ONE pass over the row: every
+// lane keeps the bounds and the best two keys of its elements, and one 5-step butterfly merges (min, max, top-2) of the 32 lanes --
+// two sorted pairs merge as  k1 = max(a1, b1),  k2 = max(min(a1, b1), max(a2, b2)).  The same keys (value descending, index
+// ascending), the same exact-equality rule and the same gradient entries as epi_row; three passes and four reductions fewer.
+__device__ __forceinline__ EpiRow epi_row_pairwise_half(int b, int l32, const float *srow, int length, int32_t *__restrict__ pairs,
+                                                        float *__restrict__ coef, const EpiArgs &a) {
+    const float len_f = (float)length;
+    const int pos_idx = a.offset + b;
+    auto norm = [&](float raw) { return a.normalize ? raw / len_f : raw; };
+    const float pos = norm(srow[pos_idx]);
+    const float limit = a.filter_threshold * pos;
+    auto filtered = [&](int c, float s) { return a.filter && c != pos_idx && s > limit; };
+    float lo = INFINITY, hi = -INFINITY;
+    unsigned long long k1 = 0, k2 = 0;
+    for (int c = l32; c < a.C; c += 32) {
+        const float s = norm(srow[c]);
+        lo = fminf(lo, s);
+        hi = fmaxf(hi, s);
+        const unsigned long long k = epi_key(filtered(c, s) ? s * a.filter_factor : s, c);
+        if (k > k1) { k2 = k1; k1 = k; }
+        else if (k > k2) k2 = k;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+        const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+        const unsigned long long mx = k1 > o1 ? k1 : o1, mn = k1 > o1 ? o1 : k1, m2 = k2 > o2 ? k2 : o2;
+        k1 = mx;
+        k2 = mn > m2 ? mn : m2;
+    }
+    const int i1 = 0x7fffffff - (int)(uint32_t)k1, i2 = 0x7fffffff - (int)(uint32_t)k2;
+    auto value = [&](int c) {
+        const float s = norm(srow[c]);
+        return filtered(c, s) ? s * a.filter_factor : s;
+    };
+    const float v1 = value(i1), v2 = value(i2);
+    const bool first_is_pos = v1 == pos;                              // :311 exact float equality
+    const int neg_idx = first_is_pos ? i2 : i1;
+    const float neg = first_is_pos ? v2 : v1;
+    const float x = (neg - pos) * a.inv_T;
+    const float row_loss = x > 20.0f ? x : log1pf(expf(x));          // F.softplus (beta 1, threshold 20)
+    const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+    const float up = sig * a.inv_T / (float)a.B;                      // dLoss / dneg = -dLoss / dpos
+    float c_neg = up, c_pos = -up;
+    if (filtered(neg_idx, norm(srow[neg_idx]))) c_neg *= a.filter_factor;
+    if (a.normalize) { c_neg /= len_f; c_pos /= len_f; }
+    const bool pos_first = pos_idx <= neg_idx;
+    const int doc0 = pos_first ? pos_idx : neg_idx, doc1 = pos_first ? neg_idx : pos_idx;
+    if (l32 == 0) {
+        const int e = 2 * b;
+        pairs[2 * e] = b;
+        pairs[2 * e + 1] = doc0;
+        coef[e] = pos_first ? c_pos : c_neg;
+        pairs[2 * e + 2] = b;
+        pairs[2 * e + 3] = doc1;
+        coef[e + 1] = pos_first ? c_neg : c_pos;
+    }
+    return EpiRow{row_loss, lo, hi, doc0, doc1};
+}
+
 // ---- the same for SMALL batches (B <= kEpiSmallRows rows, B * C scores that one workgroup reads in a few microseconds -- BASELINE
 // config 5: 32 x 256): ONE workgroup of 16 waves.  Phase 1, one round trip to memory: the whole score matrix is copied into LDS (when
 // it fits kEpiStageFloats) and every wave counts the tokens of its rows.  Phase 2: one wave per row at a time (shuffle reductions
@@ -326,15 +387,29 @@ __global__ __launch_bounds__(kEpiSmallThreads) void loss_epilogue_small_kernel(c
         }
     }
     __syncthreads();
-    for (int b = wave; b < a.B; b += kWaves) {
-        const float *srow = staged ? stage + (size_t)b * a.C : scores + (size_t)b * a.ld;
-        const EpiRow r = epi_row<true>(b, lane, 64, srow, row_len[b], Q, G, pairs, coef, a, &unused);
-        if (lane == 0) {
-            row_loss[b] = r.loss;
-            row_lo[b] = r.lo;
-            row_hi[b] = r.hi;
-            pair_doc[2 * b] = r.doc0;
-            pair_doc[2 * b + 1] = r.doc1;
+    if (a.mode == kEpiPairwise) {
+        // pairwise: a row per HALF wave, one pass over the row (32 rows at a time)
+        const int l32 = lane & 31;
+        for (int b = tid >> 5; b < a.B; b += kEpiSmallThreads / 32) {
+            const float *srow = staged ? stage + (size_t)b * a.C : scores + (size_t)b * a.ld;
+            const EpiRow r = epi_row_pairwise_half(b, l32, srow, row_len[b], pairs, coef, a);
+            if (l32 == 0) {
+                row_loss[b] = r.loss;
+                row_lo[b] = r.lo;
+                row_hi[b] = r.hi;
+                pair_doc[2 * b] = r.doc0;
+                pair_doc[2 * b + 1] = r.doc1;
+            }
+        }
+    } else {
+        for (int b = wave; b < a.B; b += kWaves) {
+            const float *srow = staged ? stage + (size_t)b * a.C : scores + (size_t)b * a.ld;
+            const EpiRow r = epi_row<true>(b, lane, 64, srow, row_len[b], Q, G, pairs, coef, a, &unused);
+            if (lane == 0) {
+                row_loss[b] = r.loss;
+                row_lo[b] = r.lo;
+                row_hi[b] = r.hi;
+            }
         }
     }
     __syncthreads();
