@@ -154,6 +154,42 @@ def short_docs_numbers(amd, dev):
     return out
 
 
+def wide_320_numbers(amd, dev):
+    """Width 320 (ColQwen3, models/qwen3/colqwen3/modeling_colqwen3.py:48) on the panel kernels: 4 096 pages x 1 024 rows x 320 bf16
+    (2.5 GiB resident).  4 queries: K1sP (HBM-bound); 1000 x 32: K1bP's query box; 1000 x 40 and 1000 ragged U{12..48}: the flat
+    kernel K1bPF (round 5), whose rate per REAL token should sit within 10 % of the Lq 32 one."""
+    n_docs, doc_len, dim = 4096, 1024, 320
+    g = torch.Generator(device=dev).manual_seed(11)
+    blob = torch.nn.functional.normalize(torch.randn((n_docs * doc_len, dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
+    from colpali_amd.corpus import PackedCorpus
+    corpus = PackedCorpus(blob=blob, offsets=(torch.arange(n_docs + 1, dtype=torch.int64) * doc_len).to(torch.int32).to(dev), clamp0=None,
+                          lengths=torch.full((n_docs,), doc_len, dtype=torch.int64))
+    out = {"workload": f"{n_docs} pages x {doc_len} rows x {dim} bf16 ({blob.numel() * 2 / 2**30:.1f} GiB resident)"}
+    for name, lens in (("4_queries_x_32", [32] * 4), ("1000_queries_x_32", [32] * 1000), ("1000_queries_x_40", [40] * 1000),
+                       ("1000_queries_ragged_12_48", parse_regime("1000xr12-48", 32)[1])):
+        tok = torch.nn.functional.normalize(torch.randn((sum(lens), dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
+        uniform = len(set(lens)) == 1
+        q = tok.view(len(lens), lens[0], dim) if uniform else amd.pack_queries(list(tok.split(lens)), dev)     # a box (msim_fwd picks) / flat
+        scores = torch.empty((len(lens), n_docs), dtype=torch.float32, device=dev)
+        amd.maxsim_scores(q, corpus, out=scores)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for a, b in evs:
+            a.record(); amd.maxsim_scores(q, corpus, out=scores); b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[1]
+        alg = blob.numel() * 2 + sum(lens) * dim * 2 + len(lens) * n_docs * 4
+        flops = 2.0 * sum(lens) * n_docs * doc_len * dim
+        gbs, tf = alg / ms / 1e6, flops / ms / 1e9
+        bound = "hbm" if alg / HBM_PEAK_GBS / 1e9 >= flops / MFMA_PEAK_TFLOPS / 1e12 else "mfma"
+        out[name] = {"kernel_ms": ms, "q_tokens": sum(lens), "real_token_pages_per_s": sum(lens) * n_docs / ms * 1e3, "hbm_gbs": gbs,
+                     "useful_mfma_tflops": tf, "bound": bound, "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS}
+        del scores
+    out["ragged_per_real_token_rate_vs_Lq32"] = (out["1000_queries_ragged_12_48"]["real_token_pages_per_s"] /
+                                                 out["1000_queries_x_32"]["real_token_pages_per_s"])
+    del corpus, blob
+    return out
+
+
 def make_queries(n_q, q_len, device, seed):
     g = torch.Generator().manual_seed(seed)
     q = torch.nn.functional.normalize(torch.randn(n_q, q_len, 128, generator=g), dim=-1).to(torch.bfloat16)
@@ -1246,6 +1282,10 @@ def main():
         out["embed_and_score_1k_pages"] = embed_and_score_numbers(amd, dev)
         out["resident_colqwen2_page_geometry"] = ragged_docs_numbers(amd, dev, args.topk)
         out["resident_short_documents"] = short_docs_numbers(amd, dev)
+        try:
+            out["resident_width_320"] = wide_320_numbers(amd, dev)
+        except Exception as e:
+            out["resident_width_320"] = {"error": f"{type(e).__name__}: {e}"}
 
     # other regimes of the same step on the same resident shard (every rank takes part: collectives inside)
     regimes = []

@@ -360,10 +360,16 @@ class PackedQueries:
 
 
 MAX_FLAT_QUERY_TOKENS = 1024       # a query's tokens share one workgroup (maxsim_abi.hip: flat_plan); longer ones keep the box layout
+WIDE_DIM = 320                     # ColQwen3's projection (models/qwen3/colqwen3/modeling_colqwen3.py:48): the panel kernels (K1sP / K1bP / K1bPF)
+MAX_FLAT_QUERY_TOKENS_WIDE = 512   # ... whose query block holds 8 waves x 4 units of 16 tokens (maxsim_abi.hip: panels_flat_plan)
 
 
 def _is_flat_shape(dtype: torch.dtype, dim: int) -> bool:
-    return dtype in (torch.bfloat16, torch.float16) and dim == EMBED_DIM
+    return dtype in (torch.bfloat16, torch.float16) and dim in (EMBED_DIM, WIDE_DIM)
+
+
+def max_flat_query_tokens(dim: int) -> int:
+    return MAX_FLAT_QUERY_TOKENS_WIDE if dim == WIDE_DIM else MAX_FLAT_QUERY_TOKENS
 
 
 def _flat_from_host_list(qs: Sequence[torch.Tensor], dim: int, device: torch.device, compact: bool) -> Optional["PackedQueries"]:
@@ -385,7 +391,7 @@ def _flat_from_host_list(qs: Sequence[torch.Tensor], dim: int, device: torch.dev
             raise RuntimeError(f"msim_host_count_nonzero_rows failed: {L.msim_last_error().decode()}")
     else:
         counts = rows.astype(np.int32)
-    if int(counts.max(initial=0)) > MAX_FLAT_QUERY_TOKENS:
+    if int(counts.max(initial=0)) > max_flat_query_tokens(dim):
         return None
     off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(counts, out=off[1:])
@@ -440,7 +446,7 @@ def _flat_from_device_box(box: torch.Tensor, compact: bool) -> Optional["PackedQ
     n_q, Lq, dim = box.shape
     box = box.contiguous()
     if not compact or n_q == 0 or Lq == 0:
-        if Lq > MAX_FLAT_QUERY_TOKENS:
+        if Lq > max_flat_query_tokens(dim):
             return None
         oh = (torch.arange(n_q + 1, dtype=torch.int64) * Lq).to(torch.int32)
         tok = box.reshape(n_q * Lq, dim)
@@ -457,7 +463,7 @@ def _flat_from_device_box(box: torch.Tensor, compact: bool) -> Optional["PackedQ
         _lib_mod.check(L.msim_query_compact(_lib_mod.ptr(box), n_q, Lq, row_bytes, None, _lib_mod.ptr(counts), None, stream),
                        "msim_query_compact")
         counts_h = counts.cpu()
-        if int(counts_h.max()) > MAX_FLAT_QUERY_TOKENS:
+        if int(counts_h.max()) > max_flat_query_tokens(dim):
             return None
         oh = torch.zeros(n_q + 1, dtype=torch.int32)
         torch.cumsum(counts_h, 0, out=oh[1:])
@@ -476,11 +482,11 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
                  compact: bool = True) -> Union[torch.Tensor, "PackedQueries"]:
     """Queries for the device.
 
-    layout="flat" (what "auto" picks on the GPU for bf16 / f16 embeddings of width 128): a `PackedQueries` -- every query's
+    layout="flat" (what "auto" picks on the GPU for bf16 / f16 embeddings of width 128 or 320): a `PackedQueries` -- every query's
     tokens back to back; with `compact` (default) rows that are entirely zero are dropped, which changes no score: a zero
     query row scores exactly 0 against everything (its max is 0).
     layout="box": [n_q, Lq, width], zero padded (rows beyond a query's length and columns beyond its width) -- every other
-    dtype / width, CPU tensors, and queries of more than 1024 tokens.  processing_utils.py:172 pads each 128-query block to
+    dtype / width, CPU tensors, and queries of more than 1024 tokens (512 at width 320).  processing_utils.py:172 pads each 128-query block to
     its own longest query; padding all queries to the global maximum returns identical values for the same reason.
     """
     if layout not in ("auto", "flat", "box"):
@@ -495,8 +501,8 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
             if flat is not None:
                 return flat
         if layout == "flat":
-            raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 on the GPU, at most "
-                                      f"{MAX_FLAT_QUERY_TOKENS} tokens per query")
+            raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 (320) on the GPU, at most "
+                                      f"{MAX_FLAT_QUERY_TOKENS} ({MAX_FLAT_QUERY_TOKENS_WIDE}) tokens per query")
         return _widen(qs.to(device, non_blocking=True)).contiguous()
     if len(qs) == 0:
         raise ValueError("No queries provided")
@@ -519,8 +525,8 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
         if flat is not None:
             return flat
     if layout == "flat":
-        raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 on the GPU, at most "
-                                  f"{MAX_FLAT_QUERY_TOKENS} tokens per query")
+        raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 (320) on the GPU, at most "
+                                  f"{MAX_FLAT_QUERY_TOKENS} ({MAX_FLAT_QUERY_TOKENS_WIDE}) tokens per query")
     if device.type == "cuda" and all(q.device.type == "cpu" for q in qs):
         # no torch CPU op on the way: pad_sequence's parallel loop costs tens of ms on a 128-thread host when it runs
         # between other multi-threaded work (measured 24 ms for 100 x 32 x 128), a memset + one memcpy per query costs 0.1

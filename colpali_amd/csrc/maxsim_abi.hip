@@ -382,6 +382,37 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
     return MSIM_OK;
 }
 
+// document ranges per XCD of a K1b / K1bPF launch (the rule is explained where launch_batch calls it): one block -> one range per
+// resident workgroup; several blocks -> the smallest number of ranges whose last round of resident workgroups is >= 97 % full, else the
+// fullest; never ranges of fewer than `min_docs` documents (~2000 rows by the caller's MSIM_FLAG_AVG_ROWS hint, 64 documents without it)
+int ranges_per_xcd(int n_qblocks, int cus_per_xcd, int n_d, int avg_rows) {
+    int min_docs = 64;
+    if (avg_rows > 0) {
+        min_docs = (2048 + avg_rows - 1) / avg_rows;
+        min_docs = min_docs < 2 ? 2 : (min_docs > 64 ? 64 : min_docs);
+    }
+    int sub = n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / n_qblocks;
+    if (n_qblocks > 1) {
+        double best = 0.0;
+        int best_sub = 1;
+        for (int s = 1; s <= 32; ++s) {
+            if (s > 1 && (long long)8 * s * min_docs > n_d) break;
+            const long long slots_x = (long long)n_qblocks * s;
+            const long long rounds = (slots_x + cus_per_xcd - 1) / cus_per_xcd;
+            const double eff = (double)slots_x / (double)(rounds * cus_per_xcd);
+            if (eff > best + 1e-9) {
+                best = eff;
+                best_sub = s;
+            }
+            if (eff >= (s == 1 ? 0.93 : 0.97)) break;    // one range per XCD keeps every block of a range resident at once: the convoy
+                                                        // holds them together and the range is fetched from HBM once (30 blocks on 32
+                                                        // CUs: 33 GB per launch instead of 354 GB in sixteen ranges, for the same time)
+        }
+        sub = best_sub;
+    }
+    return sub;
+}
+
 template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
 int launch_batch(const FwdCall &c, const FlatPlan &plan) {
     auto kern = msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
@@ -412,30 +443,7 @@ int launch_batch(const FwdCall &c, const FlatPlan &plan) {
         // rows.  The host does not see the row offsets: without the caller's hint (MSIM_FLAG_AVG_ROWS) that is taken as 64 documents.
         // (Round 5: with that floor alone a 1000-page corpus of 1030-row pages -- the drop-in call of BASELINE config 2 -- got ONE range
         // per XCD: 4 query blocks x 8 ranges = 32 workgroups on 256 CUs.)
-        int min_docs = 64;
-        if (c.avg_rows > 0) {
-            min_docs = (2048 + c.avg_rows - 1) / c.avg_rows;
-            min_docs = min_docs < 2 ? 2 : (min_docs > 64 ? 64 : min_docs);
-        }
-        int sub = a.n_qblocks >= cus_per_xcd ? 1 : cus_per_xcd / a.n_qblocks;
-        if (a.n_qblocks > 1) {
-            double best = 0.0;
-            int best_sub = 1;
-            for (int s = 1; s <= 32; ++s) {
-                if (s > 1 && (long long)8 * s * min_docs > c.n_d) break;
-                const long long slots_x = (long long)a.n_qblocks * s;
-                const long long rounds = (slots_x + cus_per_xcd - 1) / cus_per_xcd;
-                const double eff = (double)slots_x / (double)(rounds * cus_per_xcd);
-                if (eff > best + 1e-9) {
-                    best = eff;
-                    best_sub = s;
-                }
-                if (eff >= (s == 1 ? 0.93 : 0.97)) break;    // one range per XCD keeps every block of a range resident at once: the convoy
-                                                            // holds them together and the range is fetched from HBM once (30 blocks on 32
-                                                            // CUs: 33 GB per launch instead of 354 GB in sixteen ranges, for the same time)
-            }
-            sub = best_sub;
-        }
+        int sub = ranges_per_xcd(a.n_qblocks, cus_per_xcd, c.n_d, c.avg_rows);
         // Two workgroups share a CU in the 4-wave form, and the matrix pipe serves the OLDER wave first: of two workgroups that start
         // together one finishes after ~2/3 of the launch and the other runs its last third alone, one wave per SIMD, which cannot fill
         // the pipe (tools/trace_batch.py: workgroup 0 busy for 68 % of the launch; SQ_WAVE_CYCLES: 83 % occupancy).  With 8 x more, smaller
@@ -1030,6 +1038,69 @@ int panels_dispatch(const FwdCall &c) {
     return c.n_q <= 8 ? launch_batch_panels<1, 1, F16>(c) : launch_batch_panels<2, 1, F16>(c);
 }
 
+
+// ---- K1bPF: the flat token layout at width 320 (maxsim_panels.hip).  One shape: 8 waves x <= 4 units, query blocks of whole queries
+// (<= 512 tokens, <= 64 queries), filled greedily in query order and re-cut evenly like K1b's.
+constexpr int kPanelsFlatMaxU = 4;
+constexpr int kPanelsFlatMaxTokens = msim::kBatchWaves * kPanelsFlatMaxU * msim::kUnitTok;      // 512
+
+int panels_flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
+    if ((long long)hq.at(n_q) - hq.at(0) < 0) return fail(MSIM_EINVAL, "query token offsets are not non-decreasing");
+    p = FlatPlan{};
+    p.nw = msim::kBatchWaves;
+    p.maxu = kPanelsFlatMaxU;
+    if (!fill_blocks(hq, n_q, p.nw, p.maxu, p.blk_q0))
+        return fail(MSIM_EUNSUPPORTED, "a query of more than %d tokens does not fit one query block of the width-320 kernels: pad the "
+                    "queries to one length and call msim_fwd", kPanelsFlatMaxTokens);
+    balance_blocks(hq, n_q, p.nw, p.maxu, p.blk_q0);
+    return MSIM_OK;
+}
+
+template <bool F16>
+int launch_batch_panels_flat(const FwdCall &c) {
+    thread_local FlatPlan plan;
+    if (int rc = panels_flat_plan(host_q(c), c.n_q, plan)) return rc;
+    auto kern = msim::maxsim_batch_panels_flat_kernel<F16, kPanels320, kLast320, kPanelsFlatMaxU>;
+    constexpr int lds = msim::kPanelStages * kPanels320 * msim::kSlabBytes + msim::kBatchWaves * kPanelsFlatMaxU * msim::kUnitTok * 16 +
+                        msim::kBatchWaves * 8 * 8;       // stage ring + the per-token max table + the queries' token ranges
+    static std::atomic<int> configured[kMaxDevices];
+    if (int rc = allow_lds(kern, lds, configured)) return rc;
+    const int cus_per_xcd = c.di->cus / 8 > 0 ? c.di->cus / 8 : 1;       // one workgroup per CU
+    const int total_blocks = plan.n_blocks();
+    for (int b0 = 0; b0 < total_blocks; b0 += msim::kMaxQBlocks) {
+        msim::BatchArgs a{};
+        a.ld = c.ld;
+        a.fq = flat_q(c);
+        a.n_d = c.n_d;
+        a.flags = c.flags;
+        a.n_qblocks = total_blocks - b0 < msim::kMaxQBlocks ? total_blocks - b0 : msim::kMaxQBlocks;
+        for (int b = 0; b <= a.n_qblocks; ++b) a.blk_q0[b] = plan.blk_q0[b0 + b];
+        const int sub = ranges_per_xcd(a.n_qblocks, cus_per_xcd, c.n_d, c.avg_rows);
+        a.n_ranges = 8 * sub;
+        const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
+        a.convoy = nullptr;
+        a.trace = nullptr;
+        hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_panels_flat_kernel launch: %s", hipGetErrorString(e));
+    }
+    return MSIM_OK;
+}
+
+// a uniform box [n_q, Lq, 320] on the flat kernel?  K1sP keeps the calls of <= 4 token tiles (HBM-bound, no barriers); K1bP keeps whole
+// queries of 32 or 64 tokens (no padding to win back); everything else up to 512 tokens is scored as 16-token units of the token matrix,
+// which cross query borders (1000 x Lq 40: 2500 units of 16 instead of 2000 tiles of 32) -- and three and more tiles per query, which
+// K1bP does not take, are just more units.  MSIM_PANELS_FLAT=0|1 forces the choice (A/B knob of the measurement builds, not ABI).
+bool box_on_panels_flat(int dtype, int dim, int n_q, int Lq) {
+    if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || dim != 320 || Lq > kPanelsFlatMaxTokens) return false;
+    const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
+    if ((long long)n_q * tpq <= 4) return false;
+    static const int forced = ab_env("MSIM_PANELS_FLAT", -1);
+    if (forced == 0) return tpq > 2;
+    if (forced == 1) return true;
+    return tpq > 2 || (Lq % msim::kTokTile) != 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1078,8 +1149,8 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
     if (n_q < 0 || n_d < 0) return fail(MSIM_EINVAL, "negative size (n_q=%d n_d=%d)", n_q, n_d);
     if (n_q == 0 || n_d == 0) return MSIM_OK;
     if (!scores || !Qt || !D || !d_off || !q_off || !q_off_host) return fail(MSIM_EINVAL, "null pointer argument");
-    if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || dim != msim::kDim)
-        return fail(MSIM_EUNSUPPORTED, "msim_fwd_ragged takes bfloat16 / float16 embeddings of width %d (dtype code %d, dim %d): "
+    if (!(dtype == MSIM_DTYPE_BF16 || dtype == MSIM_DTYPE_F16) || !(dim == msim::kDim || dim == 320))
+        return fail(MSIM_EUNSUPPORTED, "msim_fwd_ragged takes bfloat16 / float16 embeddings of width %d or 320 (dtype code %d, dim %d): "
                     "pad the queries to one length and call msim_fwd", msim::kDim, dtype, dim);
     if ((reinterpret_cast<uintptr_t>(Qt) | reinterpret_cast<uintptr_t>(D)) & 15) return fail(MSIM_EINVAL, "Qt and D must be 16-byte aligned");
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(MSIM_EINVAL, "workspace must be 16-byte aligned");
@@ -1107,6 +1178,21 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
     c.q_off = q_off;
     c.q_off_host = q_off_host;
     c.avg_rows = avg_rows;
+    if (dim == 320) {
+        // width 320 (ColQwen3): queries of ONE length and at most four 32-token tiles in all are a box K1sP streams without a barrier;
+        // everything else goes to the flat panel kernel
+        const int L0 = q_off_host[1];
+        bool uniform = true;
+        for (int i = 1; i < n_q && uniform; ++i) uniform = q_off_host[i + 1] - q_off_host[i] == L0;
+        const int tpq = (L0 + msim::kTokTile - 1) / msim::kTokTile;
+        if (uniform && L0 > 0 && is_panels(dtype, dim, (long long)n_q * tpq, tpq) && (long long)n_q * tpq <= 4) {
+            c.Lq = L0;
+            c.q_off = nullptr;
+            c.q_off_host = nullptr;
+            return dtype == MSIM_DTYPE_F16 ? panels_dispatch<true>(c) : panels_dispatch<false>(c);
+        }
+        return dtype == MSIM_DTYPE_F16 ? launch_batch_panels_flat<true>(c) : launch_batch_panels_flat<false>(c);
+    }
     return dtype == MSIM_DTYPE_F16 ? fwd_dispatch<true>(c) : fwd_dispatch<false>(c);
 }
 
@@ -1122,7 +1208,8 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
     if (flags & ~(MSIM_FLAG_REF_ROUNDING)) return fail(MSIM_EINVAL, "unknown flags 0x%x", flags);
     {
         const int tpq = (Lq + msim::kTokTile - 1) / msim::kTokTile;
-        if (is_panels(dtype, dim, (long long)n_q * tpq, tpq)) {
+        const bool on_flat = box_on_panels_flat(dtype, dim, n_q, Lq);
+        if (on_flat || is_panels(dtype, dim, (long long)n_q * tpq, tpq)) {
             FwdCall c;
             if (int rc = device_info(&c.di)) return rc;
             c.Q = static_cast<const uint16_t *>(Q);
@@ -1135,8 +1222,10 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
             c.Lq = Lq;
             c.n_d = n_d;
             c.flags = flags;
-    c.avg_rows = avg_rows;
+            c.avg_rows = avg_rows;
             c.st = static_cast<hipStream_t>(stream);
+            if (on_flat)      // the box IS a flat token matrix with uniform offsets (FlatQ: q_off null, Lq)
+                return dtype == MSIM_DTYPE_F16 ? launch_batch_panels_flat<true>(c) : launch_batch_panels_flat<false>(c);
             return dtype == MSIM_DTYPE_F16 ? panels_dispatch<true>(c) : panels_dispatch<false>(c);
         }
     }

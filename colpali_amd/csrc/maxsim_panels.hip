@@ -385,4 +385,230 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// K1bPF -- K1bP on the FLAT token layout of maxsim_common.hpp (round 5): the queries are one token matrix Qt [T, DIM] + token offsets,
+// a query block holds WHOLE queries (at most 8 * MAXU units of 16 tokens and 64 queries: one 8-lane group of the 512 threads per query
+// in the reduction), its units are dealt to the eight waves round-robin, and the per-token maxima of a document go through the LDS
+// table where 8 lanes per query add their query's tokens (reduce_query_tokens: the same order as K1s / K1b, whatever the batch).
+// What the [n_q, Lq, DIM] box of K1bP pays for and this form does not: the rows that pad a query to a multiple of 32 tokens (Lq = 40:
+// 64 rows in the box, 48 here) and to the longest query of the call (ragged questions, processing_utils.py:86).  Queries of more than
+// two 32-token tiles -- which K1bP does not take at all -- are just more units.
+// Document stream, stage ring, swizzled panel-slab image and the MFMA chain across the panels are K1bP's; block -> (query block,
+// document range) mapping, the one-table epilogue and its barrier rule (a one-slab document gets a barrier of its own between the
+// previous document's sums and its writes) are K1b's, with the 32-row slab in the place of K1b's chunk.
+template <bool F16, int PANELS, int KS_LAST, int MAXU>
+__global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const uint16_t *__restrict__ Qt, const uint16_t *__restrict__ D,
+                                                                           const int32_t *__restrict__ d_off,
+                                                                           const uint8_t *__restrict__ clamp0,
+                                                                           float *__restrict__ scores, BatchArgs a) {
+    constexpr int KT = (PANELS - 1) * 8 + KS_LAST;
+    constexpr int DIM = KT * 16;
+    constexpr int ROW_BYTES = DIM * 2;
+    constexpr int kStage = PANELS * kSlabBytes;
+    constexpr int NW = kBatchWaves;
+    static_assert(KS_LAST % 2 == 0, "the last panel must hold whole k-steps of 32");
+    static_assert(MAXU >= 1 && MAXU <= 4, "a wave holds up to four units: 4 x KT / 2 operand registers each");
+    constexpr int KT32 = KT / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *const tokmax = smem + kPanelStages * kStage;                       // per-token max table: NW * MAXU units x 16 tokens x 16 B
+    int *const rtab = reinterpret_cast<int *>(tokmax + NW * MAXU * kUnitTok * 16);   // the queries' token ranges: 64 x 2 ints
+
+    // ---- which (query block, document range) is this workgroup?  (K1b's XCD-aware mapping)
+    const int sub = a.n_ranges >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int qblock, range;
+    if (sub > 1) { qblock = slot % a.n_qblocks; range = xcd * sub + slot / a.n_qblocks; }
+    else         { qblock = slot;               range = xcd; }
+    if (qblock >= a.n_qblocks || range >= a.n_ranges) return;
+    const long long row0 = d_off[0], total_rows = (long long)d_off[a.n_d] - row0;     // d_off may be a slice of absolute offsets
+    const int want_lo = (int)(row0 + (total_rows * range) / a.n_ranges), want_hi = (int)(row0 + (total_rows * (range + 1)) / a.n_ranges);
+    const int d_lo = lower_bound_wave(a.n_d, want_lo, lane, [&](int k) { return d_off[k]; });
+    const int d_hi = (range + 1 == a.n_ranges) ? a.n_d : lower_bound_wave(a.n_d, want_hi, lane, [&](int k) { return d_off[k]; });
+    if (d_lo >= d_hi) return;
+
+    // ---- this block's tokens; block-local unit u lives in wave u % NW (slot u / NW)
+    const int qb0 = a.blk_q0[qblock];
+    const int qb_n = a.blk_q0[qblock + 1] - qb0;                             // <= 64
+    const int tok0 = flat_qoff(a.fq, qb0);
+    const int n_tok = flat_qoff(a.fq, qb0 + qb_n) - tok0;                    // <= 16 * NW * MAXU
+    const int n_units = (n_tok + kUnitTok - 1) / kUnitTok;
+    const int my_nu = wave < n_units ? (n_units - 1 - wave) / NW + 1 : 0;    // wave-uniform
+
+    // ---- this wave's share of a stage's 8 * PANELS LDS-DMA wave-instructions (K1bP): rows 4 * wave .. + 3 of every panel-slab
+    const int my_src_full = panel_src_off(lane, wave & 3, ROW_BYTES, 16) + wave * 4 * ROW_BYTES;
+    const int my_src_last = panel_src_off(lane, wave & 3, ROW_BYTES, 2 * KS_LAST) + wave * 4 * ROW_BYTES;
+    const int my_lds = wave * 1024;
+    int rd_off[2][kKSteps16];
+    slab_rd_offsets16(lane, rd_off);
+
+    // ---- producer cursor over the flattened (document, slab) sequence of [d_lo, d_hi)
+    int p_idx = d_lo, p_row = 0, p_len = 0;
+    __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D, 0, 0, 0x00020000);
+    auto p_open = [&]() {
+        while (p_idx < d_hi) {
+            const int r0 = d_off[p_idx], r1 = d_off[p_idx + 1];
+            p_len = r1 - r0;
+            if (p_len > 0) {
+                p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(D + (size_t)r0 * DIM), 0, p_len * ROW_BYTES, 0x00020000);
+                p_row = 0;
+                return;
+            }
+            ++p_idx;
+        }
+    };
+    p_open();
+    int p_slot = 0;
+    auto produce = [&]() -> bool {
+        if (p_idx >= d_hi) return false;
+        char *dst = smem + p_slot * kStage;
+        const int soff = p_row * ROW_BYTES;               // rows past the document end read as zeros (bounds check)
+#pragma unroll
+        for (int u = 0; u < PANELS; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + my_lds + u * kSlabBytes), 16,
+                                                     u == PANELS - 1 ? my_src_last : my_src_full, soff + u * kPanelBytes, 0, 0);
+        p_slot = (p_slot + 1 == kPanelStages) ? 0 : p_slot + 1;
+        p_row += kSlabRows;
+        if (p_row >= p_len) {
+            ++p_idx;
+            p_open();
+        }
+        return true;
+    };
+#pragma unroll
+    for (int i = 0; i < kPanelStages - 1; ++i) produce();
+
+    // ---- the block's units (B operands, [unit][k-step of 32]), loaded behind the first stages' LDS-DMA requests
+    bf16x8 qf[MAXU][KT32];
+#pragma unroll
+    for (int t = 0; t < MAXU; ++t) {
+        const int row = (wave + NW * t) * kUnitTok + (lane & 15);
+        const bool valid = t < my_nu && row < n_tok;
+        const uint16_t *p = Qt + ((size_t)tok0 + (valid ? row : 0)) * DIM + (lane >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KT32; ++ks) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+            qf[t][ks] = valid ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    {
+        const int rq = threadIdx.x >> 3;
+        if (rq < qb_n) {
+            const int s = flat_qoff(a.fq, qb0 + rq) - tok0, e = flat_qoff(a.fq, qb0 + rq + 1) - tok0;
+            rtab[2 * rq] = s;
+            rtab[2 * rq + 1] = e;
+        }
+    }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int t = 0; t < MAXU; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KT32; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+
+    const bool ref_bf16 = (a.flags & kFlagRefBf16) != 0;
+    const bool round_total = ref_bf16 && !(a.flags & kFlagPartial);
+    int c_slot = 0;
+
+    auto reduce_doc = [&](int doc, bool clamp) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));        // opaque: nothing derived from it stays live across the slab loop
+        const int rq = tid >> 3, ri = tid & 7;
+        if (rq < qb_n) {
+            float tot = reduce_query_tokens<F16>(tokmax, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
+            if (round_total) tot = round_to_input<F16>(tot);
+            if (ri == 0) scores[(size_t)(qb0 + rq) * a.ld + doc] = tot;
+        }
+    };
+    auto lds_barrier = [&]() {               // a barrier that also orders this wave's table writes
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    auto run = [&](auto nu_c) {
+    constexpr int NU = decltype(nu_c)::value;
+    constexpr int NUA = NU > 0 ? NU : 1;
+    int pend_doc = -1;                                      // document whose maxima wait in the table (the same in all waves)
+    bool pend_clamp = false;
+    for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
+        const int len = d_off[c_idx + 1] - d_off[c_idx];
+        const int nslab = (len + kSlabRows - 1) / kSlabRows;
+        bool clamp = false;
+        if (clamp0 != nullptr) {
+            const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c_idx;
+            clamp = ((scalar_load_u32(addr & ~3ull) >> ((addr & 3) * 8)) & 0xffu) != 0;
+        }
+        if (nslab == 0) {           // a document without rows never enters the ring: every token's max is over nothing (-inf, or 0 under clamp0)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int rq = tid >> 3;
+            if (rq < qb_n && (tid & 7) == 0)
+                scores[(size_t)(qb0 + rq) * a.ld + c_idx] = (rtab[2 * rq + 1] > rtab[2 * rq] && !clamp) ? -INFINITY : 0.0f;
+            continue;
+        }
+        float m[NUA];
+#pragma unroll
+        for (int t = 0; t < NUA; ++t) m[t] = -INFINITY;
+        for (int s = 0; s < nslab; ++s) {
+            // my share of this stage has landed once at most (stages - 2) later stages of mine are still in flight
+            if (p_idx < d_hi) wait_vmcnt<PANELS * (kPanelStages - 2)>(); else wait_vmcnt<0>();
+            lds_barrier();                  // everyone's share landed; everyone is done reading the previous stage (and has written its maxima)
+            produce();                      // refill the stage that was read in the previous iteration
+            if (s == 0 && pend_doc >= 0) reduce_doc(pend_doc, pend_clamp);   // the previous document's token sums, behind its barrier
+            const char *st = smem + c_slot * kStage;
+            c_slot = (c_slot + 1 == kPanelStages) ? 0 : c_slot + 1;
+            if constexpr (NU > 0) {
+                UnitAcc acc[NUA];
+#pragma unroll
+                for (int t = 0; t < NUA; ++t)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[t].a[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < PANELS; ++p)
+#pragma unroll
+                    for (int ks = 0; ks < kKSteps16; ++ks)
+                        if (ks < (p == PANELS - 1 ? KS_LAST / 2 : kKSteps16)) {
+                            bf16x8 af[2];
+#pragma unroll
+                            for (int g = 0; g < 2; ++g) af[g] = *reinterpret_cast<const bf16x8 *>(st + p * kSlabBytes + rd_off[g][ks]);
+#pragma unroll
+                            for (int t = 0; t < NUA; ++t)
+#pragma unroll
+                                for (int g = 0; g < 2; ++g)
+                                    acc[t].a[g] = mfma16<F16>(af[g], qf[t][p * kKSteps16 + ks], acc[t].a[g]);
+                        }
+                const int rows_left = len - s * kSlabRows;
+#pragma unroll
+                for (int t = 0; t < NUA; ++t) {
+                    if (rows_left < kSlabRows) unit_mask_tail(acc[t], rows_left, lane);
+                    unit_fold(m[t], acc[t]);
+                }
+            }
+        }
+        // ---- document epilogue: this wave's maxima into the workgroup's ONE table; the sums are taken behind the next barrier.  A
+        // one-slab document has no barrier between the previous document's sums and these writes, so it gets one
+        if (nslab == 1) lds_barrier();
+        if constexpr (NU > 0) {
+#pragma unroll
+            for (int t = 0; t < NUA; ++t) store_token_max(tokmax, wave + NW * t, m[t], lane);
+        }
+        pend_doc = c_idx;
+        pend_clamp = clamp;
+    }
+    if (pend_doc >= 0) {
+        lds_barrier();
+        reduce_doc(pend_doc, pend_clamp);
+    }
+    };   // run
+
+    switch (my_nu) {                                       // wave-uniform; every body executes the same barriers
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: if constexpr (MAXU >= 2) run(std::integral_constant<int, 2>{}); break;
+        case 3: if constexpr (MAXU >= 3) run(std::integral_constant<int, 3>{}); break;
+        default: if constexpr (MAXU >= 4) run(std::integral_constant<int, 4>{}); break;
+    }
+}
+
 }  // namespace msim

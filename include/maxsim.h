@@ -29,11 +29,11 @@
  *                                     pad_sequence(..., padding_value=0))
  *   Q        bf16|f16|f32 [n_q, Lq, dim]     queries (same dtype as D), zero rows = padding (they add 0)
  *
- * Flat query layout (msim_fwd_ragged; bf16 / f16, dim 128) -- queries are ragged in real use
+ * Flat query layout (msim_fwd_ragged; bf16 / f16, dim 128 or 320) -- queries are ragged in real use
  * (colpali_engine/utils/processing_utils.py:86 appends 10 augmentation tokens to a question of any length; a batch is
  * padded to its longest member, colpali_engine/collators/visual_retriever_collator.py:82-85) and a zero row adds exactly
  * 0 to every score, so the kernels take the real tokens only:
- *   Qt       bf16|f16 [T, 128]       every query's tokens back to back
+ *   Qt       bf16|f16 [T, dim]       every query's tokens back to back
  *   q_off    int32 [n_q + 1]         query q owns tokens q_off[q] .. q_off[q+1]-1 (on the device AND on the host: the
  *                                    launch plan -- which whole queries share a workgroup -- is made on the host)
  */
@@ -141,8 +141,11 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
  * max_{j in doc c} <Qt[q_off[q] + i, :], D[j, :]>.  A query's score is a pure function of its own tokens and the
  * document (the token sum runs in an order fixed by the query's length alone), so it does not depend on the batch it is
  * scored in, on the kernel shape the plan picks, or on whether msim_fwd or msim_fwd_ragged computed it (for queries of up
- * to 128 tokens).  bf16 / f16 embeddings of width 128 only (MSIM_EUNSUPPORTED otherwise: pad the queries to one length and
- * call msim_fwd); a query may hold 0 .. 1280 tokens.  `q_off` is the device copy, `q_off_host` the host copy of the same
+ * to 128 tokens).  bf16 / f16 embeddings of width 128, a query of 0 .. 1280 tokens -- or of width 320 (ColQwen3,
+ * models/qwen3/colqwen3/modeling_colqwen3.py:48: the flat panel kernel K1bPF), a query of 0 .. 512 tokens; MSIM_EUNSUPPORTED otherwise:
+ * pad the queries to one length and call msim_fwd.  At width 320 a call of ONE query length and at most four 32-token tiles in all is
+ * streamed by K1sP, whose token sum is a butterfly: there the bits depend on which kernel ran (values agree to fp32 summation
+ * order); every other width-320 call is batch-independent like width 128.  `q_off` is the device copy, `q_off_host` the host copy of the same
  * n_q + 1 numbers (read during the call only).  Workspace as msim_fwd's: msim_fwd_ragged_workspace_bytes() bytes or NULL.
  * Replaces the same reference lines as msim_fwd (processing_utils.py:172-179 with its pad_sequence of the query block).
  */

@@ -33,23 +33,23 @@ def amd():
     return colpali_amd
 
 
-def unit_rows(n, g, dtype=torch.bfloat16):
-    return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(dtype)
+def unit_rows(n, g, dtype=torch.bfloat16, dim=128):
+    return torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=-1).to(dtype)
 
 
-def unit_row_list(lens, g, dtype=torch.bfloat16):
+def unit_row_list(lens, g, dtype=torch.bfloat16, dim=128):
     """One tensor of unit rows cut into pieces of the given lengths (one torch call instead of one per piece: a many-core host spends
     tens of milliseconds in every small CPU op)."""
     lens = [int(n) for n in lens]
-    return list(unit_rows(sum(lens), g, dtype).split(lens)) if lens else []
+    return list(unit_rows(sum(lens), g, dtype, dim).split(lens)) if lens else []
 
 
 def oracle(qs, ps, batch_size=10**9):
     return mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], batch_size=batch_size, mode="f32")
 
 
-def docs(g, n, lo, hi, dtype=torch.bfloat16):
-    return unit_row_list(torch.randint(lo, hi + 1, (n,), generator=g).tolist(), g, dtype)
+def docs(g, n, lo, hi, dtype=torch.bfloat16, dim=128):
+    return unit_row_list(torch.randint(lo, hi + 1, (n,), generator=g).tolist(), g, dtype, dim)
 
 
 # (query lengths, what the plan makes of them) -- flat_plan in colpali_amd/csrc/maxsim_abi.hip
@@ -210,7 +210,7 @@ def test_msim_fwd_ragged_through_the_c_abi(amd):
     assert close(out[:, :len(ps)].cpu().numpy(), oracle(qs, ps))
     assert bool((out[:, len(ps):] == -7.0).all())                        # the padding columns of the caller's matrix are untouched
     assert call(dtype=2) == -2 and b"msim_fwd" in L.msim_last_error()     # fp32: not the flat path's shape
-    assert call(dim=320) == -2
+    assert call(dim=64) == -2                                             # 128 and 320 are the flat path's widths
     assert call(ld=len(ps) - 1) == -1
     assert call(flags=0x80) == -1
     bad = off_h.copy()
@@ -254,3 +254,147 @@ def test_flat_forward_captures_in_a_hipgraph(amd):
     torch.cuda.synchronize()
     eager = amd.maxsim_scores(q, corpus)
     assert torch.equal(out, eager)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Width 320 (ColQwen3: colpali_engine/models/qwen3/colqwen3/modeling_colqwen3.py:48) on the flat layout: K1bPF (maxsim_panels.hip),
+# one shape -- 8 waves x <= 4 units per query block (512 tokens, 64 queries) -- plus K1sP for a uniform call of <= 4 token tiles.
+WIDE = 320
+PLANS_WIDE = [
+    ([5], "one query, one unit"),
+    ([16], "one full unit"),
+    ([17], "two units"),
+    ([20, 40, 33], "three ragged queries straddling units"),
+    ([32] * 4, "uniform, four tiles: the box K1sP streams"),
+    ([12] * 8, "uniform, eight tiles of a box = 6 units here"),
+    ([40] * 3, "uniform Lq 40: 120 tokens = 8 units, one per wave"),
+    ([33, 47, 12, 40, 21, 38, 9, 27, 44], "271 tokens = 17 units: three waves hold 3, five hold 2"),
+    ([31] * 16, "496 tokens = 31 units: every wave but one holds 4"),
+    ([32] * 16, "512 tokens: a full block"),
+    ([31] * 30, "930 tokens: two blocks by the token limit"),
+    ([7] * 70, "two blocks by the query limit (64 queries)"),
+    ([200, 33, 270, 12], "long ragged queries: 515 tokens, two blocks"),
+    ([512], "one query filling a block"),
+    ([0, 19, 0, 40], "empty queries score 0"),
+    ([40] * 40, "1600 tokens: four blocks"),
+]
+
+
+@pytest.mark.parametrize("lens,what", PLANS_WIDE, ids=[w for _, w in PLANS_WIDE])
+def test_wide_flat_queries_in_every_plan_shape_match_the_oracle(amd, lens, what):
+    g = torch.Generator().manual_seed(3200 + sum(lens) + len(lens))
+    qs = unit_row_list(lens, g, dim=WIDE)
+    ps = docs(g, 150, 1, 300, dim=WIDE) + unit_row_list([1024, 32, 33, 128, 129], g, dim=WIDE)
+    want = oracle(qs, ps, batch_size=16)
+    got = amd.score_multi_vector(qs, ps, batch_size=16, device="cuda:0").numpy()
+    assert got.shape == (len(qs), len(ps))
+    assert close(got, want), what
+    q = amd.pack_queries(qs, DEV)
+    assert isinstance(q, amd.PackedQueries) and q.lengths.tolist() == lens
+    corpus = amd.pack_passages(ps, DEV, batch_size=len(ps))
+    assert close(amd.maxsim_scores(q, corpus).cpu().numpy(), oracle(qs, ps)), what
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wide_ragged_thousand_queries_many_blocks(amd, dtype):
+    """1000 queries of U{12..48} tokens at width 320: ~60 balanced blocks over several document ranges per XCD; with empty documents
+    and one-slab documents (the barrier of their own) in the corpus."""
+    g = torch.Generator().manual_seed(78)
+    lens = torch.randint(12, 49, (1000,), generator=g).tolist()
+    qs = unit_row_list(lens, g, dtype, WIDE)
+    ps = docs(g, 700, 0, 140, dtype, WIDE)
+    corpus = amd.pack_passages(ps, DEV, batch_size=None)
+    got = amd.maxsim_scores(amd.pack_queries(qs, DEV), corpus).cpu().numpy()
+    empty = np.asarray([p.shape[0] == 0 for p in ps])
+    assert empty.any() and np.all(np.isneginf(got[:, empty]))             # a max over nothing (no passage block pads these: batch_size=None)
+    want = oracle(qs, [p for p in ps if p.shape[0]], batch_size=1)        # blocks of one passage: no block padding either
+    assert close(got[:, ~empty], want)
+
+
+def test_wide_zero_rows_are_dropped_and_the_box_entry_agrees(amd):
+    """Zero padding rows are dropped by pack_queries at width 320 too; the box entry (msim_fwd) of a uniform Lq = 40 batch runs on the
+    same flat kernel (48 rows per query instead of K1bP's 64) and returns the flat entry's bits."""
+    g = torch.Generator().manual_seed(6)
+    lens = [12, 33, 40, 7, 25]
+    l_max = 48
+    ps = docs(g, 120, 5, 400, dim=WIDE)
+    corpus = amd.pack_passages(ps, DEV, batch_size=len(ps))
+    real = [unit_rows(n, g, dim=WIDE) for n in lens]
+    want = oracle(real, ps)
+    box = torch.zeros((len(lens), l_max, WIDE), dtype=torch.bfloat16)
+    for i, q in enumerate(real):
+        box[i, :q.shape[0]] = q
+    s_box = amd.maxsim_scores(box.to(DEV), corpus).cpu().numpy()          # every row multiplied: msim_fwd, K1bP (Lq 48 -> two tiles)
+    for src in (box, box.to(DEV), list(torch.unbind(box))):
+        flat = amd.pack_queries(src, DEV)
+        assert isinstance(flat, amd.PackedQueries) and flat.lengths.tolist() == lens
+        assert close(amd.maxsim_scores(flat, corpus).cpu().numpy(), want)
+    assert close(s_box, want)
+    same = [unit_rows(40, g, dim=WIDE) for _ in range(12)]
+    a = amd.maxsim_scores(torch.stack(same).to(DEV), corpus).cpu().numpy()
+    b = amd.maxsim_scores(amd.pack_queries(same, DEV), corpus).cpu().numpy()
+    assert np.array_equal(a, b) and close(a, oracle(same, ps))
+    three_tiles = [unit_rows(90, g, dim=WIDE) for _ in range(6)]                 # more tiles per query than K1bP takes: units on K1bPF
+    c = amd.maxsim_scores(torch.stack(three_tiles).to(DEV), corpus).cpu().numpy()
+    assert close(c, oracle(three_tiles, ps))
+
+
+def test_wide_query_scores_the_same_bits_in_any_flat_batch(amd):
+    """On K1bPF a query's token sum runs in an order fixed by its own length: the same bits in a one-block launch, in a multi-block
+    launch and at any position (batches of mixed lengths, so none of them is the uniform <= 4-tile call K1sP takes)."""
+    g = torch.Generator().manual_seed(10)
+    lens = torch.randint(10, 49, (90,), generator=g).tolist()
+    lens[0], lens[1] = 11, 37
+    qs = unit_row_list(lens, g, dim=WIDE)
+    ps = docs(g, 300, 30, 500, dim=WIDE)
+    corpus = amd.pack_passages(ps, DEV)
+    full = amd.maxsim_scores(amd.pack_queries(qs, DEV), corpus).cpu().numpy()
+    assert close(full, oracle(qs, ps, batch_size=128))
+    for lo, hi in [(0, 2), (0, 7), (10, 16), (20, 33), (40, 70), (85, 90)]:
+        part = amd.maxsim_scores(amd.pack_queries(qs[lo:hi], DEV), corpus).cpu().numpy()
+        assert np.array_equal(part, full[lo:hi]), (lo, hi)
+
+
+def test_wide_literal_tier_and_too_long_queries(amd):
+    """MSIM_FLAG_REF_ROUNDING on K1bPF: within one bf16 ulp of the oracle's literal tier.  A query above a block's 512 tokens keeps the
+    box layout (generic kernels) and still matches."""
+    g = torch.Generator().manual_seed(22)
+    lens = [12, 40, 33, 48, 20, 17, 29]
+    qs = [unit_rows(n, g, dim=WIDE) for n in lens]
+    ps = docs(g, 100, 10, 300, dim=WIDE)
+    want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], batch_size=128, mode="bf16ref")
+    lit = amd.maxsim_scores(amd.pack_queries(qs, DEV), amd.pack_passages(ps, DEV), ref_rounding=True).cpu().numpy()
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-30))) - 7)
+    assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
+    long_qs = [unit_rows(513, g, dim=WIDE), unit_rows(20, g, dim=WIDE)]
+    packed = amd.pack_queries(long_qs, DEV)
+    assert not isinstance(packed, amd.PackedQueries)
+    assert close(amd.score_multi_vector(long_qs, ps, device="cuda:0").numpy(), oracle(long_qs, ps, batch_size=128))
+
+
+def test_wide_msim_fwd_ragged_through_the_c_abi(amd):
+    """msim_fwd_ragged at width 320 as a C caller uses it; a query above 512 tokens is refused (-2) with a message naming the limit."""
+    L = amd._lib.lib()
+    g = torch.Generator().manual_seed(4)
+    lens = [33, 12, 40, 25, 48, 19]
+    qs = [unit_rows(n, g, dim=WIDE) for n in lens]
+    ps = [unit_rows(150, g, dim=WIDE) for _ in range(80)]
+    corpus = amd.pack_passages(ps, DEV, batch_size=None)
+    tokens = torch.cat(qs).to(DEV)
+    off_h = np.zeros(len(lens) + 1, dtype=np.int32)
+    np.cumsum(lens, out=off_h[1:])
+    off_d = torch.from_numpy(off_h).to(DEV)
+    out = torch.full((len(lens), len(ps) + 3), -7.0, dtype=torch.float32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.msim_fwd_ragged_workspace_bytes(0, off_h.ctypes.data, len(lens), len(ps), WIDE) == 0
+    rc = L.msim_fwd_ragged(0, tokens.data_ptr(), off_d.data_ptr(), off_h.ctypes.data, len(lens), corpus.blob.data_ptr(),
+                           corpus.offsets.data_ptr(), None, len(ps), WIDE, out.data_ptr(), out.stride(0), 0, None, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert close(out[:, :len(ps)].cpu().numpy(), oracle(qs, ps))
+    assert bool((out[:, len(ps):] == -7.0).all())
+    huge = np.array([0, 513], dtype=np.int32)
+    big = torch.zeros((513, WIDE), dtype=torch.bfloat16, device=DEV)
+    rc = L.msim_fwd_ragged(0, big.data_ptr(), off_d.data_ptr(), huge.ctypes.data, 1, corpus.blob.data_ptr(), corpus.offsets.data_ptr(),
+                           None, len(ps), WIDE, out.data_ptr(), out.stride(0), 0, None, st)
+    assert rc == -2 and b"512" in L.msim_last_error()
