@@ -220,6 +220,72 @@ def effective_cpus() -> int:
     return max(1, n)
 
 
+_gpu_cpus = {}
+
+
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(device):
+    """CPUs of the NUMA node the GPU hangs off (`local_cpulist` of its PCI function in sysfs) that this process may run on, or None
+    when the host has one node / sysfs does not say / COLPALI_AMD_NUMA=0.  The GPU boxes are two-socket hosts with four GPUs per
+    socket and no cpuset on the container: a drop-in call whose gather threads and pinned staging buffer sit on the GPU's own socket
+    takes 6.2 ms, one that the scheduler spread over both 7-8.5 ms (profiles/r05_logs/ab_dropin_knobs.log, host_topology.log)."""
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    if idx in _gpu_cpus:
+        return _gpu_cpus[idx]
+    cpus = None
+    if os.environ.get("COLPALI_AMD_NUMA", "1") != "0":
+        try:
+            p = torch.cuda.get_device_properties(idx)
+            bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            local = _parse_cpulist(open(f"/sys/bus/pci/devices/{bus}/local_cpulist").read())
+            allowed = os.sched_getaffinity(0)
+            local &= allowed
+            if len(local) >= 2 and local != allowed:
+                cpus = frozenset(local)
+        except Exception:
+            cpus = None
+    _gpu_cpus[idx] = cpus
+    return cpus
+
+
+class on_gpu_local_cpus:
+    """Context manager: the calling thread runs on the GPU's own NUMA node inside the block (threads it starts there inherit the
+    mask and KEEP it: the native pool's workers are started by their first parallel region; memory it first-touches there is
+    node-local).  A hint only: any failure leaves the affinity as it was."""
+
+    def __init__(self, device):
+        self.cpus = gpu_local_cpus(device) if torch.cuda.is_available() else None
+        self.saved = None
+
+    def __enter__(self):
+        if self.cpus is not None:
+            try:
+                saved = os.sched_getaffinity(0)
+                if saved != self.cpus:
+                    os.sched_setaffinity(0, self.cpus)
+                    self.saved = saved
+            except Exception:
+                self.saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            try:
+                os.sched_setaffinity(0, self.saved)
+            except Exception:
+                pass
+        return False
+
+
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 

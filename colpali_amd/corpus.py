@@ -94,6 +94,9 @@ def _widen(x: torch.Tensor) -> torch.Tensor:
 
 
 _COPY_THREADS = max(1, min(8, _lib_mod.effective_cpus() // 2))      # half of what the container grants, at most 8
+if os.environ.get("COLPALI_AMD_COPY_THREADS"):                      # tuning knob (tools/dropin_profile.py)
+    _COPY_THREADS = max(1, int(os.environ["COLPALI_AMD_COPY_THREADS"]))
+_EDGE_CHUNK_BYTES = int(os.environ.get("COLPALI_AMD_EDGE_CHUNK_MB", "16")) << 20     # first and last chunk of a pipelined upload (0: off)
 # pinned host memory per staging buffer = two halves that alternate: while one half is on its way to the GPU the passages of the
 # next chunk are memcpy'd into the other, so a call costs max(host memcpy, PCIe upload) instead of their sum -- 32 MiB per half
 # is large enough for both to run at full speed and small enough for a 264 MB corpus (1000 ColPali pages) to overlap almost fully
@@ -205,8 +208,7 @@ class _Staging:
         with self.lock:
             half = self._halves(total)
             base = self.buf.data_ptr()
-            for c0 in range(0, total, half):
-                c1 = min(total, c0 + half)
+            for c0, c1 in _chunk_schedule(total, half):
                 h = self.next_half
                 self.next_half ^= 1
                 if self.events[h] is not None:
@@ -221,6 +223,24 @@ class _Staging:
                 self.events[h] = ev
                 if on_chunk is not None:
                     on_chunk(c1)
+
+
+def _chunk_schedule(total: int, half: int):
+    """[c0, c1) byte ranges of a pipelined upload through staging halves of `half` bytes.  Nothing overlaps the gather of the FIRST
+    chunk (no upload is running yet) nor the upload of the LAST one (nothing is left to gather): both are kept small
+    (_EDGE_CHUNK_BYTES), the chunks in between are whole halves.  Measured at BASELINE config 2 (264 MB), toggled inside one process and
+    interleaved (tools/ab_dropin_edge.py, profiles/r05_logs/ab_dropin_edge.log): 16 MiB edges 7.65 -> 7.19 ms and 8.18 -> 7.97 ms
+    (2 / 4 / 8 MiB: -0.0 .. -0.2 ms: their per-chunk cost eats what the shorter head and tail give)."""
+    edge = min(_EDGE_CHUNK_BYTES, half)
+    if edge <= 0 or total <= 2 * half:
+        return [(c0, min(total, c0 + half)) for c0 in range(0, total, half)]
+    cuts = [0, edge]
+    while total - cuts[-1] > half + edge:
+        cuts.append(cuts[-1] + half)
+    if total - cuts[-1] > edge:
+        cuts.append(total - edge)
+    cuts.append(total)
+    return list(zip(cuts[:-1], cuts[1:]))
 
 
 _staging = _Staging()

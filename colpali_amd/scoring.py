@@ -218,17 +218,21 @@ def score_multi_vector(
         assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
         return scores
     dev = _require_gpu(device)
-    q = pack_queries(qs, dev)
-    if not isinstance(ps, torch.Tensor):
-        scores = _score_host_list_pipelined(q, ps, dev, batch_size, ref_rounding)
-        if scores is not None:
-            assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
-            return scores
-    cols = []
-    for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
-        corpus = pack_passages(ps[lo:hi], dev, batch_size=batch_size)
-        cols.append(maxsim_scores(q, corpus, ref_rounding=ref_rounding).cpu())
-        del corpus
+    # The host side of the call -- the native gather threads (started by their first parallel region: they keep the mask), the pinned
+    # staging buffers (first touched here) and the thread that issues the copies -- runs on the GPU's own NUMA node for the length
+    # of the call (colpali_amd/_lib.py: gpu_local_cpus); the caller's affinity is restored on the way out.
+    with _lib.on_gpu_local_cpus(dev):
+        q = pack_queries(qs, dev)
+        if not isinstance(ps, torch.Tensor):
+            scores = _score_host_list_pipelined(q, ps, dev, batch_size, ref_rounding)
+            if scores is not None:
+                assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+                return scores
+        cols = []
+        for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
+            corpus = pack_passages(ps[lo:hi], dev, batch_size=batch_size)
+            cols.append(maxsim_scores(q, corpus, ref_rounding=ref_rounding).cpu())
+            del corpus
     scores = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
     assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
     return scores.to(torch.float32)

@@ -565,3 +565,36 @@ def test_stream_const_cache_evicts_oldest_first_and_is_bounded():
         cache.get(i, "cpu", lambda i=i: made.append(i) or i)
     assert len(cache) == 3 and made == [0, 1, 2, 3, 4]
     assert cache.get(4, "cpu", lambda: "new") == 4 and cache.get(0, "cpu", lambda: "again") == "again"
+
+
+def test_chunk_schedule_covers_the_image_with_small_edges():
+    """The pipelined upload's chunks (colpali_amd/corpus.py): contiguous, every byte once, none above a staging half; images of more
+    than two halves start and end with the small edge chunk."""
+    from colpali_amd import corpus as C
+
+    half = 32 << 20
+    for total in (1, 5 << 20, half, 2 * half, 2 * half + 1, 263_680_000, 7 * half + 12345, 100 * half):
+        sch = C._chunk_schedule(total, half)
+        assert sch[0][0] == 0 and sch[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(sch, sch[1:]))
+        assert all(0 < c1 - c0 <= half for c0, c1 in sch)
+        if total > 2 * half and C._EDGE_CHUNK_BYTES:
+            edge = min(C._EDGE_CHUNK_BYTES, half)
+            assert sch[0][1] - sch[0][0] == edge and sch[-1][1] - sch[-1][0] == edge
+
+
+def test_gpu_local_cpus_is_a_hint_that_never_fails(monkeypatch):
+    """The NUMA-local host side of the drop-in (colpali_amd/_lib.py): cpulist parsing; without a GPU the context manager leaves the
+    caller's affinity alone; COLPALI_AMD_NUMA=0 switches the hint off."""
+    import os
+
+    from colpali_amd import _lib
+
+    assert _lib._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert _lib._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    with _lib.on_gpu_local_cpus(torch.device("cuda:0")) as ctx:
+        if not torch.cuda.is_available():
+            assert ctx.cpus is None
+        assert os.sched_getaffinity(0) == (ctx.cpus or before)
+    assert os.sched_getaffinity(0) == before
