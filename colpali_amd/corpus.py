@@ -123,7 +123,9 @@ class _Staging:
             for ev in self.events:
                 if ev is not None:
                     ev.synchronize()
-            self.buf = torch.empty((2 * half,), dtype=torch.uint8, pin_memory=True)
+            # pinned pages come from the allocating thread's NUMA node: the GPU's own (_lib.gpu_local_cpus), whoever asks first
+            with _lib_mod.on_gpu_local_cpus(torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None):
+                self.buf = torch.empty((2 * half,), dtype=torch.uint8, pin_memory=True)
         return self.buf.numel() // 2
 
     def upload(self, ps: Sequence[torch.Tensor], dim: int, device: torch.device,

@@ -322,47 +322,66 @@ def test_transpose_detecting_asymmetric_inputs_fp32(amd):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# Panel kernels (K1sP / K1bP): the tuned path for dim = 320 (ColQwen3), 16-bit.
+# Panel kernels (K1sP / K1bP / K1bPF): the tuned path for dim = 320 (ColQwen3), 16-bit.  The drop-in packs width-320 queries into
+# the flat layout since round 5 (ragged lists -> K1bPF; a uniform list of <= 4 tiles -> K1sP); the query BOX entry (maxsim_scores on
+# a [n_q, Lq, 320] tensor -> msim_fwd) keeps K1sP (<= 4 tiles in all) and K1bP (whole queries of 32 / 64 rows) and sends the rest to
+# K1bPF: both entries are checked against the oracle for every shape.
+
+def _box320(qs, dtype):
+    """the queries zero-padded to one length that is a multiple of 32 (the shape K1sP / K1bP take as it stands)"""
+    lq = (max(q.shape[0] for q in qs) + 31) // 32 * 32
+    box = torch.zeros((len(qs), lq, 320), dtype=dtype)
+    for i, q in enumerate(qs):
+        box[i, :q.shape[0]] = q
+    return box
+
 
 @pytest.mark.parametrize("dtype,n_q,lq_max,n_d,ld_max,bs", [
-    (torch.bfloat16, 1, 32, 300, 1100, 128),    # K1sP<1,1>: ragged long documents, tails of every size
-    (torch.bfloat16, 2, 20, 257, 200, 128),     # K1sP<2,1>
-    (torch.bfloat16, 3, 32, 64, 1024, 16),      # K1sP<3,1>
-    (torch.bfloat16, 4, 32, 100, 300, 7),       # K1sP<4,1>, clamp0 everywhere
-    (torch.bfloat16, 1, 64, 90, 260, 128),      # K1sP<2,2>
-    (torch.bfloat16, 2, 50, 120, 200, 128),     # K1sP<4,2>
-    (torch.bfloat16, 1, 96, 60, 200, 128),      # K1sP<3,3>
-    (torch.bfloat16, 1, 128, 40, 150, 128),     # K1sP<4,4>
-    (torch.bfloat16, 8, 32, 300, 500, 128),     # K1bP<1,1>: exactly one workgroup's queries
-    (torch.bfloat16, 5, 32, 300, 500, 5),       # K1bP<1,1>: partial
-    (torch.bfloat16, 13, 32, 300, 500, 128),    # K1bP<2,1>
-    (torch.bfloat16, 33, 32, 500, 300, 128),    # K1bP<2,1>, three query blocks, partial last block
-    (torch.bfloat16, 17, 64, 90, 260, 128),     # K1bP<2,2>
-    (torch.bfloat16, 9, 100, 40, 130, 128),     # four tiles per query, more than K1sP holds -> generic kernel
+    (torch.bfloat16, 1, 32, 300, 1100, 128),    # box: K1sP<1,1>: ragged long documents, tails of every size
+    (torch.bfloat16, 2, 20, 257, 200, 128),     # box: K1sP<2,1>
+    (torch.bfloat16, 3, 32, 64, 1024, 16),      # box: K1sP<3,1>
+    (torch.bfloat16, 4, 32, 100, 300, 7),       # box: K1sP<4,1>, clamp0 everywhere
+    (torch.bfloat16, 1, 64, 90, 260, 128),      # box: K1sP<2,2>
+    (torch.bfloat16, 2, 50, 120, 200, 128),     # box: K1sP<4,2>
+    (torch.bfloat16, 1, 96, 60, 200, 128),      # box: K1sP<3,3>
+    (torch.bfloat16, 1, 128, 40, 150, 128),     # box: K1sP<4,4>
+    (torch.bfloat16, 8, 32, 300, 500, 128),     # box: K1bP<1,1>: exactly one workgroup's queries
+    (torch.bfloat16, 5, 32, 300, 500, 5),       # box: K1bP<1,1>: partial
+    (torch.bfloat16, 13, 32, 300, 500, 128),    # box: K1bP<2,1>
+    (torch.bfloat16, 33, 32, 500, 300, 128),    # box: K1bP<2,1>, three query blocks, partial last block
+    (torch.bfloat16, 17, 64, 90, 260, 128),     # box: K1bP<2,2>
+    (torch.bfloat16, 9, 100, 40, 130, 128),     # box: four tiles per query, more than K1bP takes -> K1bPF (the generic kernel before round 5)
     (torch.float16, 3, 32, 200, 700, 128),
     (torch.float16, 40, 40, 120, 500, 128),
 ])
 def test_dim320_panel_kernels_against_oracle(amd, dtype, n_q, lq_max, n_d, ld_max, bs):
     qs, ps = _random_generic(n_q * 31 + n_d, n_q, lq_max, n_d, ld_max, 320, dtype)
-    got = amd.score_multi_vector(qs, ps, batch_size=bs, device="cuda:0").numpy()
-    assert close(got, _oracle(qs, ps, bs))
+    want = _oracle(qs, ps, bs)
+    got = amd.score_multi_vector(qs, ps, batch_size=bs, device="cuda:0").numpy()        # flat entry: K1bPF / K1sP
+    assert close(got, want)
+    dev = torch.device("cuda:0")
+    corpus = amd.pack_passages(ps, dev, batch_size=bs)
+    box = amd.maxsim_scores(_box320(qs, dtype).to(dev), corpus).cpu().numpy()           # box entry: K1sP / K1bP (zero rows add exactly 0)
+    assert close(box, want)
 
 
 def test_dim320_panel_kernels_agree_bitwise_with_each_other_and_closely_with_the_generic_kernel(amd):
     # the same 16x16x32 MFMA chain in the same k order and the same reduction tree in K1sP (query alone) and K1bP (inside a
-    # batch): bit-identical; K1g (same query zero-padded to 160 tokens: five tiles, which only the generic kernel takes) runs
-    # 32x32x16 tiles: equal up to the summation order inside the matrix unit
+    # batch): bit-identical.  K1bPF (the same queries in the flat layout) runs the same chain and adds the tokens in K1b's order, K1g
+    # (same query zero-padded to 520 tokens: more than a K1bPF block holds, which only the generic kernel takes) runs 32x32x16 tiles:
+    # both equal up to fp32 summation order
     qs, ps = _random_generic(11, 20, 32, 200, 500, 320, torch.bfloat16)
     dev = torch.device("cuda:0")
     corpus = amd.pack_passages(ps, dev)
-    big = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()                      # K1bP<2,1>
-    lq = max(q.shape[0] for q in qs)
+    box = _box320(qs, torch.bfloat16)
+    big = amd.maxsim_scores(box.to(dev), corpus).cpu()                                    # K1bP<2,1>
+    flat = amd.maxsim_scores(amd.pack_queries(qs, dev), corpus).cpu()                     # K1bPF
+    assert float(((flat - big).abs() / big.abs().clamp_min(1.0)).max()) < 2e-6
     for i in (0, 7, 19):
-        padded = torch.cat([qs[i], qs[i].new_zeros(lq - qs[i].shape[0], 320)])
-        one = amd.maxsim_scores(amd.pack_queries([padded], dev), corpus).cpu()            # K1sP<1,1>
+        one = amd.maxsim_scores(box[i:i + 1].to(dev), corpus).cpu()                       # K1sP<1,1>
         assert torch.equal(one[0], big[i])
-        long_q = torch.cat([qs[i], qs[i].new_zeros(160 - qs[i].shape[0], 320)])
-        gen = amd.maxsim_scores(amd.pack_queries([long_q], dev), corpus).cpu()            # K1g
+        long_q = torch.cat([qs[i], qs[i].new_zeros(520 - qs[i].shape[0], 320)])
+        gen = amd.maxsim_scores(long_q[None].to(dev), corpus).cpu()                       # K1g
         assert float(((gen[0] - big[i]).abs() / big[i].abs().clamp_min(1.0)).max()) < 2e-6
 
 
@@ -372,10 +391,13 @@ def test_dim320_many_documents_and_literal_rounding(amd):
     assert close(got, _oracle(qs, ps, 128))
     qs, ps = _random_generic(6, 12, 32, 300, 400, 320, torch.bfloat16)
     dev = torch.device("cuda:0")
-    lit = amd.maxsim_scores(amd.pack_queries(qs, dev), amd.pack_passages(ps, dev), ref_rounding=True).cpu().numpy()
     want = mo.score_multi_vector([q.float().numpy() for q in qs], [p.float().numpy() for p in ps], mode="bf16ref")
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-3))) - 7)
-    assert np.all(np.abs(lit - want) <= ulp) and np.mean(lit == want) > 0.9
+    corpus = amd.pack_passages(ps, dev)
+    for queries in (amd.pack_queries(qs, dev), _box320(qs, torch.bfloat16).to(dev), _box320(qs[:3], torch.bfloat16).to(dev)):   # K1bPF, K1bP, K1sP
+        lit = amd.maxsim_scores(queries, corpus, ref_rounding=True).cpu().numpy()
+        w, u = want[:lit.shape[0]], ulp[:lit.shape[0]]
+        assert np.all(np.abs(lit - w) <= u) and np.mean(lit == w) > 0.9
 
 
 @pytest.mark.parametrize("n_q,lq,n_d,ld_max,dtype", [
