@@ -38,6 +38,9 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
         case MSIM_PROBE_PIECES128B: piece = 128; break;
         case 11: case 12: case 13: piece = 128; break;          // round 3: the 128-byte pattern with other lane -> (row, chunk) mappings
         case MSIM_PROBE_PIECES512B: piece = 512; tile_rows = 128; break;
+        case 21: piece = 512; tile_rows = 64; break;             // round 5: K3's split-K candidates -- what still fits the LDS
+        case 22: piece = 512; tile_rows = 128; break;
+        case 23: piece = 256; tile_rows = 128; break;
         default: return fail(MSIM_EINVAL, "unknown probe variant %d", variant);
     }
     if (row_bytes % piece != 0 || rows % tile_rows != 0)
@@ -50,6 +53,10 @@ int msim_probe_stream(int variant, const void *X, int64_t rows, int row_elems, f
         case 11: rc = run_probe<128, 32, 4, 8, 1>(x, rows, row_elems, sink, st); break;   // 128-byte pieces, rows of an instruction 16 KiB apart
         case 12: rc = run_probe<128, 32, 4, 8, 2>(x, rows, row_elems, sink, st); break;   // ... every row of an instruction at another K chunk
         case 13: rc = run_probe<128, 32, 4, 8, 3>(x, rows, row_elems, sink, st); break;   // ... every instruction of a wave at another K chunk
+        // round 5 (the review's "measured freeze" of K3): the widened visits in the shapes the CU can hold next to the weight ring
+        case 21: rc = run_probe<512, 8, 3, 8>(x, rows, row_elems, sink, st); break;    // 512-byte pieces x 8 rows x 8 waves x 3 slots = 96 KiB
+        case 22: rc = run_probe<512, 16, 2, 8>(x, rows, row_elems, sink, st); break;   // 512-byte pieces x 16 rows x 8 waves x 2 slots = 128 KiB
+        case 23: rc = run_probe<256, 16, 3, 8>(x, rows, row_elems, sink, st); break;   // 256-byte pieces x 16 rows x 8 waves x 3 slots = 96 KiB
         default: rc = run_probe<512, 16, 2, 8>(x, rows, row_elems, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_stream_kernel launch failed (variant %d)", variant);

@@ -17,8 +17,10 @@ for H in [int(x) for x in os.environ.get("PS_WIDTHS", "1536,1984,2048,2112,2560,
     x = torch.empty((rows, H), dtype=torch.bfloat16, device=dev).normal_()
     line = f"row width {H:5d} ({2 * H:5d} B stride), {rows * 2 * H / 2**30:.2f} GiB:"
     for variant, name in ((1, "128-B x 32 rows"), (0, "256-B x 32 rows"), (2, "512-B x 16 rows"), (11, "128-B, rows 16 KiB apart"),
-                          (12, "128-B, chunk skewed per row"), (13, "128-B, chunk skewed per instruction")):
-        piece = {1: 128, 0: 256, 2: 512, 11: 128, 12: 128, 13: 128}[variant]
+                          (12, "128-B, chunk skewed per row"), (13, "128-B, chunk skewed per instruction"),
+                          (21, "512-B x 8 rows x 3 slots (96 KiB)"), (22, "512-B x 16 rows x 2 slots (128 KiB)"),
+                          (23, "256-B x 16 rows x 3 slots (96 KiB)")):
+        piece = {1: 128, 0: 256, 2: 512, 11: 128, 12: 128, 13: 128, 21: 512, 22: 512, 23: 256}[variant]
         if (2 * H) % piece:
             line += f"   {name}: n/a"
             continue
