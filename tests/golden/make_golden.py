@@ -67,10 +67,18 @@ def ragged_case(seed, q_lens, p_lens, dim, batch_sizes, name):
     save(name, **out)
 
 
+def ragged_d320():
+    # (1b) the same at ColQwen3's width (models/qwen3/colqwen3/modeling_colqwen3.py:48): ragged queries straddling 16-token units and
+    #      32-token tiles -- what the flat panel kernel K1bPF sees (round 5)
+    ragged_case(13, [5, 40, 17, 33, 48, 12, 1, 20, 64], [64, 33, 100, 1, 47, 300, 128, 31, 32, 160, 7], 320, [128, 4, 1],
+                "score_ragged_d320.npz")
+
+
 def main():
     # (1) small ragged lists, d=128: exercises block padding (finding 4), tails, 1-row docs
     ragged_case(11, [5, 32, 17, 1], [64, 33, 100, 1, 47, 96, 128, 31, 32, 160], 128, [128, 4, 3, 1],
                 "score_ragged_d128.npz")
+    ragged_d320()
 
     # (2) config 1 of BASELINE.json: 4 queries x 16 docs, [32,128] x [1024,128] bf16.
     #     Inputs are regenerated from the seed by the tests; the sha256 pins them.

@@ -37,8 +37,9 @@ def amd():
     return colpali_amd
 
 
-def test_golden_ragged_all_block_sizes(amd):
-    z = load_golden("score_ragged_d128.npz")
+@pytest.mark.parametrize("name", ["score_ragged_d128.npz", "score_ragged_d320.npz"])      # d320: ColQwen3's width on K1bPF (round 5)
+def test_golden_ragged_all_block_sizes(amd, name):
+    z = load_golden(name)
     qs, ps = ragged_from_golden(z)
     qs = [bits_to_bf16(q) for q in qs]
     ps = [bits_to_bf16(p) for p in ps]

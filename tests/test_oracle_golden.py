@@ -13,8 +13,9 @@ from tests.helpers import bits_list_to_f32, config1_inputs, ragged_from_golden, 
 TRUTH_RTOL = 2e-6
 
 
-def test_ragged_lists_all_block_sizes():
-    z = load_golden("score_ragged_d128.npz")
+@pytest.mark.parametrize("name", ["score_ragged_d128.npz", "score_ragged_d320.npz"])      # d320: ColQwen3's width (round 5)
+def test_ragged_lists_all_block_sizes(name):
+    z = load_golden(name)
     qs, ps = ragged_from_golden(z)
     qs, ps = bits_list_to_f32(qs), bits_list_to_f32(ps)
     for bs in z["batch_sizes"]:
