@@ -145,7 +145,9 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
  * models/qwen3/colqwen3/modeling_colqwen3.py:48: the flat panel kernel K1bPF), a query of 0 .. 512 tokens; MSIM_EUNSUPPORTED otherwise:
  * pad the queries to one length and call msim_fwd.  At width 320 a call of ONE query length and at most four 32-token tiles in all is
  * streamed by K1sP, whose token sum is a butterfly: there the bits depend on which kernel ran (values agree to fp32 summation
- * order); every other width-320 call is batch-independent like width 128.  `q_off` is the device copy, `q_off_host` the host copy of the same
+ * order); every other width-320 call of THIS entry is batch-independent like width 128.  (msim_fwd on a width-320 box whose Lq is a
+ * multiple of 32 runs K1sP / K1bP -- butterfly sums as well: equal to this entry's result up to fp32 summation order, not bit for bit;
+ * any other Lq <= 512 runs the flat kernel and returns this entry's bits.)  `q_off` is the device copy, `q_off_host` the host copy of the same
  * n_q + 1 numbers (read during the call only).  Workspace as msim_fwd's: msim_fwd_ragged_workspace_bytes() bytes or NULL.
  * Replaces the same reference lines as msim_fwd (processing_utils.py:172-179 with its pad_sequence of the query block).
  */
