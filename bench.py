@@ -16,6 +16,10 @@ batch against the whole shard with the fused gfx950 MaxSim kernel, selects the p
 and (N>1) merges the shards' top-k with one RCCL all-gather.  Weak scaling: the shard per GPU is
 fixed, the corpus grows with N.
 
+stdout is ONE compact strict-JSON line (bench_legs/line.py: the contract keys, `roofline`, `cpu_baseline`, `topk_parity` and a flat
+dict of scalar summaries, <= 8 KiB, no NaN tokens); the full report of every leg is written to bench_detail.json next to this file
+(and to gpurun_out/ when that directory exists).  Nothing else is printed to stdout; stderr carries library banners only.
+
 The JSON line carries
   roofline     -- of the dominant kernel (the fused MaxSim kernel), from HIP events recorded on the
                   launch stream inside the timed region; algorithmic bytes = docs streamed once
@@ -37,8 +41,26 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md): 8.0 TB/s; 6.29 TB/s is the measured copy ceiling
-MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak
+from bench_legs.common import (HBM_PEAK_GBS, MFMA_PEAK_TFLOPS, make_queries, make_query_list, make_ragged_shard, make_shard,  # noqa: F401,E402
+                               parse_regime, pmc_traffic, regime_numbers)
+
+# The legs live in bench_legs/ and are imported when they run (tools/*.py reach them as bench.<name> through __getattr__ below).
+_LEGS = {"resident": ("run_regime", "power_sample", "forced_collective_numbers", "stream_ceiling", "mfma_ceiling", "topk_parity",
+                      "ragged_docs_numbers", "short_docs_numbers", "wide_320_numbers"),
+         "baselines": ("cpu_baseline", "reference_scorer", "torch_gpu_reference"),
+         "dropin": ("dropin_numbers", "embed_and_score_numbers"),
+         "head": ("embed_head_numbers",),
+         "loss_step": ("loss_step_numbers",),
+         "vlm": ("vlm_in_the_loop_numbers",)}
+
+
+def __getattr__(name):
+    import importlib
+
+    for mod, names in _LEGS.items():
+        if name in names:
+            return getattr(importlib.import_module(f"bench_legs.{mod}"), name)
+    raise AttributeError(name)
 
 
 def parse_args():
@@ -61,1011 +83,6 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args()
-
-
-def make_shard(n_docs, doc_len, device, seed):
-    """Unit-norm bf16 rows, generated on the device in chunks (no host copy of the corpus exists)."""
-    from colpali_amd.corpus import PackedCorpus
-
-    g = torch.Generator(device=device).manual_seed(seed)
-    blob = torch.empty((n_docs * doc_len, 128), dtype=torch.bfloat16, device=device)
-    chunk = 512
-    for d0 in range(0, n_docs, chunk):
-        n = min(chunk, n_docs - d0)
-        x = torch.randn((n * doc_len, 128), generator=g, device=device, dtype=torch.float32)
-        blob[d0 * doc_len : (d0 + n) * doc_len] = torch.nn.functional.normalize(x, dim=-1).to(torch.bfloat16)
-    lengths = torch.full((n_docs,), doc_len, dtype=torch.int64)
-    offsets = (torch.arange(n_docs + 1, dtype=torch.int64) * doc_len).to(torch.int32).to(device)
-    return PackedCorpus(blob=blob, offsets=offsets, clamp0=None, lengths=lengths)
-
-
-def make_ragged_shard(n_docs, lo, hi, device, seed):
-    """BASELINE config 3's page geometry on the resident path: ColQwen2 pages of U{lo..hi} patch rows each (dynamic resolution), unit-norm
-    bf16 rows generated on the device."""
-    from colpali_amd.corpus import PackedCorpus
-
-    gl = torch.Generator().manual_seed(seed)
-    lengths = torch.randint(lo, hi + 1, (n_docs,), generator=gl)
-    offsets = torch.zeros(n_docs + 1, dtype=torch.int64)
-    torch.cumsum(lengths, 0, out=offsets[1:])
-    rows = int(offsets[-1])
-    g = torch.Generator(device=device).manual_seed(seed)
-    blob = torch.empty((rows, 128), dtype=torch.bfloat16, device=device)
-    step = 1 << 19
-    for r0 in range(0, rows, step):
-        n = min(step, rows - r0)
-        x = torch.randn((n, 128), generator=g, device=device, dtype=torch.float32)
-        blob[r0:r0 + n] = torch.nn.functional.normalize(x, dim=-1).to(torch.bfloat16)
-    return PackedCorpus(blob=blob, offsets=offsets.to(torch.int32).to(device), clamp0=None, lengths=lengths.to(torch.int64))
-
-
-def ragged_docs_numbers(amd, dev, topk):
-    """The resident path on BASELINE config 3's page geometry (ColQwen2: 267..779 patch rows per page, here 60 000 pages = 8 GiB): the
-    HBM-bound and the MFMA-bound regime with ragged documents AND ragged queries.  Context (the headline shard is config 4's 1024-row pages)."""
-    corpus = make_ragged_shard(60000, 267, 779, dev, seed=77)
-    rows = int(corpus.blob.shape[0])
-    out = {"workload": f"60000 pages x U{{267..779}} rows ({rows} rows, {rows * 256 / 2**30:.1f} GiB resident)"}
-    for name, lens in (("4_queries_x_32", [32] * 4), ("4_queries_ragged_12_48", parse_regime("4xr12-48", 32)[1]),
-                       ("1000_queries_ragged_12_48", parse_regime("1000xr12-48", 32)[1])):
-        q = amd.pack_queries(make_query_list(lens, seed=sum(lens)), dev)
-        scores = torch.empty((len(lens), len(corpus)), dtype=torch.float32, device=dev)
-        for _ in range(2):
-            amd.maxsim_scores(q, corpus, out=scores)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-        for a, b in evs:
-            a.record(); amd.maxsim_scores(q, corpus, out=scores); b.record()
-        amd.topk(scores, topk)
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in evs)[2]
-        alg = rows * 256 + sum(lens) * 256 + len(lens) * len(corpus) * 4
-        flops = 2.0 * sum(lens) * rows * 128
-        gbs, tf = alg / ms / 1e6, flops / ms / 1e9
-        bound = "hbm" if alg / HBM_PEAK_GBS / 1e9 >= flops / MFMA_PEAK_TFLOPS / 1e12 else "mfma"
-        out[name] = {"kernel_ms": ms, "pairs_per_s": len(lens) * len(corpus) / ms * 1e3, "hbm_gbs": gbs, "mfma_tflops": tf, "bound": bound,
-                     "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS, "q_tokens": sum(lens)}
-    del corpus
-    return out
-
-
-def short_docs_numbers(amd, dev):
-    """The resident path on SHORT documents (round-4 review, weak 8): a token-pooled corpus -- pool factor 3 of a 1030-patch page
-    (README.md:225, compression/token_pooling) = 343 rows -- and 64-row documents, 8 GiB of rows each, in the HBM-bound and the
-    MFMA-bound regime.  K1b pays one chunk barrier, one table write and one pass of token sums per document: the numbers show what
-    that costs (the structural fix -- several documents per chunk -- is not built)."""
-    out = {}
-    for name, doc_len in (("pooled_343_rows", 343), ("64_rows", 64)):
-        n_docs = (8 << 30) // (doc_len * 256)
-        corpus = make_shard(n_docs, doc_len, dev, seed=5)
-        leg = {"docs": n_docs, "doc_len": doc_len}
-        for qname, lens in (("4_queries_x_32", [32] * 4), ("1000_queries_x_32", [32] * 1000), ("1000_queries_ragged_12_48", parse_regime("1000xr12-48", 32)[1])):
-            q = amd.pack_queries(make_query_list(lens, seed=sum(lens) + doc_len), dev)
-            scores = torch.empty((len(lens), n_docs), dtype=torch.float32, device=dev)
-            amd.maxsim_scores(q, corpus, out=scores)
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
-            for a, b in evs:
-                a.record(); amd.maxsim_scores(q, corpus, out=scores); b.record()
-            torch.cuda.synchronize()
-            ms = sorted(a.elapsed_time(b) for a, b in evs)[1]
-            r = regime_numbers(len(lens), 32, n_docs, doc_len, ms, q_tokens=sum(lens))
-            leg[qname] = {"kernel_ms": ms, "bound": r["bound"], "frac": r["frac"], "hbm_gbs": r["hbm_gbs"], "mfma_tflops": r["mfma_tflops"]}
-            del scores
-        out[name] = leg
-        del corpus
-    return out
-
-
-def wide_320_numbers(amd, dev):
-    """Width 320 (ColQwen3, models/qwen3/colqwen3/modeling_colqwen3.py:48) on the panel kernels: 4 096 pages x 1 024 rows x 320 bf16
-    (2.5 GiB resident).  4 queries: K1sP (HBM-bound); 1000 x 32: K1bP's query box; 1000 x 40 and 1000 ragged U{12..48}: the flat
-    kernel K1bPF (round 5), whose rate per REAL token should sit within 10 % of the Lq 32 one."""
-    n_docs, doc_len, dim = 4096, 1024, 320
-    g = torch.Generator(device=dev).manual_seed(11)
-    blob = torch.nn.functional.normalize(torch.randn((n_docs * doc_len, dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
-    from colpali_amd.corpus import PackedCorpus
-    corpus = PackedCorpus(blob=blob, offsets=(torch.arange(n_docs + 1, dtype=torch.int64) * doc_len).to(torch.int32).to(dev), clamp0=None,
-                          lengths=torch.full((n_docs,), doc_len, dtype=torch.int64))
-    out = {"workload": f"{n_docs} pages x {doc_len} rows x {dim} bf16 ({blob.numel() * 2 / 2**30:.1f} GiB resident)"}
-    for name, lens in (("4_queries_x_32", [32] * 4), ("1000_queries_x_32", [32] * 1000), ("1000_queries_x_40", [40] * 1000),
-                       ("1000_queries_ragged_12_48", parse_regime("1000xr12-48", 32)[1])):
-        tok = torch.nn.functional.normalize(torch.randn((sum(lens), dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
-        uniform = len(set(lens)) == 1
-        q = tok.view(len(lens), lens[0], dim) if uniform else amd.pack_queries(list(tok.split(lens)), dev)     # a box (msim_fwd picks) / flat
-        scores = torch.empty((len(lens), n_docs), dtype=torch.float32, device=dev)
-        amd.maxsim_scores(q, corpus, out=scores)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
-        for a, b in evs:
-            a.record(); amd.maxsim_scores(q, corpus, out=scores); b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in evs)[1]
-        alg = blob.numel() * 2 + sum(lens) * dim * 2 + len(lens) * n_docs * 4
-        flops = 2.0 * sum(lens) * n_docs * doc_len * dim
-        gbs, tf = alg / ms / 1e6, flops / ms / 1e9
-        bound = "hbm" if alg / HBM_PEAK_GBS / 1e9 >= flops / MFMA_PEAK_TFLOPS / 1e12 else "mfma"
-        out[name] = {"kernel_ms": ms, "q_tokens": sum(lens), "real_token_pages_per_s": sum(lens) * n_docs / ms * 1e3, "hbm_gbs": gbs,
-                     "useful_mfma_tflops": tf, "bound": bound, "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS}
-        del scores
-    out["ragged_per_real_token_rate_vs_Lq32"] = (out["1000_queries_ragged_12_48"]["real_token_pages_per_s"] /
-                                                 out["1000_queries_x_32"]["real_token_pages_per_s"])
-    del corpus, blob
-    return out
-
-
-def make_queries(n_q, q_len, device, seed):
-    g = torch.Generator().manual_seed(seed)
-    q = torch.nn.functional.normalize(torch.randn(n_q, q_len, 128, generator=g), dim=-1).to(torch.bfloat16)
-    return q.to(device)
-
-
-def parse_regime(spec, default_len):
-    """'N' | 'NxL' | 'NxrA-B' -> (n_queries, [length of every query], label)."""
-    if "x" not in spec:
-        n = int(spec)
-        return n, [default_len] * n, str(default_len)
-    n, ln = spec.split("x", 1)
-    n = int(n)
-    if ln.startswith("r"):
-        lo, hi = (int(v) for v in ln[1:].split("-"))
-        g = torch.Generator().manual_seed(1000 + n + lo * 7 + hi)
-        return n, torch.randint(lo, hi + 1, (n,), generator=g).tolist(), f"U{{{lo}..{hi}}}"
-    return n, [int(ln)] * n, ln
-
-
-def make_query_list(lens, seed):
-    """Host list of [len_i, 128] unit-row bf16 queries -- the drop-in's own input form (ragged lengths are the normal case)."""
-    g = torch.Generator().manual_seed(seed)
-    return [torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16) for n in lens]
-
-
-def cpu_baseline(q_len, doc_len):
-    """The reference's CPU scorer on the slice SURVEY 8(d) names: 128 queries x 1024 docs (131 072 pairs, one 128 x 128 block row of the
-    reference's blocking x 8), bf16 and fp32 inputs, best of 2.  kind = "reference": the VERBATIM
-    colpali_engine/utils/processing_utils.py (BaseVisualRetrieverProcessor.score_multi_vector, :132-187) -- the live checkout where it
-    exists, else the byte-for-byte git-ignored copy oracle/fetch_reference_tests.py leaves under tests/_reference_pkg/ (it travels to the
-    GPU box with the working tree); kind = "port": oracle/torch_port.py, the restatement with the same torch calls, only where neither
-    file is present."""
-    from oracle import refimport, torch_port
-
-    try:
-        proc, _, where = refimport.load_hot_path()
-        scorer, kind = (lambda a, b: proc.score_multi_vector(a, b, batch_size=128, device="cpu")), "reference"
-        what = f"the reference's own processing_utils.py ({where} copy), BaseVisualRetrieverProcessor.score_multi_vector(device='cpu')"
-    except Exception:
-        scorer, kind = torch_port.score_multi_vector_cpu, "port"
-        what = "oracle/torch_port.py (restatement of processing_utils.py:163-186 with the same torch calls)"
-    g = torch.Generator().manual_seed(11)
-    n_q, n_d = 128, 1024
-    qs = [torch.nn.functional.normalize(torch.randn(q_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_q)]
-    ps = [torch.nn.functional.normalize(torch.randn(doc_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_d)]
-    best = {}
-    for name, cast in (("bf16", lambda t: t), ("fp32", lambda t: t.float())):
-        a, b = [cast(t) for t in qs], [cast(t) for t in ps]
-        scorer(a[:4], b[:16])
-        ts = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            scorer(a, b)
-            ts.append(time.perf_counter() - t0)
-        best[name] = n_q * n_d / min(ts)
-    top = max(best, key=best.get)
-    # the product's own host-core path (score_multi_vector(device="cpu") -> msim_fwd_host) on the same sample and cores: context
-    import colpali_amd as amd
-
-    amd.score_multi_vector(qs[:4], ps[:16], device="cpu")
-    t0 = time.perf_counter()
-    amd.score_multi_vector(qs, ps, device="cpu")
-    host_path = n_q * n_d / (time.perf_counter() - t0)
-    return {
-        "value": best[top], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": kind, "what": what,
-        "colpali_amd_host_path_pairs_per_s": host_path,
-        "sample": f"{n_q} queries x {n_d} docs ({q_len}x128 vs {doc_len}x128), reference blocking batch_size=128, "
-                  f"best of 2, torch CPU einsum/max/sum; bf16 inputs {best['bf16']:.0f} pairs/s, fp32 inputs {best['fp32']:.0f} pairs/s",
-        "host_cpus": os.cpu_count(), "torch_num_threads": torch.get_num_threads(),
-        "cpus_the_container_grants": amd._lib.effective_cpus(),       # affinity and cgroup CPU quota (cpu.max): what `cores` can really use
-    }
-
-
-def reference_scorer(qs, ps, device):
-    """The reference's blocked scorer (oracle/torch_port.py restates processing_utils.py:132-187 with its own torch calls) on
-    `device`: the baseline legs of this file and of tools/ab_dropin.py go through here, nothing else does."""
-    from oracle import torch_port
-
-    return torch_port.score_multi_vector_cpu(qs, ps, device=device)
-
-
-def torch_gpu_reference(q_len, doc_len):
-    """What the unmodified reference does on this same GPU (its torch einsum/max/sum with host-side padding and
-    H2D per block, processing_utils.py:170-180): informational, not the optimisation target."""
-    from oracle import torch_port
-
-    g = torch.Generator().manual_seed(12)
-    n_q, n_d = 128, 1024
-    qs = [torch.nn.functional.normalize(torch.randn(q_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_q)]
-    ps = [torch.nn.functional.normalize(torch.randn(doc_len, 128, generator=g), dim=-1).to(torch.bfloat16) for _ in range(n_d)]
-    torch_port.score_multi_vector_cpu(qs[:8], ps[:128], device="cuda:0")
-    ts = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0")
-        torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    return {"value": n_q * n_d / min(ts), "unit": "pairs/s",
-            "sample": f"{n_q} queries x {n_d} docs from host lists through the reference's blocked einsum on cuda:0 "
-                      f"(includes its per-block pad_sequence + H2D), best of 3"}
-
-
-def dropin_numbers(amd):
-    """BASELINE configs 2/3 geometry through the drop-in entry point itself: 100 queries x 1000 pages handed over as HOST
-    lists (what README.md:121-126 leaves the user with), end to end including packing, PCIe upload and the D2H of the
-    result -- never the headline `value`, which is measured with the corpus resident."""
-    from oracle import torch_port
-
-    g = torch.Generator().manual_seed(21)
-
-    def unit(n):
-        return torch.nn.functional.normalize(torch.randn(n, 128, generator=g), dim=-1).to(torch.bfloat16)
-
-    out = {}
-    for name, lens in (("config2_colpali_1000x1030", [1030] * 1000),
-                       ("config3_colqwen2_1000x267-779", torch.randint(267, 780, (1000,), generator=g).tolist())):
-        qs, ps = [unit(32) for _ in range(100)], [unit(n) for n in lens]
-
-        def timed(fn, reps):
-            fn()
-            ts = []
-            for _ in range(reps):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                fn()
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            return sorted(ts)[len(ts) // 2]
-
-        # 31 calls: median and p95 (round 4 saw 70 ms stalls in one call out of four: the median alone hid them), and where a call's
-        # time goes -- the product's own phase stamps (colpali_amd.scoring.TIMELINE): checks | gather + H2D issue loop | GPU tail
-        from colpali_amd import scoring as _scoring
-
-        amd.score_multi_vector(qs, ps, device="cuda:0")
-        calls, phases = [], []
-        for _ in range(31):
-            _scoring.TIMELINE = []
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            amd.score_multi_vector(qs, ps, device="cuda:0")
-            torch.cuda.synchronize()
-            calls.append(time.perf_counter() - t0)
-            tl = dict(_scoring.TIMELINE)
-            if {"begin", "checked", "issued", "done"} <= set(tl):
-                phases.append((tl["begin"] - t0, tl["checked"] - tl["begin"], tl["issued"] - tl["checked"], tl["done"] - tl["issued"]))
-        _scoring.TIMELINE = None
-        calls.sort()
-        ours = calls[len(calls) // 2]
-        med = lambda k: sorted(p[k] for p in phases)[len(phases) // 2] * 1e3 if phases else None   # noqa: E731
-        nbytes = sum(p.numel() * p.element_size() for p in ps)
-        pin = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=True)
-        devb = torch.empty((nbytes,), dtype=torch.uint8, device="cuda:0")
-        h2d = 1e9
-        for _ in range(5):                    # this box's pinned H2D rate, 32 MiB pieces like the staging buffer's halves
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for o in range(0, nbytes, 32 << 20):
-                devb[o:o + (32 << 20)].copy_(pin[o:o + (32 << 20)], non_blocking=True)
-            torch.cuda.synchronize()
-            h2d = min(h2d, time.perf_counter() - t0)
-        del pin, devb
-        breakdown = {"p95_ms": calls[int(len(calls) * 0.95)] * 1e3, "max_ms": calls[-1] * 1e3, "min_ms": calls[0] * 1e3, "calls": len(calls),
-                     "pack_queries_ms": med(0), "checks_ms": med(1), "gather_and_h2d_issue_loop_ms": med(2), "gpu_tail_ms_last_h2d_kernel_d2h": med(3),
-                     "corpus_mb": nbytes / 1e6, "pinned_h2d_gbs_this_box": nbytes / h2d / 1e9, "h2d_floor_ms": h2d * 1e3,
-                     "frac_of_h2d_roof": h2d / ours,
-                     "what": "the call's floor is the PCIe upload of the corpus; checks, native gather and the MaxSim launches overlap it"}
-        ref = timed(lambda: torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0"), 3)
-        # parity of the two results that were just timed: ours (fp32-accurate scores of the bf16 inputs) against the
-        # reference's own torch calls on this GPU -- on fp32 upcasts of the same inputs (its truth tier) and on the raw bf16
-        # tensors (its literal tier: every similarity and the sum rounded to bf16, SURVEY finding 3)
-        got = amd.score_multi_vector(qs, ps, device="cuda:0")
-        ref32 = torch_port.score_multi_vector_cpu([t.float() for t in qs], [t.float() for t in ps], device="cuda:0")
-        ref16 = torch_port.score_multi_vector_cpu(qs, ps, device="cuda:0")
-        rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1.0)).max())   # noqa: E731
-        e32, e16 = rel(got, ref32), rel(got, ref16)
-        k = 10
-        same_top = float((got.topk(k, dim=1).indices == ref32.topk(k, dim=1).indices).all(dim=1).float().mean())
-        if e32 > 1e-3:
-            raise SystemExit(f"drop-in result differs from the reference's fp32 scorer on this GPU: max rel err {e32}")
-        out[name] = {"pairs": 100 * len(ps), "ms": ours * 1e3, "pairs_per_s": 100 * len(ps) / ours, "breakdown": breakdown,
-                     "reference_on_this_gpu_ms": ref * 1e3, "speedup_vs_reference_on_this_gpu": ref / ours,
-                     "max_rel_err_vs_reference_fp32_on_this_gpu": e32, "max_rel_err_vs_reference_bf16_on_this_gpu": e16,
-                     "frac_queries_with_identical_top10_vs_reference_fp32": same_top}
-    # BASELINE config 1 literally: 4 queries x 16 docs, random bf16 [32,128] x [1024,128] -- a latency case.  The reference runs it on
-    # the CPU (that is its "on CPU" baseline, timed here on this host); ours runs on cuda:0 and returns the same CPU fp32 tensor.
-    qs, ps = [unit(32) for _ in range(4)], [unit(1024) for _ in range(16)]
-    amd.score_multi_vector(qs, ps, device="cuda:0")
-    ts = []
-    for _ in range(21):
-        t0 = time.perf_counter()
-        got = amd.score_multi_vector(qs, ps, device="cuda:0")
-        ts.append(time.perf_counter() - t0)
-    ours1 = sorted(ts)[len(ts) // 2]
-    torch_port.score_multi_vector_cpu(qs, ps)
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        ref_cpu = torch_port.score_multi_vector_cpu([t.float() for t in qs], [t.float() for t in ps])
-        ts.append(time.perf_counter() - t0)
-    amd.score_multi_vector(qs, ps, device="cpu")
-    tc = []
-    for _ in range(21):
-        t0 = time.perf_counter()
-        got_cpu = amd.score_multi_vector(qs, ps, device="cpu")       # BASELINE config 1 AS WRITTEN: the library's host-core path
-        tc.append(time.perf_counter() - t0)
-    out["config1_4x16"] = {"pairs": 64, "ms": ours1 * 1e3, "reference_on_this_host_cpu_ms": sorted(ts)[len(ts) // 2] * 1e3,
-                           "ours_on_this_host_cpu_ms": sorted(tc)[len(tc) // 2] * 1e3,
-                           "ours_on_host_cpu_max_rel_err_vs_reference_fp32_on_cpu": float(((got_cpu - ref_cpu).abs() / ref_cpu.abs().clamp_min(1.0)).max()),
-                           "host_threads": torch.get_num_threads(),
-                           "max_rel_err_vs_reference_fp32_on_cpu": float(((got - ref_cpu).abs() / ref_cpu.abs().clamp_min(1.0)).max()),
-                           "what": "end-to-end latency of one score_multi_vector call from host lists (pack, upload, kernel, D2H)"}
-    out["device_note"] = ("BASELINE config 1 reads 'on CPU': `ours_on_this_host_cpu_ms` is score_multi_vector(device='cpu') -- the library's "
-                          "host-core scorer (msim_fwd_host) -- next to the reference's torch scorer on the same cores; `ms` is the same call with "
-                          "device='cuda:0'.  Both return the reference's CPU fp32 tensor")
-    return out
-
-
-def embed_head_numbers(amd, dev):
-    """SURVEY 8(f) N1, the step before the path: hidden states of 1000 ColPali pages (1030 x 2048 bf16, 4.2 GB) ->
-    projection + L2 norm + mask, written as the scorer's corpus rows.  HBM-bound (128 FLOP per streamed byte)."""
-    out = _embed_head_shape(amd, dev, 1000, 1030, 2048)                     # BASELINE config 2: 1k ColPali pages (PaliGemma-3B, hidden 2048)
-    out["colqwen2_1000x779x1536"] = _embed_head_shape(amd, dev, 1000, 779, 1536)   # config 3: ColQwen2 (Qwen2-VL-2B, hidden 1536)
-    return out
-
-
-def _embed_head_shape(amd, dev, B, S, H):
-    g = torch.Generator(device=dev).manual_seed(3)
-    hidden = torch.randn((B, S, H), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    weight = (torch.randn((128, H), generator=g, device=dev) / H**0.5).to(torch.bfloat16)
-    bias = (torch.randn((128,), generator=g, device=dev) * 0.1).to(torch.bfloat16)
-    mask = torch.ones((B, S), dtype=torch.long, device=dev)
-    mask[:, S - 6:] = 0
-
-    def ref():
-        proj = torch.nn.functional.linear(hidden, weight, bias)
-        proj = proj / proj.norm(dim=-1, keepdim=True)
-        return proj * mask.unsqueeze(-1)
-
-    out = {}
-    for name, fn in (("fused_head", lambda: amd.embedding_head(hidden, weight, bias, mask)), ("reference_lines_on_this_gpu", ref)):
-        for _ in range(2):
-            fn()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(7)]
-        for a, b in evs:
-            a.record(); fn(); b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in evs)[3]
-        byts = B * S * H * 2 + B * S * 256
-        out[name] = {"ms": ms, "rows_per_s": B * S / ms * 1e3, "hbm_gbs": byts / ms / 1e6, "frac_of_8TBs": byts / ms / 1e6 / HBM_PEAK_GBS}
-        # the same call 20 times back to back (no gap between launches: what an indexing loop over batches sees)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(20):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        out[name]["ms_back_to_back"] = a.elapsed_time(b) / 20
-        out[name]["hbm_gbs_back_to_back"] = byts / out[name]["ms_back_to_back"] / 1e6
-        out[name]["frac_of_8TBs_back_to_back"] = out[name]["hbm_gbs_back_to_back"] / HBM_PEAK_GBS   # `ms` above also holds the host's launch latency
-    out["workload"] = f"{B} pages x {S} tokens x hidden {H} bf16 -> [rows, 128] unit rows (algorithmic bytes = hidden read + rows written)"
-    del hidden
-    return out
-
-
-def embed_and_score_numbers(amd, dev):
-    """BASELINE configs 2 / 3 without the VLM: the last hidden states of 1000 ColPali pages (1030 tokens x 2048, padded positions
-    masked) -> embeddings -> scores of 100 queries, end to end on one GPU.
-      ours:       CorpusWriter (fused head writing the scorer's packed corpus, 250 pages per append) -> maxsim_scores -> CPU fp32
-      reference:  its three torch lines (modeling_colpali.py:67-72) -> list(torch.unbind(emb.cpu())) (README.md:121-126) -> its
-                  blocked scorer on cuda:0 (processing_utils.py:170-186, via oracle/torch_port.py)
-    Both produce the [100, 1000] fp32 score matrix on the CPU; they are compared (the reference path rounds every similarity to
-    bf16, so agreement is ~5e-3)."""
-    from oracle import torch_port
-
-    B, S, H, nq = 1000, 1030, 2048, 100
-    g = torch.Generator(device=dev).manual_seed(5)
-    hidden = torch.randn((B, S, H), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    weight = (torch.randn((128, H), generator=g, device=dev) / H**0.5).to(torch.bfloat16)
-    bias = (torch.randn((128,), generator=g, device=dev) * 0.1).to(torch.bfloat16)
-    mask = torch.ones((B, S), dtype=torch.long, device=dev)
-    mask[:, S - 6:] = 0
-    q = make_queries(nq, 32, dev, seed=8)
-    qs_host = list(torch.unbind(q.cpu()))
-
-    def ours():
-        writer = amd.CorpusWriter(capacity_rows=B * S, device=dev)
-        for b0 in range(0, B, 250):
-            writer.append(hidden[b0:b0 + 250], weight, bias, mask[b0:b0 + 250])
-        return amd.maxsim_scores(q, writer.finish()).cpu()
-
-    def ref():
-        proj = torch.nn.functional.linear(hidden, weight, bias)
-        proj = proj / proj.norm(dim=-1, keepdim=True)
-        emb = proj * mask.unsqueeze(-1)
-        ps = list(torch.unbind(emb.to("cpu")))
-        return torch_port.score_multi_vector_cpu(qs_host, ps, device="cuda:0")
-
-    def timed(fn, reps):
-        out = fn()
-        ts = []
-        for _ in range(reps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            out = fn()
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        return sorted(ts)[len(ts) // 2], out
-
-    t_ours, s_ours = timed(ours, 5)
-    t_ref, s_ref = timed(ref, 2)
-    err = float(((s_ours - s_ref).abs() / s_ref.abs().clamp_min(1.0)).max())
-    del hidden
-    return {"workload": f"{B} pages x {S} tokens x hidden {H} bf16 -> embeddings -> scores of {nq} queries (BASELINE configs 2/3 minus the VLM)",
-            "ms": t_ours * 1e3, "pages_per_s": B / t_ours, "reference_path_on_this_gpu_ms": t_ref * 1e3,
-            "speedup_vs_reference_path": t_ref / t_ours, "max_rel_err_vs_reference_path_bf16": err}
-
-
-def _median_ms(fn, reps, sync=True):
-    ts = []
-    for _ in range(reps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    return sorted(ts)[len(ts) // 2] * 1e3
-
-
-def _graph_of(step, warm=3):
-    """`step` captured once as a hipGraph (torch.cuda.graph) after `warm` eager runs on a side stream."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(warm):
-            step()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
-    graph.replay()
-    torch.cuda.synchronize()
-    return graph
-
-
-def _graph_device_ms(graph, replays=50):
-    """Device time of one replay: HIP events on the replay stream around `replays` back-to-back replays (no host gap between them)."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
-        graph.replay()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(replays):
-        graph.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / replays
-
-
-def loss_step_numbers(amd, dev):
-    """BASELINE config 5 -- "ColbertPairwiseCELoss training step, in-batch negatives bs=256, ColQwen2, 8 x MI355X data-parallel" -- as ONE
-    rank sees it: B = 32 local queries [32, Lq, 128] against the C = 256 pages gathered from the 8 ranks [256, 780, 128], offset = rank * B
-    (trainer/contrastive_trainer.py:135-162), and the trainer's symmetric direction (:202-206: the local pages as `query_embeddings`
-    [32, 780, 128] against the gathered queries [256, Lq, 128]); forward + backward of the loss alone (the three VLM forwards around it
-    stay on PyTorch-ROCm), bf16.  Per loss class: eager and one-hipGraph time of the forward direction and of BOTH directions captured as
-    one graph, device time of a replay (HIP events), peak MiB, the fraction of the roof
-        max(2 * B * C * Lq * Ld * 128 FLOP / 2.5 PFLOP/s, (Q + D read, dQ + dD written) / 8 TB/s)     per direction,
-    the reference's own module (the verbatim late_interaction_losses.py where the fetched copy exists, else its restatement) on the same
-    GPU, and loss / gradient error against the float64 oracle (oracle/li_loss_oracle.py: the checker, not the thing measured)."""
-    from oracle import li_loss_oracle, refimport
-
-    B, C, Ld, off = 32, 256, 780, 96
-    g = torch.Generator(device=dev).manual_seed(55)
-
-    def unit(*shape):
-        return torch.nn.functional.normalize(torch.randn(shape, generator=g, device=dev), dim=-1).to(torch.bfloat16)
-
-    try:
-        _, ref_mod, ref_kind = refimport.load_hot_path()
-    except Exception:
-        ref_mod, ref_kind = None, "port"
-
-    def ref_port(kind):
-        def f(q, d, offset=0):            # late_interaction_losses.py:296-313 / :152-164 restated with the reference's own torch calls
-            lengths = (q[:, :, 0] != 0).sum(dim=1)
-            scores = torch.einsum("bnd,csd->bcns", q, d).amax(dim=3).sum(dim=2) / lengths.unsqueeze(1)
-            if kind == "pairwise":
-                pos = scores.diagonal(offset=offset)
-                top2 = scores.topk(2, dim=1).values
-                neg = torch.where(top2[:, 0] == pos, top2[:, 1], top2[:, 0])
-                return torch.nn.functional.softplus(neg - pos).mean()
-            return torch.nn.functional.cross_entropy(scores / 0.02, torch.arange(q.shape[0], device=q.device) + offset)
-        return f
-
-    out = {"shape": {"B": B, "C": C, "Ld": Ld, "dim": 128, "offset": off, "dtype": "bf16"}, "reference_module": ref_kind}
-    for qname, lens in (("Lq32", [32] * C), ("Lq_ragged_20-40_left_padded_to_40", torch.randint(20, 41, (C,), generator=torch.Generator().manual_seed(3)).tolist())):
-        Lq = max(lens)
-        Qg = unit(C, Lq, 128)                                     # the queries of all ranks (the symmetric direction's gathered side)
-        for c, n in enumerate(lens):
-            Qg[c, : Lq - n] = 0                                   # left padding: rows exactly zero (modeling_colqwen2.py:36, :69)
-        D = unit(C, Ld, 128)                                      # the pages of all ranks
-        for b in range(B):                                        # positives: noisy copies of the query's tokens somewhere in its page
-            rows = torch.randperm(Ld, generator=torch.Generator().manual_seed(b))[:Lq].to(dev)
-            D[off + b, rows] = torch.nn.functional.normalize(Qg[off + b].float() + 0.6 * torch.randn((Lq, 128), generator=g, device=dev), dim=-1).to(torch.bfloat16) * (Qg[off + b, :, :1] != 0)
-        Q, P = Qg[off:off + B].clone(), D[off:off + B].clone()    # this rank's own queries and pages
-        flop = 2.0 * B * C * sum(lens[off:off + B]) / B * Ld * 128          # forward direction, real tokens only
-        flop_sym = 2.0 * B * Ld * sum(lens) * 128
-        bytes_dir = 2.0 * 2 * (B * Lq + C * Ld) * 128                        # Q, D read + dQ, dD written, bf16
-        roof_fwd_ms = max(flop / (MFMA_PEAK_TFLOPS * 1e12), bytes_dir / (HBM_PEAK_GBS * 1e9)) * 1e3
-        roof_sym_ms = max(flop_sym / (MFMA_PEAK_TFLOPS * 1e12), 2.0 * 2 * (B * Ld + C * Lq) * 128 / (HBM_PEAK_GBS * 1e9)) * 1e3
-        legs = {}
-        for cls, kind in (("ColbertPairwiseCELoss", "pairwise"), ("ColbertLoss", "infonce")):
-            ours = getattr(amd, cls)()
-            refs = getattr(ref_mod, cls)() if ref_mod is not None else ref_port(kind)
-            leaves = [t.detach().clone().requires_grad_(True) for t in (Q, D, P, Qg)]
-
-            def one(mod, q=leaves[0], d=leaves[1]):
-                q.grad = d.grad = None
-                mod(query_embeddings=q, doc_embeddings=d, offset=off).backward()
-
-            def both(mod, ls=leaves):
-                for t in ls:
-                    t.grad = None
-                l1 = mod(query_embeddings=ls[0], doc_embeddings=ls[1], offset=off)      # contrastive_trainer.py:198
-                l2 = mod(query_embeddings=ls[2], doc_embeddings=ls[3], offset=off)      # :202-206, compute_symetric_loss
-                ((l1 + l2) / 2).backward()
-
-            r = {}
-            for tag, mod in (("ours", ours), ("reference_on_this_gpu", refs)):
-                rr = {}
-                for sname, step in (("forward_direction", lambda m=mod: one(m)), ("both_directions", lambda m=mod: both(m))):
-                    for _ in range(3):
-                        step()
-                    for t in leaves:                 # what the step itself allocates at its peak, gradients included: nothing of a
-                        t.grad = None                # previous step alive when the baseline is taken
-                    torch.cuda.synchronize()
-                    torch.cuda.reset_peak_memory_stats()
-                    base = torch.cuda.memory_allocated()
-                    step()
-                    torch.cuda.synchronize()
-                    rr[sname] = {"eager_ms": _median_ms(step, 11), "peak_mib": (torch.cuda.max_memory_allocated() - base) / 2**20}
-                    if tag == "ours":
-                        graph = _graph_of(step)
-                        rr[sname]["one_hipgraph_ms"] = _median_ms(graph.replay, 21)
-                        rr[sname]["one_hipgraph_device_ms"] = _graph_device_ms(graph)
-                        roof = roof_fwd_ms if sname == "forward_direction" else roof_fwd_ms + roof_sym_ms
-                        rr[sname]["roof_ms"] = roof
-                        rr[sname]["frac_of_roof"] = roof / rr[sname]["one_hipgraph_device_ms"]
-                        del graph
-                r[tag] = rr
-            # parity of what was just timed: loss and gradients of the forward direction against the float64 oracle (CPU, the checker)
-            one(ours)
-            torch.cuda.synchronize()
-            want_loss, want_dq, want_dd = li_loss_oracle.loss_and_grads(kind, Q.float().cpu(), D.float().cpu(), offset=off)
-            got_loss = float(ours(query_embeddings=leaves[0], doc_embeddings=leaves[1], offset=off).detach().float())
-            # padding rows (exactly zero) are excluded: every similarity of such a row ties at 0, the reference's amax backward splits
-            # the gradient evenly, ours routes it to the first row, and the model multiplies it by the attention mask either way
-            q_real = (Q.float().abs().sum(-1, keepdim=True) > 0).cpu()
-            rel = lambda got, want, m=None: float(((got.detach().double().cpu() - want) * (1 if m is None else m)).abs().max() / want.abs().max().clamp_min(1e-30))   # noqa: E731
-            r["parity_vs_float64_oracle"] = {"loss": got_loss, "loss_oracle": float(want_loss),
-                                             "loss_rel_err": abs(got_loss - float(want_loss)) / max(abs(float(want_loss)), 1e-30),
-                                             "dQ_max_err_over_max_abs": rel(leaves[0].grad, want_dq, q_real),
-                                             "dD_max_err_over_max_abs": rel(leaves[1].grad, want_dd),
-                                             "note": "bf16 loss / gradients (one rounding of an fp32 result) against float64 on the same bf16-valued inputs; "
-                                                     "zero (padding) query rows excluded from dQ"}
-            r["speedup_vs_reference_both_directions_eager"] = r["reference_on_this_gpu"]["both_directions"]["eager_ms"] / r["ours"]["both_directions"]["eager_ms"]
-            legs[cls] = r
-            del leaves
-        out[qname] = legs
-    return out
-
-
-def _vlm_family(family, dev):
-    """(model, page_batch(b), n page tokens, description) for a random-init reference model class of the named geometry."""
-    from oracle import refimport
-
-    g = torch.Generator(device=dev).manual_seed(4)
-    if family == "colpali":
-        from transformers import PaliGemmaConfig
-
-        cls = refimport.load_model_class("models/paligemma/colpali/modeling_colpali", "ColPali")
-        cfg = PaliGemmaConfig(
-            vision_config=dict(model_type="siglip_vision_model", hidden_size=1152, intermediate_size=4304, num_hidden_layers=27,
-                               num_attention_heads=16, image_size=448, patch_size=14, projection_dim=2048, vocab_size=257152),
-            text_config=dict(model_type="gemma", hidden_size=2048, intermediate_size=16384, num_hidden_layers=18, num_attention_heads=8,
-                             num_key_value_heads=1, head_dim=256, vocab_size=257216),
-            image_token_index=257152, projection_dim=2048, hidden_size=2048, vocab_size=257216)
-        S, vocab = 1024 + 6, 250000
-
-        def page_batch(b):
-            ids = torch.randint(0, vocab, (b, S), generator=g, device=dev)
-            ids[:, :1024] = 257152
-            return dict(input_ids=ids, attention_mask=torch.ones((b, S), dtype=torch.long, device=dev),
-                        pixel_values=torch.randn((b, 3, 448, 448), generator=g, device=dev, dtype=torch.bfloat16))
-
-        what = "ColPali of PaliGemma-3B geometry (SigLIP-So400m/14 @ 448 + Gemma-2B): 1024 image tokens + 6 text tokens per page"
-    else:
-        from transformers import Qwen2VLConfig
-
-        cls = refimport.load_model_class("models/qwen2/colqwen2/modeling_colqwen2", "ColQwen2")
-        cfg = Qwen2VLConfig(
-            text_config=dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2,
-                             vocab_size=151936, rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]}, max_position_embeddings=32768,
-                             bos_token_id=151643, eos_token_id=151645),
-            vision_config=dict(depth=32, embed_dim=1280, hidden_size=1536, num_heads=16, mlp_ratio=4, patch_size=14, spatial_merge_size=2,
-                               temporal_patch_size=2, in_channels=3),
-            image_token_id=151655, video_token_id=151656, vision_start_token_id=151652, vision_end_token_id=151653, vocab_size=151936)
-        h, w = 48, 64                      # 3072 patches -> 768 image tokens after the 2 x 2 merge (BASELINE config 3: "768 dynamic patches")
-        n_img, vocab = h * w // 4, 150000
-        S = n_img + 2 + 9
-
-        def page_batch(b):
-            ids = torch.randint(0, vocab, (b, S), generator=g, device=dev)
-            ids[:, 0] = 151652
-            ids[:, 1:1 + n_img] = 151655
-            ids[:, 1 + n_img] = 151653
-            return dict(input_ids=ids, attention_mask=torch.ones((b, S), dtype=torch.long, device=dev),
-                        pixel_values=torch.randn((b, h * w, 1176), generator=g, device=dev, dtype=torch.bfloat16),
-                        image_grid_thw=torch.tensor([[1, h, w]] * b, device=dev), mm_token_type_ids=(ids == 151655).int())
-
-        what = "ColQwen2 of Qwen2-VL-2B geometry (ViT depth 32 + Qwen2-1.5B): 768 image tokens (48 x 64 patches merged 2 x 2) + 11 text tokens per page"
-    torch.manual_seed(0)
-    with torch.device(dev):
-        model = cls(cfg).to(torch.bfloat16).eval()
-    return model, page_batch, S, vocab, what
-
-
-def vlm_in_the_loop_numbers(amd, dev, family="colpali"):
-    """BASELINE configs 2 / 3 AS WRITTEN -- "embed + score 1k synthetic pages" -- with the VLM in the loop: a random-init model of the
-    named geometry (no checkpoint exists offline) embeds 1000 synthetic pages and 100 ragged queries on PyTorch-ROCm, its forward patched by
-    colpali_amd.patch_colpali_engine(models=True) so that the tail is the fused head; the page embeddings go to the resident packed
-    corpus, the queries are scored against it.  The class is the REFERENCE's own (oracle/refimport.py: the fetched, git-ignored copy
-    under tests/_reference_pkg/); when it is not there the leg is skipped.  Context key: the VLM forward dominates by construction
-    and is not ours -- `head_and_scorer_share` says how much of the wall time the path this repository owns takes."""
-    try:
-        model, page_batch, S, vocab, what = _vlm_family(family, dev)
-    except Exception as e:  # context only
-        return {"skipped": f"{type(e).__name__}: {e}"}
-    n_pages, n_q, bs = int(os.environ.get("BENCH_VLM_PAGES", "1000")), 100, 20
-    n_params = sum(p.numel() for p in model.parameters())
-    g = torch.Generator(device=dev).manual_seed(5)
-    q_ids = torch.randint(0, vocab, (n_q, 32), generator=g, device=dev)
-    q_mask = torch.ones((n_q, 32), dtype=torch.long, device=dev)
-    q_mask[:, 24:] = (torch.rand((n_q, 8), generator=g, device=dev) < 0.5).long().cummin(dim=1).values   # ragged right padding
-    batches = [page_batch(bs) for _ in range(2)]
-
-    def run(patched, pages=n_pages):
-        if patched:
-            amd.patch_colpali_engine(scorer=False, losses=False, models=True)
-        try:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                embs = []
-                for i in range(0, pages, bs):
-                    embs.append(model(**batches[(i // bs) & 1]))
-                q = model(input_ids=q_ids, attention_mask=q_mask)
-                torch.cuda.synchronize()
-                t_embed = time.perf_counter() - t0
-                if patched:     # resident road: embeddings never leave the GPU
-                    corpus = amd.pack_passages(torch.cat(embs), dev, batch_size=128)
-                    scores = amd.maxsim_scores(amd.pack_queries(q, dev), corpus).cpu()
-                else:           # the reference's road (README.md:121-126): unbind to host lists, its blocked scorer on this GPU
-                    from oracle import torch_port
-
-                    ps = list(torch.unbind(torch.cat(embs).to("cpu")))
-                    scores = torch_port.score_multi_vector_cpu(list(torch.unbind(q.to("cpu"))), ps, device="cuda:0")
-            torch.cuda.synchronize()
-            t_all = time.perf_counter() - t0
-            # outside the timed region: the reference's scorer in fp32 on the SAME embeddings (its truth tier), so that the scorer's own
-            # error and the end-to-end difference can be read apart from the reference's bf16 rounding
-            from oracle import torch_port as _tp
-
-            all_e = torch.cat(embs)
-            scores32 = _tp.score_multi_vector_cpu(list(torch.unbind(q.float().cpu())), list(torch.unbind(all_e.float().cpu())), device="cuda:0")
-            return t_all, t_embed, scores, scores32
-        finally:
-            if patched:
-                amd.unpatch_colpali_engine()
-
-    run(True, pages=2 * bs)                     # warm-up (library handles, allocator, GEMM autotuning) on two batches
-    run(False, pages=2 * bs)
-    t_ours, t_embed_ours, s_ours, s_ours32 = run(True)
-    t_ref, t_embed_ref, s_ref, s_ref32 = run(False)
-    rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1.0)).max())   # noqa: E731
-    err = rel(s_ours, s_ref)
-    del model
-    torch.cuda.empty_cache()
-    return {"workload": f"random-init {what} ({n_params / 1e9:.2f} B parameters, bf16): {n_pages} pages x {S} tokens (batches of {bs}) + "
-                        f"{n_q} ragged queries embedded on PyTorch-ROCm with the fused head patched into the model's forward, page embeddings -> "
-                        "resident packed corpus -> MaxSim scores -> CPU ('embed + score 1k pages')",
-            "ms": t_ours * 1e3, "pages_per_s": n_pages / t_ours, "embed_ms": t_embed_ours * 1e3,
-            "pack_and_score_ms": (t_ours - t_embed_ours) * 1e3, "head_and_scorer_share": (t_ours - t_embed_ours) / t_ours,
-            "reference_road_on_this_gpu_ms": t_ref * 1e3, "reference_embed_ms": t_embed_ref * 1e3,
-            "reference_unbind_and_score_ms": (t_ref - t_embed_ref) * 1e3, "speedup_vs_reference_road": t_ref / t_ours,
-            "max_rel_err_vs_reference_road_bf16": err,
-            "max_rel_err_vs_reference_road_fp32": rel(s_ours, s_ref32),
-            "scorer_max_rel_err_vs_reference_fp32_scorer_on_the_same_embeddings": rel(s_ours, s_ours32),
-            "error_note": "`..._road_bf16`: against what the reference literally returns (its bf16 einsum rounds every similarity: ~5e-3 by "
-                          "itself, SURVEY finding 3); `..._road_fp32`: against the reference's model + its scorer evaluated in fp32 on its own "
-                          "embeddings (what remains is the heads' last-bit differences, one bf16 ulp per element); `scorer_...`: our scorer against "
-                          "the fp32 reference scorer on the SAME embeddings (the north star's 1e-3 bound applies here)"}
-
-
-def run_regime(amd, q, corpus, steps, warmup, topk, world, rank, dist):
-    """Time `steps` full steps; returns (seconds for the K steps [max over ranks], kernel ms/launch list, the last
-    step's score matrix, the last step's (top scores, top ids))."""
-    dev = q.device
-    scores = torch.empty((len(q), len(corpus)), dtype=torch.float32, device=dev)
-
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        amd.maxsim_scores(q, corpus, out=scores)
-        if ev is not None:
-            ev[1].record()
-        return amd.shard_topk(scores, topk, corpus.id_base, world, dist)
-
-    top = None
-    for _ in range(warmup):
-        top = step()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        top = step(evs[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kern_ms = [a.elapsed_time(b) for a, b in evs]
-    return dt, kern_ms, scores, top
-
-
-def power_sample(amd, q, corpus, seconds=1.2):
-    """Socket power and shader clock while msim_fwd runs back to back for `seconds` (rocm-smi sampled by a thread; context
-    only).  The MI355X clocks to its power budget: next to a regime's roofline fraction this says whether the chip was at its
-    cap (1400 W) and how much clock the power management took (2400 MHz nominal)."""
-    import re
-    import subprocess
-    import threading
-
-    smi = "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
-        return None
-    scores = torch.empty((len(q), len(corpus)), dtype=torch.float32, device=q.device)
-    got, stop = [], threading.Event()
-
-    def sampler():
-        time.sleep(0.3)
-        while not stop.is_set():
-            try:
-                out = subprocess.run([smi, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
-                card = json.loads(out)
-                card = card[sorted(card.keys())[0]]
-                pw = next((float(v) for k, v in card.items() if "ower" in k and re.match(r"^[0-9.]+$", str(v))), None)
-                m = re.search(r"(\d+)\s*Mhz", next((str(v) for k, v in card.items() if k.lower().startswith("sclk")), ""), re.I)
-                got.append((pw, int(m.group(1)) if m else None))
-            except Exception:
-                return
-
-    th = threading.Thread(target=sampler)
-    th.start()
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(max(1, 32 // len(q))):
-            amd.maxsim_scores(q, corpus, out=scores)
-        torch.cuda.synchronize()
-    stop.set()
-    th.join()
-    pw = [p for p, _ in got if p is not None]
-    ck = [c for _, c in got if c is not None]
-    if not pw or not ck:
-        return None
-    return {"socket_power_w_avg": sum(pw) / len(pw), "socket_power_w_max": max(pw), "sclk_mhz_avg": sum(ck) / len(ck), "samples": len(got)}
-
-
-def forced_collective_numbers(amd, q, corpus, topk, dev, steps=5):
-    """The multi-GPU merge path on the ONE GPU this run has: a 1-rank `nccl` (= RCCL) process group, and the step of
-    run_regime() with shard_topk(..., force_collective=True) -- message packing, all_gather_into_tensor on the uint8
-    message, strided-view merge -- checked against the non-collective result.  Context only, never `value`."""
-    import socket
-
-    import torch.distributed as dist
-
-    created = False
-    try:
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if "MASTER_PORT" not in os.environ:
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-            created = True
-        scores = torch.empty((q.shape[0], len(corpus)), dtype=torch.float32, device=dev)
-
-        def step(force):
-            amd.maxsim_scores(q, corpus, out=scores)
-            return amd.shard_topk(scores, topk, corpus.id_base, 1, dist, force_collective=force)
-
-        plain = step(False)
-        forced = step(True)
-        torch.cuda.synchronize()
-        same = bool(torch.equal(plain[0], forced[0]) and torch.equal(plain[1], forced[1]))
-        times = {}
-        for force in (False, True):
-            step(force)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step(force)
-            torch.cuda.synchronize()
-            times[force] = (time.perf_counter() - t0) / steps * 1e3
-        return {"what": "1-rank nccl (RCCL) group on this GPU: per-shard top-k written into the 12 B/candidate message, "
-                        "all_gather_into_tensor, merge on strided views of the gathered bytes",
-                "backend": dist.get_backend(), "world": dist.get_world_size(), "ids_and_scores_equal_to_non_collective": same,
-                "ms_per_step_non_collective": times[False], "ms_per_step_forced_collective": times[True]}
-    except Exception as e:  # context only: never take the bench line down
-        return {"error": f"{type(e).__name__}: {e}"}
-    finally:
-        if created:
-            dist.destroy_process_group()
-
-
-def pmc_traffic(n_q, n_docs, doc_len, q_tokens=None):
-    """HBM bytes per launch measured with rocprofv3 PMC counters for this exact workload (committed under
-    profiles/ by tools/summarize_profile.py; FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section), else None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        table = json.load(open(path))
-    except Exception:
-        return None
-    q_tokens = n_q * 32 if q_tokens is None else q_tokens
-    hit = table.get(f"nq{n_q}_tok{q_tokens}_docs{n_docs}_len{doc_len}")
-    if hit is None and q_tokens == n_q * 32:
-        hit = table.get(f"nq{n_q}_docs{n_docs}_len{doc_len}")
-    return hit
-
-
-def regime_numbers(n_q, q_len, n_docs, doc_len, kern_ms_avg, q_tokens=None):
-    """`q_tokens`: REAL query tokens in the batch (ragged batches); FLOP and bytes count real tokens only -- padding an
-    implementation adds is never credited."""
-    pairs = n_q * n_docs
-    q_tokens = n_q * q_len if q_tokens is None else q_tokens
-    alg_bytes = n_docs * doc_len * 256 + q_tokens * 256 + pairs * 4   # docs streamed once per launch
-    flops = 2.0 * q_tokens * n_docs * doc_len * 128
-    sec = kern_ms_avg * 1e-3
-    gbs, tf = alg_bytes / sec / 1e9, flops / sec / 1e12
-    hbm_bound_s, mfma_bound_s = alg_bytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS * 1e12)
-    if hbm_bound_s >= mfma_bound_s:
-        roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-    else:
-        roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
-    roof.update({"traffic": pmc_traffic(n_q, n_docs, doc_len, q_tokens),
-                 "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this workload; not re-measured in this run)",
-                 "kernel": "maxsim fused forward", "kernel_ms": kern_ms_avg,
-                 "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops,
-                 "hbm_gbs": gbs, "mfma_tflops": tf})
-    return roof
-
-
-def stream_ceiling(amd, corpus):
-    """The machine's own ceiling for K1s' document stream: the same LDS-DMA loads of the same resident shard with no MFMA, no
-    max/sum and no output (msim_probe_stream, include/maxsim_probe.h: tools/probe/libmaxsim_probe.so, not the product library).  GB/s of the shard bytes; HIP events on the launch stream."""
-    from tools import probe
-
-    L = probe.lib()
-    if L is None:
-        return None
-    rows = int(corpus.blob.shape[0]) // 256 * 256
-    sink = torch.zeros(4, dtype=torch.float32, device=corpus.blob.device)
-    st = torch.cuda.current_stream()
-    ms = []
-    for i in range(7):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(st)
-        rc = L.msim_probe_stream(0, corpus.blob.data_ptr(), rows, 128, sink.data_ptr(), st.cuda_stream)
-        b.record(st)
-        torch.cuda.synchronize()
-        if rc != 0:
-            raise RuntimeError(f"msim_probe_stream failed: {L.msim_probe_last_error().decode()}")
-        if i >= 2:
-            ms.append(a.elapsed_time(b))
-    t = sorted(ms)[len(ms) // 2]
-    return {"gbs": rows * 256 / t / 1e6, "ms": t, "what": "msim_probe_stream(MSIM_PROBE_ROWS256B) over the same shard: "
-            "K1s' loads without its arithmetic"}
-
-
-def topk_parity(amd, q, corpus, scores, top_s, top_i, k, n_queries=2, n_random=1000):
-    """SURVEY 8(d) C4-ii on this rank's shard: for `n_queries` sampled queries re-score the returned per-shard top-k plus
-    `n_random` random documents with the CPU oracle (truth tier: fp32 inputs, double accumulate) and compare rankings.
-
-    `ids_equal`: at every rank r the oracle score of the returned id equals the r-th best oracle score of the candidate set
-    within twice the measured score error (a different id is only accepted between documents the two computations cannot
-    tell apart); `ids_exact_equal`: the id lists are identical to the oracle's (score desc, id asc) ranking."""
-    import numpy as np
-
-    from oracle import maxsim_oracle as mo
-    from oracle import topk_oracle
-
-    n = len(corpus)
-    gq = torch.Generator().manual_seed(17)
-    qsel = torch.randperm(q.shape[0], generator=gq)[:n_queries].tolist()
-    off = corpus.offsets.cpu().numpy().astype(np.int64)
-    ids_equal, exact, max_err, n_cand = True, True, 0.0, 0
-    for qi in qsel:
-        ret = top_i[qi].cpu().numpy()
-        ret_local = ret[ret >= 0] - corpus.id_base
-        rnd = torch.randperm(n, generator=gq)[:n_random].numpy()
-        cand = np.unique(np.concatenate([ret_local, rnd]))            # sorted local ids
-        docs = [corpus.blob[int(off[c]):int(off[c + 1])].float().cpu().numpy() for c in cand]
-        want = mo.score_multi_vector([q[qi].float().cpu().numpy()], docs, batch_size=10**9, mode="f32")[0]
-        got = scores[qi, torch.from_numpy(cand).to(scores.device)].float().cpu().numpy()
-        err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
-        max_err = max(max_err, err)
-        kk = int(min(k, len(ret_local)))
-        # the returned list must be the top-k of the candidate set (every returned id is in it; a random non-returned
-        # document that out-scores a returned one is a ranking error)
-        _, w_ids = topk_oracle.topk(want[None, :], kk, ids=(cand + corpus.id_base)[None, :])
-        exact = exact and bool(np.array_equal(w_ids[0], ret[:kk]))
-        order = np.argsort(-want, kind="stable")[:kk]
-        pos = np.searchsorted(cand, ret_local[:kk])
-        tol = 2.0 * err + 1e-7
-        ids_equal = ids_equal and bool(np.all(np.abs(want[pos] - want[order]) <= tol * np.maximum(np.abs(want[order]), 1.0)))
-        n_cand += len(cand)
-    return {"checked_queries": len(qsel), "candidates_rescored": n_cand, "k": k, "ids_equal": ids_equal,
-            "ids_exact_equal": exact, "max_rel_err": max_err,
-            "what": "returned top-k + random docs of this rank's shard re-scored by the CPU oracle (fp32 inputs, double "
-                    "accumulate); ids_equal tolerates swaps only between docs closer than 2 x max_rel_err"}
-
-
-def mfma_ceiling(amd, corpus):
-    """The machine's own matrix-core ceiling under its power budget (msim_probe_mfma, include/maxsim_probe.h: tools/probe/libmaxsim_probe.so, not the product library): back-to-back
-    v_mfma_f32_16x16x32_bf16 on rows of the resident shard (the operand values the scorer multiplies), two waves per SIMD, no HBM
-    traffic.  `kernel_mix` = with K1b's operand path (A fragments re-read from LDS) and its max folds; `registers_only` = nothing
-    but MFMAs.  MI355X clocks to its power budget: on real operand values the chip does not reach the 2.5 PFLOP/s of
-    1024 SIMDs x 1024 FLOP/clk x 2.4 GHz (on zeros it nearly does), so this is what an MFMA-bound kernel can be held against."""
-    from tools import probe
-
-    L = probe.lib()
-    rows = int(corpus.blob.shape[0])
-    if L is None or rows < 256 * 8 * 5 * 32:
-        return None
-    sink = torch.zeros(4, dtype=torch.float32, device=corpus.blob.device)
-    st = torch.cuda.current_stream()
-    iters = 4000
-    flop = 256 * 8 * iters * 32 * 32768
-    out = {}
-    for name, variant in (("kernel_mix", 7), ("registers_only", 4), ("kernel_mix_32x32x16_tiles", 3)):
-        ms = []
-        for i in range(6):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(st)
-            rc = L.msim_probe_mfma(variant, corpus.blob.data_ptr(), rows, iters, sink.data_ptr(), st.cuda_stream)
-            b.record(st)
-            torch.cuda.synchronize()
-            if rc != 0:
-                raise RuntimeError(f"msim_probe_mfma failed: {L.msim_probe_last_error().decode()}")
-            if i >= 2:
-                ms.append(a.elapsed_time(b))
-        out[name + "_tflops"] = flop / sorted(ms)[len(ms) // 2] / 1e9
-    out["what"] = ("msim_probe_mfma on rows of the resident shard: v_mfma_f32_16x16x32_bf16 (the scorers' tile shape) back to back, 2 waves "
-                   "per SIMD, no memory traffic; kernel_mix = A fragments from LDS + max folds (K1s / K1b's instruction mix), "
-                   "registers_only = MFMAs alone; kernel_mix_32x32x16_tiles = the same mix on the 32x32x16 tile the kernels used before")
-    return out
 
 
 def _free_port():
@@ -1149,6 +166,9 @@ def main():
             dist.init_process_group(backend=backend)
 
     import colpali_amd as amd
+    from bench_legs import line as bench_line
+    from bench_legs.resident import (forced_collective_numbers, mfma_ceiling, power_sample, ragged_docs_numbers, run_regime, short_docs_numbers,
+                                     stream_ceiling, topk_parity, topk_vs_reference_fp32, wide_320_numbers)
 
     amd._lib.lib()  # fail loudly if the HIP library is missing
     # torch sizes its intra-op pool by the host's CPU count (128 threads on a 256-CPU box) -- not by what the container may use
@@ -1223,6 +243,11 @@ def main():
         par = topk_parity(amd, q, corpus, scores, local_top[0], local_top[1], args.topk, n_random=n_rand)
         par100 = topk_parity(amd, q, corpus, scores, *amd.topk(scores, 100, corpus.id_base), 100, n_queries=1, n_random=n_rand)
         par["k100"] = {k_: par100[k_] for k_ in ("checked_queries", "ids_equal", "ids_exact_equal", "max_rel_err")}
+        if world == 1:
+            try:    # the north star's own wording: ids against the reference einsum scorer's fp32 output, k = 10 and k = 100
+                par["vs_reference_fp32"] = topk_vs_reference_fp32(amd, q, corpus, scores)
+            except Exception as e:
+                par["vs_reference_fp32"] = {"error": f"{type(e).__name__}: {e}"}
         if world > 1:
             flags = torch.tensor([int(par["ids_equal"]), int(par["ids_exact_equal"]), int(par100["ids_equal"]),
                                   int(par100["ids_exact_equal"])], dtype=torch.int32, device=ones.device)
@@ -1275,6 +300,10 @@ def main():
     if world == 1 and os.environ.get("BENCH_FORCE_COLLECTIVE", "1") != "0":
         out["forced_collective_1rank"] = forced_collective_numbers(amd, q, corpus, args.topk, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from bench_legs.baselines import cpu_baseline, torch_gpu_reference
+        from bench_legs.dropin import dropin_numbers, embed_and_score_numbers
+        from bench_legs.head import embed_head_numbers
+
         out["cpu_baseline"] = cpu_baseline(args.q_len, args.doc_len)
         out["reference_on_this_gpu"] = torch_gpu_reference(args.q_len, args.doc_len)
         out["embed_head"] = embed_head_numbers(amd, dev)
@@ -1333,6 +362,8 @@ def main():
     out["host_threads"] = {"torch_num_threads": torch.get_num_threads(), "cpus_the_container_grants": granted, "host_cpus": os.cpu_count()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("BENCH_LOSS", "1") != "0":
         try:
+            from bench_legs.loss_step import loss_step_numbers
+
             out["loss_step_config5"] = loss_step_numbers(amd, dev)                 # BASELINE config 5 (after the timed regimes: its float64
         except Exception as e:                                                     # oracle is a minute of CPU work)
             out["loss_step_config5"] = {"error": f"{type(e).__name__}: {e}"}
@@ -1340,16 +371,31 @@ def main():
         for key, family in (("embed_and_score_1k_pages_vlm_in_the_loop", "colpali"),              # BASELINE config 2
                             ("embed_and_score_1k_pages_vlm_in_the_loop_colqwen2", "colqwen2")):     # BASELINE config 3
             try:    # context only, and last: a multi-billion-parameter random-init VLM must never take the bench line down
+                from bench_legs.vlm import vlm_in_the_loop_numbers
+
                 out[key] = vlm_in_the_loop_numbers(amd, dev, family)
             except Exception as e:
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
+        # the full report of every leg -> bench_detail.json (next to this file; also gpurun_out/ when it exists, which gpurun brings
+        # back); stdout gets ONE compact strict-JSON line (bench_legs/line.py: <= 8 KiB -- round 5's 29 KB line went unparsed)
+        detail_name = "bench_detail.json" if world == 1 else f"bench_detail_gpus{world}.json"
+        written = None
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(d):
+                try:
+                    with open(os.path.join(d, detail_name), "w") as f:
+                        f.write(bench_line.dumps_detail(out) + "\n")
+                    written = written or detail_name
+                except OSError:
+                    pass
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (bench_line.dumps_line(out, written) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
     main()
+

@@ -260,7 +260,11 @@ def gpu_local_cpus(device):
 class on_gpu_local_cpus:
     """Context manager: the calling thread runs on the GPU's own NUMA node inside the block (threads it starts there inherit the
     mask and KEEP it: the native pool's workers are started by their first parallel region; memory it first-touches there is
-    node-local).  A hint only: any failure leaves the affinity as it was."""
+    node-local).  A hint only: any failure leaves the affinity as it was.
+    SIDE EFFECT, by design and process-wide: a thread FIRST CREATED inside the block keeps the narrowed mask for its lifetime -- the
+    library's own gather pool (wanted), but also e.g. torch's OpenMP pool if its first parallel region happens to run inside a
+    score_multi_vector call.  A host that needs its CPU pools spread over both sockets sets COLPALI_AMD_NUMA=0 (no narrowing at all)
+    or runs one torch CPU op before the first scoring call; staging buffers are per GPU (corpus._PerDevice)."""
 
     def __init__(self, device):
         self.cpus = gpu_local_cpus(device) if torch.cuda.is_available() else None

@@ -18,6 +18,7 @@ import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Union
 
+import numpy as np
 import torch
 
 from . import _lib as _lib_mod
@@ -62,9 +63,19 @@ class PackedCorpus:
     clamp0: Optional[torch.Tensor]     # uint8 [n] on the GPU, or None
     lengths: torch.Tensor              # int64 [n], on the host
     id_base: int = 0                   # global id of passage 0 (sharded corpora)
+    avg_rows: Optional[int] = None     # average passage length (launch-shape hint); None: derived once from `lengths` and kept
 
     def __len__(self) -> int:
         return int(self.lengths.numel())
+
+    def average_rows(self) -> int:
+        """The launch-shape hint of include/maxsim.h (MSIM_FLAG_AVG_ROWS), computed ONCE per corpus and with numpy: a torch CPU
+        reduction here sat in every retrieval step and, above ~32k passages, woke torch's intra-op pool -- the cause of the 70-90 ms
+        cgroup-throttling stalls block_clamp0 was moved off torch for (round-5 advisor finding)."""
+        if self.avg_rows is None:
+            n = len(self)
+            self.avg_rows = int(self.lengths.numpy().sum(dtype=np.int64)) // n if n else 0
+        return self.avg_rows
 
     @property
     def device(self) -> torch.device:
@@ -93,14 +104,22 @@ def _widen(x: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(x, (0, width - x.shape[-1]))
 
 
-_COPY_THREADS = max(1, min(8, _lib_mod.effective_cpus() // 2))      # half of what the container grants, at most 8
-if os.environ.get("COLPALI_AMD_COPY_THREADS"):                      # tuning knob (tools/dropin_profile.py)
-    _COPY_THREADS = max(1, int(os.environ["COLPALI_AMD_COPY_THREADS"]))
-_EDGE_CHUNK_BYTES = int(os.environ.get("COLPALI_AMD_EDGE_CHUNK_MB", "16")) << 20     # first and last chunk of a pipelined upload (0: off)
+def _env_int(name: str, default: int, lo: int, hi: int) -> int:
+    """An integer tuning knob from the environment, clamped to [lo, hi]; a malformed value falls back to the default (importing the
+    package must never raise over a typo in a knob)."""
+    try:
+        return max(lo, min(hi, int(os.environ[name])))
+    except (KeyError, ValueError):
+        return default
+
+
+# half of what the container grants, at most 8; COLPALI_AMD_COPY_THREADS: tuning knob (tools/dropin_profile.py)
+_COPY_THREADS = _env_int("COLPALI_AMD_COPY_THREADS", max(1, min(8, _lib_mod.effective_cpus() // 2)), 1, 256)
+_EDGE_CHUNK_BYTES = _env_int("COLPALI_AMD_EDGE_CHUNK_MB", 16, 0, 1024) << 20     # first and last chunk of a pipelined upload (0: off)
 # pinned host memory per staging buffer = two halves that alternate: while one half is on its way to the GPU the passages of the
 # next chunk are memcpy'd into the other, so a call costs max(host memcpy, PCIe upload) instead of their sum -- 32 MiB per half
 # is large enough for both to run at full speed and small enough for a 264 MB corpus (1000 ColPali pages) to overlap almost fully
-STAGING_BYTES = int(os.environ.get("COLPALI_AMD_STAGING_MB", "64")) << 20
+STAGING_BYTES = _env_int("COLPALI_AMD_STAGING_MB", 64, 2, 16384) << 20
 
 
 class _Staging:
@@ -245,8 +264,32 @@ def _chunk_schedule(total: int, half: int):
     return list(zip(cuts[:-1], cuts[1:]))
 
 
-_staging = _Staging()
-_staging_q = _Staging()      # queries: a second buffer, so that packing the queries never waits for the corpus upload
+class _PerDevice:
+    """One staging buffer PER GPU: its pinned pages are first touched on that GPU's NUMA node (_halves), so in a process that drives
+    GPUs on both sockets every upload stages through memory next to its own GPU (round-5 advisor finding: one process-global buffer
+    stayed on the first GPU's socket)."""
+
+    def __init__(self):
+        self._by_dev = {}
+        self._lock = threading.Lock()
+
+    def of(self, device) -> _Staging:
+        idx = torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        with self._lock:
+            st = self._by_dev.get(idx)
+            if st is None:
+                st = self._by_dev[idx] = _Staging()
+            return st
+
+    # the single-GPU spelling (tools/, tests): the buffer of the current device
+    def upload(self, ps, dim, device, slot_rows=None):
+        return self.of(device).upload(ps, dim, device, slot_rows)
+
+
+_staging = _PerDevice()
+_staging_q = _PerDevice()    # queries: a second buffer, so that packing the queries never waits for the corpus upload
 _copy_streams = {}
 
 
@@ -425,7 +468,7 @@ def _flat_from_host_list(qs: Sequence[torch.Tensor], dim: int, device: torch.dev
     else:
         # through the bounded pinned halves of the queries' staging buffer (two halves, an event each: a query set of any size pins
         # STAGING_BYTES of host memory, never its own size -- round-4 advisor finding)
-        st = _staging_q
+        st = _staging_q.of(device)
         stream = torch.cuda.current_stream(device)
         dst_bytes = tokens.view(torch.uint8).view(-1)
         if not compact:

@@ -154,7 +154,7 @@ def maxsim_backward(qc: torch.Tensor, dc: torch.Tensor, offsets: torch.Tensor, g
     B, C = qc.shape[0], dc.shape[0]
     dev = qc.device
     if B * C == 0:
-        return (torch.zeros(qc.shape, dtype=torch.float32, device=dev), torch.zeros(dc.shape, dtype=torch.float32, device=dev))
+        return (torch.zeros(qc.shape, dtype=qc.dtype, device=dev), torch.zeros(dc.shape, dtype=dc.dtype, device=dev))
     pairs = _all_pairs(B, C, dev)
     if argmax_all is None:
         _, argmax_all = maxsim_all_pairs(qc, dc, offsets, want_scores=False)

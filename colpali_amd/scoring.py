@@ -166,7 +166,7 @@ def maxsim_scores(queries: Union[torch.Tensor, PackedQueries], corpus: PackedCor
         raise ValueError("out must be fp32 [n_q, n] with unit inner stride")
     flags = _lib.MSIM_FLAG_REF_ROUNDING if ref_rounding else 0
     if n:       # launch-shape hint (include/maxsim.h: MSIM_FLAG_AVG_ROWS): the average document length, which the host side knows
-        flags |= min(65535, max(1, int(corpus.lengths.sum()) // n)) << 8
+        flags |= min(65535, max(1, corpus.average_rows())) << 8
     ld = out.stride(0) if n_q > 1 else max(n, 1)
     if flat:
         with torch.cuda.device(queries.device):
@@ -297,6 +297,7 @@ def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_ro
     side = copy_stream(dev)
     with torch.cuda.device(dev):
         blob = torch.empty((total_rows, dim), dtype=dtype, device=dev)
+        blob.record_stream(side)   # written on the copy stream: whatever happens below, its memory is not reused before that stream is done
         off_host = torch.zeros(n + 1, dtype=torch.int32)
         off_host[1:] = torch.from_numpy((prefix[1:] // row_bytes).astype(np.int32))
         offsets = off_host.to(dev, non_blocking=True)
@@ -319,15 +320,14 @@ def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_ro
                     # the WHOLE blob with the sub-range's slice of the absolute row offsets: nothing is re-based, the kernels only touch
                     # rows of passages lo .. hi-1, which have arrived
                     part = PackedCorpus(blob=blob, offsets=offsets[lo:hi + 1], clamp0=None if clamp0 is None else clamp0[lo:hi],
-                                        lengths=lengths[lo:hi])
+                                        lengths=lengths[lo:hi], avg_rows=max(1, int(rows[lo:hi].sum()) // (hi - lo)))
                     maxsim_scores(q, part, ref_rounding=ref_rounding, out=out[:, lo:hi])
                 state[0] = hi
                 state[1] += 1
 
-        _staging.upload_image(srcs, prefix, n, blob.view(torch.uint8).view(-1), side, on_chunk=score_arrived)
+        _staging.of(dev).upload_image(srcs, prefix, n, blob.view(torch.uint8).view(-1), side, on_chunk=score_arrived)
         _stamp("issued")
         scores = out.cpu()
-        blob.record_stream(side)                       # written on the copy stream: its memory is not reused before that stream is done
         _stamp("done")
     del keep
     return scores
