@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 def dtype_code(dtype) -> int:
@@ -102,6 +102,16 @@ def lib() -> ctypes.CDLL:
     L.msim_host_gather_nonzero_rows.restype = i32
     L.msim_fwd_transposed.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, vp, i64, vp, vp]
     L.msim_fwd_transposed.restype = i32
+    L.msim_dense_t_supported.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.msim_dense_t_supported.restype = i32
+    L.msim_dense_t_route_bytes.argtypes = [i32, i32, i32]
+    L.msim_dense_t_route_bytes.restype = sz
+    L.msim_fwd_transposed_route.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, vp, i64, vp, vp, vp]
+    L.msim_fwd_transposed_route.restype = i32
+    L.msim_dense_t_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.msim_dense_t_bwd_workspace_bytes.restype = sz
+    L.msim_dense_t_bwd.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, vp, i64, vp, i32, vp, vp, vp, vp, vp]
+    L.msim_dense_t_bwd.restype = i32
     L.msim_host_gather_range.argtypes = [vp, vp, vp, i64, i64, i64, i32]
     L.msim_host_gather_range.restype = i32
     L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]

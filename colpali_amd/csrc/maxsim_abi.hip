@@ -16,6 +16,7 @@
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
 #include "maxsim_batch_t.hip"
+#include "maxsim_dense_t.hip"
 #include "maxsim_pairs.hip"
 #include "maxsim_generic.hip"
 #include "maxsim_bwd.hip"
@@ -1312,10 +1313,10 @@ int msim_fwd(int dtype, const void *Q, int n_q, int Lq, const void *D, const int
 }  // extern "C"
 
 namespace {
-template <bool F16, int U, int DPW>
-int launch_batch_t(const uint16_t *Q, const uint16_t *D, float *scores, int32_t *q_lengths, msim::BatchTArgs a, const DeviceInfo &di,
-                   hipStream_t st) {
-    auto kern = msim::maxsim_batch_t_kernel<F16, U, DPW>;
+template <bool F16, int U, int DPW, bool ROUTE>
+int launch_batch_t(const uint16_t *Q, const uint16_t *D, float *scores, int32_t *q_lengths, uint8_t *route, msim::BatchTArgs a,
+                   const DeviceInfo &di, hipStream_t st) {
+    auto kern = msim::maxsim_batch_t_kernel<F16, U, DPW, ROUTE>;
     constexpr int lds = 3 * 4 * msim::kSlabBytes;                  // 96 KiB ring
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -1326,33 +1327,38 @@ int launch_batch_t(const uint16_t *Q, const uint16_t *D, float *scores, int32_t 
     if (slots_p > cap) slots_p = cap < 1 ? 1 : cap;
     a.slots_p = slots_p;
     a.n_slots = slots_p * a.n_blocks;
-    hipLaunchKernelGGL(kern, dim3(8 * a.n_slots), dim3(512), lds, st, Q, D, scores, q_lengths, a);
+    hipLaunchKernelGGL(kern, dim3(8 * a.n_slots), dim3(512), lds, st, Q, D, scores, q_lengths, route, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_t_kernel<%d,%d> launch: %s", U, DPW, hipGetErrorString(e));
     return MSIM_OK;
 }
 
 template <bool F16>
-int batch_t_dispatch(int units, const uint16_t *Q, const uint16_t *D, float *scores, int32_t *ql, const msim::BatchTArgs &a,
-                     const DeviceInfo &di, hipStream_t st) {
-    if (units <= 1) return launch_batch_t<F16, 1, 8>(Q, D, scores, ql, a, di, st);
-    if (units == 2) return launch_batch_t<F16, 2, 4>(Q, D, scores, ql, a, di, st);
-    if (units == 3) return launch_batch_t<F16, 3, 2>(Q, D, scores, ql, a, di, st);
-    if (units == 4) return launch_batch_t<F16, 4, 2>(Q, D, scores, ql, a, di, st);
-    return launch_batch_t<F16, 8, 1>(Q, D, scores, ql, a, di, st);
+int batch_t_dispatch(int units, const uint16_t *Q, const uint16_t *D, float *scores, int32_t *ql, uint8_t *route,
+                     const msim::BatchTArgs &a, const DeviceInfo &di, hipStream_t st) {
+    if (route) {        // with the routing bytes of the dense backward (documents of at most 64 rows)
+        if (units <= 1) return launch_batch_t<F16, 1, 8, true>(Q, D, scores, ql, route, a, di, st);
+        if (units == 2) return launch_batch_t<F16, 2, 4, true>(Q, D, scores, ql, route, a, di, st);
+        if (units == 3) return launch_batch_t<F16, 3, 2, true>(Q, D, scores, ql, route, a, di, st);
+        return launch_batch_t<F16, 4, 2, true>(Q, D, scores, ql, route, a, di, st);
+    }
+    if (units <= 1) return launch_batch_t<F16, 1, 8, false>(Q, D, scores, ql, nullptr, a, di, st);
+    if (units == 2) return launch_batch_t<F16, 2, 4, false>(Q, D, scores, ql, nullptr, a, di, st);
+    if (units == 3) return launch_batch_t<F16, 3, 2, false>(Q, D, scores, ql, nullptr, a, di, st);
+    if (units == 4) return launch_batch_t<F16, 4, 2, false>(Q, D, scores, ql, nullptr, a, di, st);
+    return launch_batch_t<F16, 8, 1, false>(Q, D, scores, ql, nullptr, a, di, st);
 }
-}  // namespace
 
-extern "C" {
-
-int msim_fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim, float *scores,
-                        int64_t ld_scores, int32_t *q_lengths, void *stream) {
+int fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim, float *scores,
+                   int64_t ld_scores, int32_t *q_lengths, uint8_t *route, void *stream) {
     if (n_q < 0 || n_d < 0 || Lq <= 0 || Ld <= 0) return fail(MSIM_EINVAL, "negative or empty size");
     if (n_q == 0 || n_d == 0) return MSIM_OK;
     if (!Q || !D || !scores) return fail(MSIM_EINVAL, "null pointer argument");
     if ((dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16) || dim != msim::kDim)
         return fail(MSIM_EUNSUPPORTED, "msim_fwd_transposed takes bf16 / f16 embeddings of width %d", msim::kDim);
     if (Ld > 8 * msim::kUnitTok) return fail(MSIM_EUNSUPPORTED, "resident documents of at most %d rows (got %d)", 8 * msim::kUnitTok, Ld);
+    if (route && Ld > msim::kDenseTMaxLd)
+        return fail(MSIM_EUNSUPPORTED, "the routing is kept for resident documents of at most %d rows (got %d)", msim::kDenseTMaxLd, Ld);
     if ((long long)Lq * msim::kRowBytes >= (1ll << 31)) return fail(MSIM_EUNSUPPORTED, "queries of %d rows", Lq);
     if (ld_scores < n_d) return fail(MSIM_EINVAL, "ld_scores < n_d");
     if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D)) & 15) return fail(MSIM_EINVAL, "embeddings must be 16-byte aligned");
@@ -1364,11 +1370,168 @@ int msim_fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D
     a.Lq = Lq;
     a.n_d = n_d;
     a.Ld = Ld;
+    a.Lq_pad = msim::dense_t_lq_pad(Lq);
     const int units = (Ld + msim::kUnitTok - 1) / msim::kUnitTok;
     const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return dtype == MSIM_DTYPE_F16 ? batch_t_dispatch<true>(units, q, d, scores, q_lengths, a, *di, st)
-                                   : batch_t_dispatch<false>(units, q, d, scores, q_lengths, a, *di, st);
+    return dtype == MSIM_DTYPE_F16 ? batch_t_dispatch<true>(units, q, d, scores, q_lengths, route, a, *di, st)
+                                   : batch_t_dispatch<false>(units, q, d, scores, q_lengths, route, a, *di, st);
+}
+
+// ---- the dense hard-max backward of the transposed shape (maxsim_dense_t.hip)
+constexpr int kDenseTMaxDocs = 4096;        // dP keeps one weight pair per document of the page in LDS
+constexpr int kDenseTMaxPagesPer = 256;     // dR keeps one weight pair per (page of its split, document of the workgroup) in LDS
+struct DenseTPlan {
+    size_t rimg, pimg, partial, bytes;   // byte offsets of the two operand images and the page-split partials; total
+    int ks, nsb, nc, n_split, pages_per, doc_groups;
+};
+static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+DenseTPlan dense_t_plan(int n_q, int Lq, int n_d, int Ld, int cus) {
+    DenseTPlan p{};
+    p.ks = (Ld + 31) / 32;
+    p.nsb = Ld <= 16 ? 1 : Ld <= 32 ? 2 : 4;     // 16-row blocks per document: NSB * NC = 4 combinations per wave pair
+    p.nc = 4 / p.nsb;
+    p.doc_groups = (n_d + 4 * p.nc - 1) / (4 * p.nc);
+    int split = (cus + p.doc_groups - 1) / (p.doc_groups > 0 ? p.doc_groups : 1);
+    const int min_split = (n_q + kDenseTMaxPagesPer - 1) / kDenseTMaxPagesPer;
+    split = split < min_split ? min_split : split;
+    split = split < 1 ? 1 : split > n_q ? n_q : split;
+    p.pages_per = split > 0 ? (n_q + split - 1) / split : 1;
+    p.n_split = p.pages_per > 0 ? (n_q + p.pages_per - 1) / p.pages_per : 0;
+    const size_t ksp = msim::dense_t_lq_pad(Lq) / 32;
+    p.rimg = 0;
+    p.pimg = up16((size_t)n_d * p.ks * msim::kKStepBytes);
+    p.partial = p.pimg + up16((size_t)n_q * ksp * msim::kKStepBytes);
+    p.bytes = p.partial + up16((size_t)p.n_split * n_d * Ld * msim::kDim * sizeof(float));
+    return p;
+}
+bool dense_t_supported(int dtype, int n_q, int Lq, int n_d, int Ld, int dim) {
+    if ((dtype != MSIM_DTYPE_BF16 && dtype != MSIM_DTYPE_F16) || dim != msim::kDim) return false;
+    if (Ld <= 0 || Ld > msim::kDenseTMaxLd || Lq <= 0 || n_q <= 0 || n_d <= 0 || n_d > kDenseTMaxDocs) return false;
+    const long long lq_pad = msim::dense_t_lq_pad(Lq);
+    return (long long)n_q * lq_pad * msim::kRowBytes < (1ll << 31) && (long long)n_q * n_d * lq_pad < (1ll << 31) &&
+           (long long)n_d * 64 * msim::kRowBytes < (1ll << 31);
+}
+
+template <bool F16>
+int dense_t_bwd_launch(const uint16_t *Q, const uint16_t *D, const float *G, msim::GScale gs, const uint8_t *route, uint16_t *dQ,
+                       uint16_t *dD, char *ws, const DenseTPlan &pl, msim::DenseTArgs a, hipStream_t st) {
+    uint16_t *rimg = reinterpret_cast<uint16_t *>(ws + pl.rimg), *pimg = reinterpret_cast<uint16_t *>(ws + pl.pimg);
+    float *partial = reinterpret_cast<float *>(ws + pl.partial);
+    hipLaunchKernelGGL(msim::dense_t_image_kernel, dim3(a.n_d * pl.ks), dim3(256), 0, st, D, rimg, a.n_d, a.Ld, pl.ks);
+    hipLaunchKernelGGL(msim::dense_t_image_kernel, dim3(a.n_q * a.ksp), dim3(256), 0, st, Q, pimg, a.n_q, a.Lq, a.ksp);
+    static std::atomic<int> conf_long[2][kMaxDevices], conf_short[4][kMaxDevices];
+    // LDS: the 3-stage operand ring + the routing bytes + the weight pairs (dP: one per document of the page, padded to whole stages;
+    // dR: one per (page of the split, document of the workgroup)); the attribute is raised once to what dense_t_supported admits
+    constexpr int kLongRing = msim::kDenseTLongRing, kShortRing = msim::kDenseTShortRing;
+    constexpr int kLongStage = msim::kDenseTLongSteps * (8192 + 128 + 144);      // image + routing bytes + W patterns (KS = 1: one document per step)
+    constexpr int lds_long_max = kLongRing * kLongStage + 4 * (kDenseTMaxDocs + 4), lds_short_max = kShortRing * (16384 + 1024) + 4 * 16 * kDenseTMaxPagesPer;
+    const int lds_long = kLongRing * kLongStage + 4 * ((a.n_d + 3) / 4 * 4 + 4);
+    const int lds_short = kShortRing * (16384 + 1024) + 4 * 16 * pl.pages_per;
+    const dim3 grid_long((a.Lq + 127) / 128, a.n_q);
+    if (pl.ks == 1) {
+        auto k = msim::dense_t_bwd_long_kernel<F16, 1>;
+        if (int rc = allow_lds(k, lds_long_max, conf_long[0])) return rc;
+        hipLaunchKernelGGL(k, grid_long, dim3(512), lds_long, st, rimg, route, G, gs, dQ, a);
+    } else {
+        auto k = msim::dense_t_bwd_long_kernel<F16, 2>;
+        if (int rc = allow_lds(k, lds_long_max, conf_long[1])) return rc;
+        hipLaunchKernelGGL(k, grid_long, dim3(512), lds_long, st, rimg, route, G, gs, dQ, a);
+    }
+    const dim3 grid_short(pl.doc_groups, pl.n_split);
+#define MSIM_SHORT(NSB, NC, SLOT)                                                                         \
+    {                                                                                                     \
+        auto k = msim::dense_t_bwd_short_kernel<F16, NSB, NC>;                                            \
+        if (int rc = allow_lds(k, lds_short_max, conf_short[SLOT])) return rc;                                \
+        hipLaunchKernelGGL(k, grid_short, dim3(512), lds_short, st, pimg, route, G, gs, partial, a);      \
+    }
+    if (pl.nsb <= 1) MSIM_SHORT(1, 4, 0)
+    else if (pl.nsb == 2) MSIM_SHORT(2, 2, 1)
+    else MSIM_SHORT(4, 1, 2)
+#undef MSIM_SHORT
+    const long long n_elems = (long long)a.n_d * a.Ld * msim::kDim;
+    hipLaunchKernelGGL(msim::dense_t_bwd_short_sum_kernel<F16>, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, st, partial, dD,
+                       n_elems, pl.n_split);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "msim_dense_t_bwd launch: %s", hipGetErrorString(e));
+    return MSIM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int msim_fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim, float *scores,
+                        int64_t ld_scores, int32_t *q_lengths, void *stream) {
+    return fwd_transposed(dtype, Q, n_q, Lq, D, n_d, Ld, dim, scores, ld_scores, q_lengths, nullptr, stream);
+}
+
+size_t msim_dense_t_route_bytes(int n_q, int Lq, int n_d) {
+    if (n_q <= 0 || Lq <= 0 || n_d <= 0) return 0;
+    return (size_t)n_q * n_d * msim::dense_t_lq_pad(Lq);
+}
+
+int msim_dense_t_supported(int dtype, int n_q, int Lq, int n_d, int Ld, int dim) {
+    return dense_t_supported(dtype, n_q, Lq, n_d, Ld, dim) ? 1 : 0;
+}
+
+int msim_fwd_transposed_route(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim, float *scores,
+                              int64_t ld_scores, int32_t *q_lengths, uint8_t *route, void *stream) {
+    if (!route) return fail(MSIM_EINVAL, "null routing buffer");
+    if (n_q > 0 && n_d > 0 && !dense_t_supported(dtype, n_q, Lq, n_d, Ld, dim))
+        return fail(MSIM_EUNSUPPORTED, "msim_fwd_transposed_route: bf16 / f16, width %d, documents of at most %d rows, sizes below 2^31 bytes",
+                    msim::kDim, msim::kDenseTMaxLd);
+    return fwd_transposed(dtype, Q, n_q, Lq, D, n_d, Ld, dim, scores, ld_scores, q_lengths, route, stream);
+}
+
+size_t msim_dense_t_bwd_workspace_bytes(int n_q, int Lq, int n_d, int Ld, int dim) {
+    (void)dim;
+    if (n_q <= 0 || n_d <= 0 || Lq <= 0 || Ld <= 0) return 0;
+    const DeviceInfo *di = nullptr;
+    const int cus = device_info(&di) == MSIM_OK ? di->cus : 256;            // the plan only has to be the same in both calls
+    return dense_t_plan(n_q, Lq, n_d, Ld, cus).bytes;
+}
+
+int msim_dense_t_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim, const float *G, int64_t ldg,
+                     const void *g_scale, int g_scale_dtype, const uint8_t *route, void *dQ, void *dD, void *workspace, void *stream) {
+    if (n_q < 0 || n_d < 0 || Lq <= 0 || Ld <= 0) return fail(MSIM_EINVAL, "negative or empty size");
+    if (n_q == 0 || n_d == 0) return MSIM_OK;
+    if (!Q || !D || !G || !route || !dQ || !dD || !workspace) return fail(MSIM_EINVAL, "null pointer argument");
+    if (!dense_t_supported(dtype, n_q, Lq, n_d, Ld, dim))
+        return fail(MSIM_EUNSUPPORTED, "msim_dense_t_bwd: bf16 / f16, width %d, documents of at most %d rows, sizes below 2^31 bytes",
+                    msim::kDim, msim::kDenseTMaxLd);
+    if (ldg < n_d) return fail(MSIM_EINVAL, "ldg < n_d");
+    if (g_scale && g_scale_dtype != MSIM_DTYPE_BF16 && g_scale_dtype != MSIM_DTYPE_F16 && g_scale_dtype != MSIM_DTYPE_F32)
+        return fail(MSIM_EINVAL, "g_scale dtype code %d", g_scale_dtype);
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(dQ) | reinterpret_cast<uintptr_t>(dD) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return fail(MSIM_EINVAL, "embeddings, gradients and workspace must be 16-byte aligned");
+    const DeviceInfo *di = nullptr;
+    if (int rc = device_info(&di)) return rc;
+    const DenseTPlan pl = dense_t_plan(n_q, Lq, n_d, Ld, di->cus);
+    msim::DenseTArgs a{};
+    a.ldg = ldg;
+    a.n_q = n_q;
+    a.Lq = Lq;
+    a.n_d = n_d;
+    a.Ld = Ld;
+    a.Lq_pad = msim::dense_t_lq_pad(Lq);
+    a.ksp = a.Lq_pad / 32;
+    a.n_split = pl.n_split;
+    a.pages_per = pl.pages_per;
+    if (msim::kAbBuild) {
+        const char *e = getenv("MSIM_DENSE_T_DBG");
+        a.dbg = e ? atoi(e) : 0;
+        const char *o = getenv("MSIM_DENSE_T_DBG_OUT");
+        a.dbg_out = o ? reinterpret_cast<unsigned long long *>(strtoull(o, nullptr, 0)) : nullptr;
+    }
+    const msim::GScale gs{g_scale, g_scale_dtype};
+    const uint16_t *q = static_cast<const uint16_t *>(Q), *d = static_cast<const uint16_t *>(D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == MSIM_DTYPE_F16
+               ? dense_t_bwd_launch<true>(q, d, G, gs, route, static_cast<uint16_t *>(dQ), static_cast<uint16_t *>(dD),
+                                          static_cast<char *>(workspace), pl, a, st)
+               : dense_t_bwd_launch<false>(q, d, G, gs, route, static_cast<uint16_t *>(dQ), static_cast<uint16_t *>(dD),
+                                           static_cast<char *>(workspace), pl, a, st);
 }
 
 // ---------------------------------------------------------------- pair lists (training losses)

@@ -35,13 +35,20 @@ struct BatchTArgs {
     int n_blocks;       // document blocks of 8 * DPW documents
     int n_slots;        // page slots per XCD: the workgroup of (xcd, slot) walks pages xcd + 8 * (slot / n_blocks), then += 8 * slots_p
     int slots_p;        // page slots per XCD = n_slots / n_blocks
+    int Lq_pad;         // ROUTE: bytes per (page, document) of the routing = Lq rounded up to 32
 };
 
 // U   : 16-row units per resident document (Ld <= 16 * U)
 // DPW : documents per wave (U * DPW <= 8 units = 128 operand registers)
-template <bool F16, int U, int DPW>
+// ROUTE (round 6): also write the ROUTING of every (page, document, page row) -- the resident row that won the max, one byte,
+//   route[(page * n_d + doc) * Lq_pad + row], Lq_pad = Lq rounded up to 64, bytes of rows in [Lq, Lq_pad) unspecified -- for the dense
+//   hard-max backward on the matrix cores (maxsim_dense_t.hip: ColbertLoss / ColbertSigmoidLoss in the trainer's symmetric direction,
+//   late_interaction_losses.py:140-164, contrastive_trainer.py:202-206).  The first maximal row wins a tie (maxsim_pairs.hip's rule);
+//   the scores are bit-identical to the ROUTE = false form (the same MFMAs, the max taken as compare-and-select instead of max3).
+template <bool F16, int U, int DPW, bool ROUTE = false>
 __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
-                                                                float *__restrict__ scores, int32_t *__restrict__ q_lengths, BatchTArgs a) {
+                                                                float *__restrict__ scores, int32_t *__restrict__ q_lengths,
+                                                                uint8_t *__restrict__ route, BatchTArgs a) {
     static_assert(U * DPW <= 8 && U >= 1 && DPW >= 1, "a wave holds at most 8 units");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 8;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
         for (int d = 0; d < DPW; ++d) sum[d] = 0.0f;
         int n_real = 0;
 
-        auto slab = [&](int src_lds, auto tail, int rows_left) {
+        auto slab = [&](int src_lds, auto tail, int rows_left, int row0) {
             constexpr bool kTail = decltype(tail)::value;
             bf16x8 af[2][kKSteps16];
 #pragma unroll
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
 #pragma unroll
             for (int d = 0; d < DPW; ++d) {
                 float m0 = -INFINITY, m1 = -INFINITY;
+                int i0 = 0, i1 = 0;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -152,25 +160,62 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
                             if (u * kUnitTok + r >= row_lim) { acc0[r] = -INFINITY; acc1[r] = -INFINITY; }
                         }
                     }
-                    m0 = max3(m0, acc0[0], acc0[1]);
-                    m0 = max3(m0, acc0[2], acc0[3]);
-                    m1 = max3(m1, acc1[0], acc1[1]);
-                    m1 = max3(m1, acc1[2], acc1[3]);
+                    if constexpr (ROUTE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {                    // rows in ascending order, strict >: the first maximum stays
+                            const bool g0 = acc0[r] > m0, g1 = acc1[r] > m1;
+                            m0 = g0 ? acc0[r] : m0;
+                            i0 = g0 ? u * kUnitTok + r : i0;
+                            m1 = g1 ? acc1[r] : m1;
+                            i1 = g1 ? u * kUnitTok + r : i1;
+                        }
+                    } else {
+                        m0 = max3(m0, acc0[0], acc0[1]);
+                        m0 = max3(m0, acc0[2], acc0[3]);
+                        m1 = max3(m1, acc1[0], acc1[1]);
+                        m1 = max3(m1, acc1[2], acc1[3]);
+                    }
                 }
-                x[d][0] = m0;
-                x[d][1] = m1;
+                if constexpr (ROUTE) {
+                    // the exchange at once (nothing is kept across documents: the routing costs registers the plain form spends on
+                    // hiding the exchange behind the next document's MFMAs): (max, lowest row) over the four lane groups
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        float v = g == 0 ? m0 : m1;
+                        int vi = (g == 0 ? i0 : i1) + 4 * l4;
+#pragma unroll
+                        for (int m = 16; m <= 32; m <<= 1) {
+                            const float o = __shfl_xor(v, m);
+                            const int oi = __shfl_xor(vi, m);
+                            const bool take = o > v || (o == v && oi < vi);
+                            v = take ? o : v;
+                            vi = take ? oi : vi;
+                        }
+                        // lane group d & 3 stores document d's byte of page row row0 + 16 g + l16 (16 consecutive bytes per group)
+                        const int row = row0 + 16 * g + l16;
+                        if (l4 == (d & 3) && doc0 + d < a.n_d && row < a.Lq_pad)
+                            route[((size_t)page * a.n_d + doc0 + d) * a.Lq_pad + row] = row < a.Lq ? (uint8_t)vi : (uint8_t)255;
+                        if constexpr (kTail) v = (16 * g + l16 < rows_left) ? v : 0.0f;
+                        sum[d] += v;
+                    }
+                } else {
+                    x[d][0] = m0;
+                    x[d][1] = m1;
+                }
             }
             // one exchange across the four lane groups per (document, 16 page rows), behind all of the slab's MFMAs
+            if constexpr (!ROUTE) {
 #pragma unroll
-            for (int d = 0; d < DPW; ++d)
+                for (int d = 0; d < DPW; ++d)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    float v = x[d][g];
-                    v = fmaxf(v, __shfl_xor(v, 16));
-                    v = fmaxf(v, __shfl_xor(v, 32));
-                    if constexpr (kTail) v = (16 * g + l16 < rows_left) ? v : 0.0f;   // page rows that do not exist add nothing
-                    sum[d] += v;
-                }
+                    for (int g = 0; g < 2; ++g) {
+                        float v = x[d][g];
+                        v = fmaxf(v, __shfl_xor(v, 16));
+                        v = fmaxf(v, __shfl_xor(v, 32));
+                        if constexpr (kTail) v = (16 * g + l16 < rows_left) ? v : 0.0f;   // page rows that do not exist add nothing
+                        sum[d] += v;
+                    }
+            }
         };
 
         for (int ch = 0; ch < nchunk; ++ch) {
@@ -182,9 +227,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
             const int rows_in_chunk = a.Lq - ch * kCRows;
             const int n_full = rows_in_chunk >= kCRows ? kCSlabs : rows_in_chunk / kSlabRows;
 #pragma unroll 1
-            for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows);
+            for (int sl = 0; sl < n_full; ++sl) slab(cbuf + sl * kSlabBytes, std::false_type{}, kSlabRows, ch * kCRows + sl * kSlabRows);
             const int rem = rows_in_chunk - n_full * kSlabRows;
-            if (n_full < kCSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem);
+            if (n_full < kCSlabs && rem > 0) slab(cbuf + n_full * kSlabBytes, std::true_type{}, rem, ch * kCRows + n_full * kSlabRows);
         }
         // ---- page done: fold the 16 page-row lanes (every lane group holds the same sums), one store per document
 #pragma unroll

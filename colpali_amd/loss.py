@@ -74,6 +74,54 @@ def _box_scores(qc: torch.Tensor, dc: torch.Tensor, corpus: PackedCorpus, want_l
     return (scores, None) if want_lengths else scores
 
 
+def _dense_t_ok(qc: torch.Tensor, dc: torch.Tensor) -> bool:
+    """Long queries against short documents with a gradient on EVERY pair (ColbertLoss / ColbertSigmoidLoss in the trainer's symmetric
+    direction, trainer/contrastive_trainer.py:202-206): the shape whose backward runs as two GEMMs on the matrix cores
+    (msim_dense_t_bwd) instead of 1.6 GB of gathers.  bf16 / f16, width 128, documents of at most 64 rows."""
+    B, Lq, width = qc.shape
+    C, Ld, _ = dc.shape
+    if not (qc.dtype in (torch.bfloat16, torch.float16) and width == 128 and Lq > 128 and 0 < Ld <= 64 and B > 0 and C > 0):
+        return False
+    return bool(_lib.lib().msim_dense_t_supported(_lib.dtype_code(qc.dtype), B, Lq, C, Ld, width))
+
+
+def _dense_t_forward(qc: torch.Tensor, dc: torch.Tensor, want_lengths: bool = False):
+    """(scores fp32 [B, C], int32 [B] token counts or None, routing uint8 [B, C, Lq_pad]): msim_fwd_transposed_route."""
+    L = _lib.lib()
+    B, Lq, width = qc.shape
+    C, Ld, _ = dc.shape
+    dev = qc.device
+    scores = torch.empty((B, C), dtype=torch.float32, device=dev)
+    lengths = torch.empty((B,), dtype=torch.int32, device=dev) if want_lengths else None
+    route = torch.empty((L.msim_dense_t_route_bytes(B, Lq, C),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.msim_fwd_transposed_route(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), C, Ld, width, _lib.ptr(scores), C,
+                                         _lib.ptr(lengths), _lib.ptr(route), _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_fwd_transposed_route")
+    return scores, lengths, route
+
+
+def _dense_t_backward(qc: torch.Tensor, dc: torch.Tensor, G: torch.Tensor, route: torch.Tensor, g_scale=None):
+    """(dQ, dD) in the embeddings' dtype for dense dLoss/dscores G fp32 [B, C] and the forward's routing: msim_dense_t_bwd."""
+    L = _lib.lib()
+    B, Lq, width = qc.shape
+    C, Ld, _ = dc.shape
+    dev = qc.device
+    G = G.to(torch.float32)
+    if G.stride(-1) != 1 or (B > 1 and G.stride(0) < C):
+        G = G.contiguous()
+    dq = torch.empty_like(qc)
+    dd = torch.empty_like(dc)
+    gs, gs_code = _scale_arg(g_scale)
+    with torch.cuda.device(dev):
+        ws = torch.empty((L.msim_dense_t_bwd_workspace_bytes(B, Lq, C, Ld, width),), dtype=torch.uint8, device=dev)
+        rc = L.msim_dense_t_bwd(_lib.dtype_code(qc.dtype), _lib.ptr(qc), B, Lq, _lib.ptr(dc), C, Ld, width, _lib.ptr(G),
+                                G.stride(0) if B > 1 else C, _lib.ptr(gs), gs_code, _lib.ptr(route), _lib.ptr(dq), _lib.ptr(dd), _lib.ptr(ws),
+                                _lib.current_stream_handle(dev))
+    _lib.check(rc, "msim_dense_t_bwd")
+    return dq, dd
+
+
 class _MaxSim(torch.autograd.Function):
     """scores[b, c] = sum_n max_s <Q[b,n], D[c,s]> with a recompute backward.
 
@@ -86,7 +134,13 @@ class _MaxSim(torch.autograd.Function):
         qc, dc = q.contiguous(), d.contiguous()
         corpus = _dense_corpus(dc)
         B, C = qc.shape[0], dc.shape[0]
+        ctx.dense_t = False
         if dense_grad and any(ctx.needs_input_grad[:2]) and B * C > 0:
+            if _dense_t_ok(qc, dc):         # long queries x short documents: byte routing now, two GEMMs when the gradient arrives
+                scores, _, route = _dense_t_forward(qc, dc)
+                ctx.dense_t = True
+                ctx.save_for_backward(qc, dc, corpus.offsets, route)
+                return scores
             scores = torch.empty((B, C), dtype=torch.float32, device=qc.device)   # returned as is (not a view: callers modify it in place)
             _, argmax = maxsim_all_pairs(qc, dc, corpus.offsets, scores_out=scores)
             ctx.save_for_backward(qc, dc, corpus.offsets, argmax)
@@ -98,6 +152,9 @@ class _MaxSim(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_scores: torch.Tensor):
         qc, dc, offsets, argmax = ctx.saved_tensors
+        if ctx.dense_t:
+            dq, dd = _dense_t_backward(qc, dc, grad_scores, argmax)
+            return (dq if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None)
         dq, dd = maxsim_backward(qc, dc, offsets, grad_scores, argmax_all=argmax)
         return (dq if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None)
 
@@ -418,7 +475,12 @@ class _FusedInBatchLoss(torch.autograd.Function):
         dev = qc.device
         need_grad = any(ctx.needs_input_grad[:2])
         aux = q_lengths = None                      # InfoNCE + gradients: [B*C, Lq] routing (hard max) or logsumexp (smooth max)
-        if mode == MODE_INFONCE and need_grad:
+        ctx.dense_t = False
+        if mode == MODE_INFONCE and need_grad and not smooth and B * C > 0 and _dense_t_ok(qc, dc):
+            # the trainer's symmetric direction: byte routing from the transposed kernel (and the token counts, as for the pairwise loss)
+            scores, q_lengths, aux = _dense_t_forward(qc, dc, want_lengths=True)
+            ctx.dense_t = True
+        elif mode == MODE_INFONCE and need_grad:
             scores = torch.empty((B, C), dtype=torch.float32, device=dev)
             if smooth:
                 _, aux = smooth_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, dev), tau, scores_out=scores)
@@ -469,12 +531,15 @@ class _FusedInBatchLoss(torch.autograd.Function):
                 _, argmax = maxsim_pairs(qc, dc, offsets, pairs, want_scores=False)
                 dq, dd = _pairs_backward(qc, dc, offsets, pairs, order, coef, argmax, g_scale=grad_loss)
         else:
-            all_pairs, all_order = _all_pairs(B, C, qc.device), _all_pairs_order(B, C, qc.device)
-            if ctx.smooth:
-                gp = (G * grad_loss.to(torch.float32)).reshape(-1)
-                dq, dd = _smooth_backward(qc, dc, offsets, all_pairs, gp, ctx.tau, lse=aux, order=all_order)
+            if ctx.dense_t:
+                dq, dd = _dense_t_backward(qc, dc, G, aux, g_scale=grad_loss)
             else:
-                dq, dd = _pairs_backward(qc, dc, offsets, all_pairs, all_order, G.reshape(-1), aux, g_scale=grad_loss)
+                all_pairs, all_order = _all_pairs(B, C, qc.device), _all_pairs_order(B, C, qc.device)
+                if ctx.smooth:
+                    gp = (G * grad_loss.to(torch.float32)).reshape(-1)
+                    dq, dd = _smooth_backward(qc, dc, offsets, all_pairs, gp, ctx.tau, lse=aux, order=all_order)
+                else:
+                    dq, dd = _pairs_backward(qc, dc, offsets, all_pairs, all_order, G.reshape(-1), aux, g_scale=grad_loss)
         return (dq.to(qc.dtype) if ctx.needs_input_grad[0] else None,
                 dd.to(dc.dtype) if ctx.needs_input_grad[1] else None) + (None,) * 10
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 18
+#define MSIM_ABI_VERSION 19
 
 /* error codes */
 #define MSIM_OK 0
@@ -177,6 +177,32 @@ int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32
  */
 int msim_fwd_transposed(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim,
                         float *scores, int64_t ld_scores, int32_t *q_lengths, void *stream);
+
+/*
+ * The DENSE hard-max backward of that shape on the matrix cores (round 6; maxsim_dense_t.hip) -- what autograd derives for
+ * late_interaction_losses.py:297-298 when EVERY (query, document) pair carries a gradient: ColbertLoss (:140-164, the trainer's
+ * default loss, trainer/colmodel_training.py:33) and ColbertSigmoidLoss (:440-465) in the trainer's symmetric direction
+ * (trainer/contrastive_trainer.py:202-206).  bf16 | f16, width 128, documents of at most 64 rows (msim_dense_t_supported; every
+ * other shape keeps msim_pairs_bwd).
+ *   msim_fwd_transposed_route   msim_fwd_transposed (bit-identical scores) that also leaves the ROUTING: route uint8
+ *                               [n_q, n_d, Lq_pad] (Lq_pad = Lq rounded up to 64; msim_dense_t_route_bytes), route[q, c, i] = the row of
+ *                               document c that won the max for row i of query q (the first maximal row on a tie); bytes of rows i >= Lq are unspecified
+ *                               (they never reach a result: those rows of the query image are zero and no gradient is stored for them).
+ *   msim_dense_t_bwd            dQ[q, i, :] = sum_c G[q, c] * g_scale * D[c, route[q, c, i], :]
+ *                               dD[c, s, :] = sum_q sum_{i : route[q, c, i] = s} G[q, c] * g_scale * Q[q, i, :]
+ *                               as two GEMMs against a G-scaled one-hot operand built in registers (v_mfma_f32_16x16x32), G rounded to
+ *                               the embeddings' dtype per term, fp32 sums in a fixed order (no float atomics), dQ / dD written in the
+ *                               embeddings' dtype.  G fp32 [n_q, ldg]; g_scale: NULL or one device scalar (dtype code g_scale_dtype).
+ *                               workspace: msim_dense_t_bwd_workspace_bytes bytes, 16-byte aligned, contents irrelevant.
+ */
+int msim_dense_t_supported(int dtype, int n_q, int Lq, int n_d, int Ld, int dim);
+size_t msim_dense_t_route_bytes(int n_q, int Lq, int n_d);
+int msim_fwd_transposed_route(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim,
+                              float *scores, int64_t ld_scores, int32_t *q_lengths, uint8_t *route, void *stream);
+size_t msim_dense_t_bwd_workspace_bytes(int n_q, int Lq, int n_d, int Ld, int dim);
+int msim_dense_t_bwd(int dtype, const void *Q, int n_q, int Lq, const void *D, int n_d, int Ld, int dim,
+                     const float *G, int64_t ldg, const void *g_scale, int g_scale_dtype, const uint8_t *route,
+                     void *dQ, void *dD, void *workspace, void *stream);
 
 /*
  * Packing queries into the flat layout: rows that are entirely zero (the model's padded positions,

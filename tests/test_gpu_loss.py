@@ -542,8 +542,12 @@ def test_symmetric_loss_documents_in_the_query_slot(amd, cls, kind, dtype):
                 assert int(bad.sum()) == 0, kw
         else:
             assert abs(float(loss.detach()) - float(want_loss)) <= 2.0**-8 * abs(float(want_loss)) + 1e-6, kw
-            assert grads_close(p.grad, want_dp, p_real.expand_as(want_dp)), kw
-            assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq)), kw
+            # ColbertLoss at this shape runs its backward as two GEMMs on the matrix cores (msim_dense_t_bwd, round 6): dLoss/dscores enters
+            # them rounded to bf16 -- exactly what the reference's own autograd multiplies by (its [B, C] score gradient IS a bf16 tensor)
+            # -- so every one of a row's ~B resp. ~780 B terms carries a relative 2^-9: two "paths" of slack in grads_close's terms
+            paths = 2 if kind == "infonce" else 1
+            assert grads_close(p.grad, want_dp, p_real.expand_as(want_dp), paths=paths), kw
+            assert grads_close(q.grad, want_dq, q_real.expand_as(want_dq), paths=paths), kw
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
