@@ -74,7 +74,12 @@ class PackedCorpus:
         cgroup-throttling stalls block_clamp0 was moved off torch for (round-5 advisor finding)."""
         if self.avg_rows is None:
             n = len(self)
-            self.avg_rows = int(self.lengths.numpy().sum(dtype=np.int64)) // n if n else 0
+            if not n:
+                self.avg_rows = 0
+            elif self.lengths.device.type == "cpu":
+                self.avg_rows = int(self.lengths.numpy().sum(dtype=np.int64)) // n
+            else:       # `lengths` is a host tensor by contract; under a `with torch.device("cuda")` default the packers' torch.full lands there
+                self.avg_rows = int(self.lengths.sum()) // n
         return self.avg_rows
 
     @property

@@ -28,6 +28,24 @@
 
 namespace msim {
 
+// max / min over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), the result in all four -- on the VALU:
+// v_permlane16_swap / v_permlane32_swap exchange whole 16- / 32-lane rows between two copies of the register, so max(copy0, copy1)
+// IS the pair maximum in every lane.  (__shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip per step, 16 per slab here.)
+__device__ __forceinline__ float group_max4(float v) {
+    uint32_t u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ uint32_t group_min4(uint32_t u) {
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    u = r[0] < r[1] ? r[0] : r[1];
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return r[0] < r[1] ? r[0] : r[1];
+}
+
 struct BatchTArgs {
     long long ld;       // leading dimension of scores [n_q, ld]
     int n_q, Lq;        // streamed side: n_q pages of Lq rows each (a dense box)
@@ -129,6 +147,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
 #pragma unroll
         for (int d = 0; d < DPW; ++d) sum[d] = 0.0f;
         int n_real = 0;
+        uint8_t *rbase[DPW];                    // ROUTE: this page's routing bytes of the wave's documents
+        if constexpr (ROUTE) {
+#pragma unroll
+            for (int d = 0; d < DPW; ++d) rbase[d] = route + ((size_t)page * a.n_d + (doc0 + d < a.n_d ? doc0 + d : 0)) * a.Lq_pad;
+        }
 
         auto slab = [&](int src_lds, auto tail, int rows_left, int row0) {
             constexpr bool kTail = decltype(tail)::value;
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
 #pragma unroll
             for (int d = 0; d < DPW; ++d) {
                 float m0 = -INFINITY, m1 = -INFINITY;
-                int i0 = 0, i1 = 0;
+                f32x4 keep0[U], keep1[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -160,41 +183,33 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
                             if (u * kUnitTok + r >= row_lim) { acc0[r] = -INFINITY; acc1[r] = -INFINITY; }
                         }
                     }
+                    m0 = max3(m0, acc0[0], acc0[1]);
+                    m0 = max3(m0, acc0[2], acc0[3]);
+                    m1 = max3(m1, acc1[0], acc1[1]);
+                    m1 = max3(m1, acc1[2], acc1[3]);
                     if constexpr (ROUTE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {                    // rows in ascending order, strict >: the first maximum stays
-                            const bool g0 = acc0[r] > m0, g1 = acc1[r] > m1;
-                            m0 = g0 ? acc0[r] : m0;
-                            i0 = g0 ? u * kUnitTok + r : i0;
-                            m1 = g1 ? acc1[r] : m1;
-                            i1 = g1 ? u * kUnitTok + r : i1;
-                        }
-                    } else {
-                        m0 = max3(m0, acc0[0], acc0[1]);
-                        m0 = max3(m0, acc0[2], acc0[3]);
-                        m1 = max3(m1, acc1[0], acc1[1]);
-                        m1 = max3(m1, acc1[2], acc1[3]);
+                        // this lane's candidates of the unit, kept until the document's maximum is known (below): 8 registers per unit
+                        keep0[u] = acc0;
+                        keep1[u] = acc1;
                     }
                 }
                 if constexpr (ROUTE) {
-                    // the exchange at once (nothing is kept across documents: the routing costs registers the plain form spends on
-                    // hiding the exchange behind the next document's MFMAs): (max, lowest row) over the four lane groups
+                    // (max, lowest maximal row) over the four lane groups, at once (nothing is kept across documents: the routing costs
+                    // registers the plain form spends on hiding the exchange behind the next document's MFMAs)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        float v = g == 0 ? m0 : m1;
-                        int vi = (g == 0 ? i0 : i1) + 4 * l4;
+                        const float M = group_max4(g == 0 ? m0 : m1);
+                        // the lowest row of THIS lane whose similarity is the maximum (descending scan: the first one stays), else 255
+                        uint32_t vi = 255u;
 #pragma unroll
-                        for (int m = 16; m <= 32; m <<= 1) {
-                            const float o = __shfl_xor(v, m);
-                            const int oi = __shfl_xor(vi, m);
-                            const bool take = o > v || (o == v && oi < vi);
-                            v = take ? o : v;
-                            vi = take ? oi : vi;
-                        }
+                        for (int u = U - 1; u >= 0; --u)
+#pragma unroll
+                            for (int r = 3; r >= 0; --r) vi = (g == 0 ? keep0[u][r] : keep1[u][r]) == M ? (uint32_t)(u * kUnitTok + r + 4 * l4) : vi;
+                        vi = group_min4(vi);
                         // lane group d & 3 stores document d's byte of page row row0 + 16 g + l16 (16 consecutive bytes per group)
                         const int row = row0 + 16 * g + l16;
-                        if (l4 == (d & 3) && doc0 + d < a.n_d && row < a.Lq_pad)
-                            route[((size_t)page * a.n_d + doc0 + d) * a.Lq_pad + row] = row < a.Lq ? (uint8_t)vi : (uint8_t)255;
+                        if (l4 == (d & 3) && doc0 + d < a.n_d && row < a.Lq_pad) rbase[d][row] = row < a.Lq ? (uint8_t)vi : (uint8_t)255;
+                        float v = M;
                         if constexpr (kTail) v = (16 * g + l16 < rows_left) ? v : 0.0f;
                         sum[d] += v;
                     }
@@ -209,9 +224,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
                 for (int d = 0; d < DPW; ++d)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        float v = x[d][g];
-                        v = fmaxf(v, __shfl_xor(v, 16));
-                        v = fmaxf(v, __shfl_xor(v, 32));
+                        float v = group_max4(x[d][g]);
                         if constexpr (kTail) v = (16 * g + l16 < rows_left) ? v : 0.0f;   // page rows that do not exist add nothing
                         sum[d] += v;
                     }
