@@ -11,6 +11,9 @@
 //                 neg = where(top2[:, 0] == pos, top2[:, 1], top2[:, 0]);  loss = softplus((neg - pos) / T).mean()
 //   ColbertLoss.forward :164
 //                 loss = cross_entropy(scores / T, pos_idx)
+//   ColbertSigmoidLoss.forward :457-465   (round 6)
+//                 sign = -1 everywhere, +1 at the flat positions pos_idx * (B + 1) of the [B * B] square;
+//                 loss = softplus(-scores.view(-1) / T * sign).mean()          -- the square: C == B, hence offset == 0
 //
 // What autograd would derive is written out directly.  Pairwise: exactly two score entries per query carry a gradient (the
 // positive and the selected negative): the kernel emits them as the pair list the backward kernels consume -- 2*B pairs, sorted
@@ -26,7 +29,7 @@
 namespace msim {
 
 constexpr int kEpiThreads = 256;
-constexpr int kEpiPairwise = 0, kEpiInfoNCE = 1;
+constexpr int kEpiPairwise = 0, kEpiInfoNCE = 1, kEpiSigmoid = 2;
 
 struct EpiArgs {
     long long ld;            // leading dimension of scores / G
@@ -181,6 +184,29 @@ __device__ __forceinline__ EpiRow epi_row(int b, int tid, int nthr, const float 
             pairs[2 * e + 3] = doc1;
             coef[e + 1] = pos_first ? c_neg : c_pos;
         }
+    } else if (a.mode == kEpiSigmoid) {
+        // :457-465: row b of the [B, B] square, +1 on its diagonal element (flat position pos_idx * (B + 1) with pos_idx = b + offset
+        // and offset == 0 for a square), -1 elsewhere; the row's term is its share of the mean over B * C elements, times B (the fold
+        // divides by B).  dLoss/dv = -sign / T * sigmoid(-v sign / T) / (B C), chained through the filter factor and the normalisation.
+        const float inv_C = 1.0f / (float)a.C;
+        float acc = 0.f;
+        float *grow = G != nullptr ? G + (size_t)b * a.ld : nullptr;
+        for (int c = tid; c < a.C; c += nthr) {
+            const float s = norm(srow[c]);
+            const bool f = filtered(c, s);
+            const float v = f ? s * a.filter_factor : s;
+            const float sign = c == pos_idx ? 1.0f : -1.0f;
+            const float x = -v * a.inv_T * sign;
+            acc += x > 20.0f ? x : log1pf(expf(x));                       // F.softplus (beta 1, threshold 20)
+            if (grow != nullptr) {
+                const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+                float g = -sign * a.inv_T * sig * inv_B * inv_C;
+                if (f) g *= a.filter_factor;
+                if (a.normalize) g /= len_f;
+                grow[c] = g;
+            }
+        }
+        row_loss = epi_reduce<WAVE, float>(acc, [](float x, float y) { return x + y; }, sh->f) * inv_C;
     } else {
         // cross entropy of row b with target pos_idx: lse(v / T) - pos / T
         // Softmax without cancellation: d_c = logit_c - max (<= 0, the logit ONE rounded product everywhere: __fmul_rn keeps the

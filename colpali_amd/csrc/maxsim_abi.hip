@@ -1655,7 +1655,9 @@ int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C, 
                        float *G, int32_t *pairs, float *coef, int32_t *order, void *workspace, float *out, void *loss_out,
                        const int32_t *q_lengths, void *stream) {
     if (B < 0 || C < 0 || Lq < 0 || width <= 0) return fail(MSIM_EINVAL, "negative size");
-    if (mode != MSIM_LOSS_PAIRWISE && mode != MSIM_LOSS_INFONCE) return fail(MSIM_EINVAL, "unknown loss mode %d", mode);
+    if (mode != MSIM_LOSS_PAIRWISE && mode != MSIM_LOSS_INFONCE && mode != MSIM_LOSS_SIGMOID) return fail(MSIM_EINVAL, "unknown loss mode %d", mode);
+    if (mode == MSIM_LOSS_SIGMOID && C != B)
+        return fail(MSIM_EINVAL, "the sigmoid loss is defined on the in-batch square: %d queries, %d documents", B, C);
     if (!scores || !Q || !out) return fail(MSIM_EINVAL, "null pointer argument");
     if (q_dtype != MSIM_DTYPE_BF16 && q_dtype != MSIM_DTYPE_F16 && q_dtype != MSIM_DTYPE_F32)
         return fail(MSIM_EUNSUPPORTED, "dtype code %d", q_dtype);
@@ -1679,7 +1681,7 @@ int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C, 
     a.q_is_f16 = q_dtype == MSIM_DTYPE_F16;
     a.q_row_bytes = width * a.q_elem_bytes;
     a.offset = offset;
-    a.mode = mode == MSIM_LOSS_PAIRWISE ? msim::kEpiPairwise : msim::kEpiInfoNCE;
+    a.mode = mode == MSIM_LOSS_PAIRWISE ? msim::kEpiPairwise : mode == MSIM_LOSS_SIGMOID ? msim::kEpiSigmoid : msim::kEpiInfoNCE;
     a.normalize = normalize != 0;
     a.filter = filter != 0;
     a.inv_T = 1.0f / temperature;

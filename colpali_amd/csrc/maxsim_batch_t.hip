@@ -62,7 +62,8 @@ struct BatchTArgs {
 //   route[(page * n_d + doc) * Lq_pad + row], Lq_pad = Lq rounded up to 64, bytes of rows in [Lq, Lq_pad) unspecified -- for the dense
 //   hard-max backward on the matrix cores (maxsim_dense_t.hip: ColbertLoss / ColbertSigmoidLoss in the trainer's symmetric direction,
 //   late_interaction_losses.py:140-164, contrastive_trainer.py:202-206).  The first maximal row wins a tie (maxsim_pairs.hip's rule);
-//   the scores are bit-identical to the ROUTE = false form (the same MFMAs, the max taken as compare-and-select instead of max3).
+//   the scores are bit-identical to the ROUTE = false form (the same MFMAs and the same max3 chain; the row is found by comparing the
+//   lane's candidates with the exchanged maximum).
 template <bool F16, int U, int DPW, bool ROUTE = false>
 __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                                 float *__restrict__ scores, int32_t *__restrict__ q_lengths,
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
     const int my_row_off = (wave >> 1) * kSlabRows + (wave & 1) * 16;
     // resident rows beyond the document's end (the last unit when Ld is not a multiple of 16) are zero rows in the registers: their
     // similarities are masked to -inf (a real similarity may be negative)
+    // (round 6: a template form without this wave-uniform branch behind every unit's 8 MFMAs -- the slab body as ONE basic block,
+    // 130 instead of 356 VALU per 64 MFMAs -- was measured and NOT kept: 50.9 -> 55.0 us at config 5's shape, the kernel is bound by
+    // its per-chunk latency chain, not by instruction issue)
     const bool need_mask = a.Ld != U * kUnitTok;            // wave-uniform
     const int row_lim = a.Ld - 4 * l4;                      // resident row 16 u + 4 l4 + r exists iff 16 u + r < row_lim
 

@@ -15,7 +15,8 @@ For the two in-batch losses (`ColbertPairwiseCELoss`, `ColbertLoss`) the [B, C]-
 has no host synchronisation and captures as one hipGraph.  The backward recomputes the per-token
 arg-max only for the (query, doc) pairs that carry a gradient -- the two per query the epilogue
 emits for the pairwise loss -- instead of keeping the similarity tensor alive.  The sigmoid and
-explicit-negative losses keep their (tiny) epilogues in torch on top of the same fused cores.
+explicit-negative losses keep their (tiny) epilogues in torch on top of the same fused cores; the sigmoid loss has its own epilogue
+mode since round 6.
 """
 from __future__ import annotations
 
@@ -452,7 +453,7 @@ def _epilogue_workspace(B: int, C: int, device: torch.device):
     return torch.zeros((need,), dtype=torch.uint8, device=device) if need else None
 
 
-MODE_PAIRWISE, MODE_INFONCE = 0, 1
+MODE_PAIRWISE, MODE_INFONCE, MODE_SIGMOID = 0, 1, 2
 
 
 class _FusedInBatchLoss(torch.autograd.Function):
@@ -476,11 +477,12 @@ class _FusedInBatchLoss(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:2])
         aux = q_lengths = None                      # InfoNCE + gradients: [B*C, Lq] routing (hard max) or logsumexp (smooth max)
         ctx.dense_t = False
-        if mode == MODE_INFONCE and need_grad and not smooth and B * C > 0 and _dense_t_ok(qc, dc):
+        dense = mode in (MODE_INFONCE, MODE_SIGMOID)     # a gradient on every (query, document) pair
+        if dense and need_grad and not smooth and B * C > 0 and _dense_t_ok(qc, dc):
             # the trainer's symmetric direction: byte routing from the transposed kernel (and the token counts, as for the pairwise loss)
             scores, q_lengths, aux = _dense_t_forward(qc, dc, want_lengths=True)
             ctx.dense_t = True
-        elif mode == MODE_INFONCE and need_grad:
+        elif dense and need_grad:
             scores = torch.empty((B, C), dtype=torch.float32, device=dev)
             if smooth:
                 _, aux = smooth_pairs(qc, dc, corpus.offsets, _all_pairs(B, C, dev), tau, scores_out=scores)
@@ -784,13 +786,13 @@ class ColbertSigmoidLoss(ColbertModule):
         self.ce_loss = torch.nn.CrossEntropyLoss()
 
     def forward(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor, offset: int = 0) -> torch.Tensor:
-        scores, _, pos_idx = self._inbatch_scores(query_embeddings, doc_embeddings, offset, dense_grad=True)
-        n = scores.size(0)
-        sign = -torch.ones(n * n, device=scores.device)                 # :457-459: +1 on the positives of the flattened square
-        flat_pos = pos_idx * (n + 1)
-        sign.scatter_(0, flat_pos, torch.ones_like(flat_pos, dtype=sign.dtype))   # `sign[flat_pos] = 1.0` synchronises the host
-        flat = scores.view(-1) / self.temperature                       # :462 (requires C == B, like the reference)
-        return F.softplus(-flat * sign).mean().to(_loss_dtype(query_embeddings))
+        # :444-465 in two launches (round 6): the MaxSim forward that keeps the routing, then msim_loss_epilogue(MSIM_LOSS_SIGMOID) --
+        # lengths, normalisation, filtering, the +1 / -1 sign square, the softplus mean and dLoss/dscores; until round 5 the sign mask,
+        # its scatter, the division, softplus and mean were six torch launches and a B x B mask per step
+        B, C = query_embeddings.shape[0], doc_embeddings.shape[0]
+        if C != B:      # what `-scores.view(-1) * pos_mask` raises in the reference (:459-465): the loss is defined on the in-batch square
+            raise RuntimeError(f"The size of tensor a ({B * C}) must match the size of tensor b ({B * B}) at non-singleton dimension 0")
+        return self._fused_inbatch_loss(MODE_SIGMOID, query_embeddings, doc_embeddings, offset)
 
 
 class _ExplicitNegativesMixin:

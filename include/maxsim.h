@@ -324,11 +324,13 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
  *   colpali_engine/loss/late_interaction_losses.py:296 (lengths), :300-301 (normalisation), :303-307 (pos-aware filtering) and
  *   MSIM_LOSS_PAIRWISE  :309-313  softplus((hardest in-batch negative - positive) / T).mean()     (ColbertPairwiseCELoss)
  *   MSIM_LOSS_INFONCE   :164      cross_entropy(scores / T, pos_idx)                                (ColbertLoss)
+ *   MSIM_LOSS_SIGMOID   :457-465  softplus(-scores.view(-1) / T * sign).mean(), sign +1 on the diagonal of the in-batch square,
+ *                                 -1 elsewhere (C == B, offset == 0)                                (ColbertSigmoidLoss; round 6)
  * together with what autograd derives for them:
  *   PAIRWISE  pairs int32 [2B, 2] = the two (query, doc) entries per query that carry a gradient (positive, selected negative),
  *             sorted by (query, doc); coef fp32 [2B] = dLoss/dscore of each for a unit upstream gradient; order int32 [2B] = the
  *             stable by-document permutation msim_pairs_bwd wants.  Always exactly 2B pairs: nothing to read back.  C >= 2.
- *   INFONCE   G fp32 [B, ld] = dLoss/dscores (dense).
+ *   INFONCE, SIGMOID   G fp32 [B, ld] = dLoss/dscores (dense).
  * Q [B, Lq, width] are the query embeddings (q_dtype as in msim_fwd): lengths[b] = number of tokens whose first component is
  * non-zero.  out fp32 [3] = loss, min and max of the normalised scores (the reference prints when they leave [-tol, 1+tol]).
  * q_lengths: NULL (the token counts are taken from Q here), or int32 [B] = lengths[b] ready-made (msim_fwd_transposed's by-product:
@@ -342,6 +344,7 @@ int msim_smooth_pairs_bwd(int dtype, const void *Q, int n_q, int Lq,
  */
 #define MSIM_LOSS_PAIRWISE 0
 #define MSIM_LOSS_INFONCE 1
+#define MSIM_LOSS_SIGMOID 2
 size_t msim_loss_epilogue_workspace_bytes(int B, int C);
 int msim_loss_epilogue(int mode, const float *scores, int64_t ld, int B, int C,
                        const void *Q, int q_dtype, int Lq, int width, int offset,

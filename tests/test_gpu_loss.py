@@ -397,6 +397,43 @@ def test_sigmoid_loss_fp32_against_reference_goldens_and_bf16_against_oracle(amd
         assert grads_close(d.grad, want_dd, None if smooth else d_real.expand_as(want_dd), paths=2), (vname, "dD bf16")
 
 
+def test_sigmoid_loss_runs_on_the_fused_epilogue_and_captures_as_one_graph(amd, monkeypatch):
+    """Round 6: ColbertSigmoidLoss (late_interaction_losses.py:440-465) = the MaxSim forward + ONE msim_loss_epilogue(MSIM_LOSS_SIGMOID)
+    launch -- no torch softplus / scatter / mask behind the kernels, nothing that synchronises the host (the step captures as a
+    hipGraph and replays to the same bits) -- and a non-square batch fails like the reference's `-scores.view(-1) * pos_mask`."""
+    import torch.nn.functional as F
+
+    def boom(*a, **k):
+        raise AssertionError("torch softplus in the sigmoid loss: the epilogue is fused")
+
+    monkeypatch.setattr(F, "softplus", boom)
+    g = torch.Generator().manual_seed(11)
+    Q = torch.nn.functional.normalize(torch.randn(16, 24, 128, generator=g), dim=-1).to(torch.bfloat16).cuda()
+    D = torch.nn.functional.normalize(torch.randn(16, 300, 128, generator=g), dim=-1).to(torch.bfloat16).cuda()
+    mod = amd.ColbertSigmoidLoss()
+    q, d = Q.clone().requires_grad_(True), D.clone().requires_grad_(True)
+    mod(q, d).backward()
+    eager = (q.grad.clone(), d.grad.clone())
+    qs, ds = Q.clone().requires_grad_(True), D.clone().requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            qs.grad = ds.grad = None
+            mod(qs, ds).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    qs.grad = ds.grad = None
+    with torch.cuda.graph(graph):
+        loss = mod(qs, ds)
+        loss.backward()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(qs.grad, eager[0]) and torch.equal(ds.grad, eager[1])
+    with pytest.raises(RuntimeError, match="must match the size of tensor b"):
+        mod(Q[:8], D)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE config 5 at its stated per-rank shape: bs 256 over 8 ranks -> B = 32 local queries, C = world * B = 256 gathered
 # documents, offset = rank * B (trainer/contrastive_trainer.py:143-160), Lq = 32, Ld = 780 (ColQwen2, left padded).
