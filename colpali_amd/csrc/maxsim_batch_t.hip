@@ -96,9 +96,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_t_kernel(const uint16_t *
     const int my_row_off = (wave >> 1) * kSlabRows + (wave & 1) * 16;
     // resident rows beyond the document's end (the last unit when Ld is not a multiple of 16) are zero rows in the registers: their
     // similarities are masked to -inf (a real similarity may be negative)
-    // (round 6: a template form without this wave-uniform branch behind every unit's 8 MFMAs -- the slab body as ONE basic block,
-    // 130 instead of 356 VALU per 64 MFMAs -- was measured and NOT kept: 50.9 -> 55.0 us at config 5's shape, the kernel is bound by
-    // its per-chunk latency chain, not by instruction issue)
+    // (round 6, measured and NOT kept at config 5's shape, 32 pages x 256 documents of 32 rows: a template form without this
+    // wave-uniform branch behind every unit's 8 MFMAs -- the slab body as ONE basic block, 130 instead of 356 VALU per 64 MFMAs --
+    // 50.9 -> 55.0 us; two documents per wave with a two-chunk ring, i.e. two workgroups per CU, 50.9 -> 56.7 us.  The kernel is
+    // bound by its per-chunk latency chain, not by instruction issue or occupancy.)
     const bool need_mask = a.Ld != U * kUnitTok;            // wave-uniform
     const int row_lim = a.Ld - 4 * l4;                      // resident row 16 u + 4 l4 + r exists iff 16 u + r < row_lim
 
