@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -675,12 +676,49 @@ DdPlan dd_plan(int n_pairs, int Lq, int n_d, int dim, int max_doc_rows, int cus)
     return pl;
 }
 
+// A side stream and a few events per device, created on first use (round 6).  The two GEMM kernels of msim_dense_t_bwd (dP, dR) are
+// independent of each other and each alone keeps the matrix cores ~27 % busy (latency chains, one workgroup per CU): the call forks
+// them onto two streams and joins before it returns to the caller's stream, so they share the CUs (LDS 67 + 70 KiB, 4 waves per
+// SIMD) and cover each other's stalls (ColbertLoss, both directions at config 5's shape: 0.468 -> 0.390 ms).  Fork / join with
+// events is the capturable pattern: a hipGraph of the step gets two parallel branches.
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t ev[8] = {};
+    std::atomic<int> ready{0};
+    std::atomic<unsigned> next{0};
+};
+SideStream g_side[kMaxDevices];
+
+int side_stream(SideStream **out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) return fail(MSIM_ELAUNCH, "device ordinal %d out of range", dev);
+    SideStream &s = g_side[dev];
+    if (!s.ready.load(std::memory_order_acquire)) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!s.ready.load(std::memory_order_relaxed)) {
+            hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+            if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+            for (auto &ev : s.ev) {
+                e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e != hipSuccess) return fail(MSIM_ELAUNCH, "hipEventCreateWithFlags: %s", hipGetErrorString(e));
+            }
+            s.ready.store(1, std::memory_order_release);
+        }
+    }
+    *out = &s;
+    return MSIM_OK;
+}
+
 // every gradient kernel of one msim_pairs_bwd call; OUT16: dQ / dD in the embeddings' own 16-bit dtype
 template <int DT, bool OUT16>
 void launch_bwd_kernels(const char *Q, const char *D, const int32_t *d_off, int max_doc_rows, const int32_t *pairs,
                         const int32_t *order_by_doc, const float *g, const int32_t *argmax, void *dQ, void *dD,
                         const msim::PairsArgs &a, int dim, int cus, hipStream_t st, float *partial, const DdPlan &pl, msim::GScale gs) {
     const int row_bytes = dim * msim::elem_size<DT>();
+    // (round 6, measured and NOT kept: dQ on a second stream beside dD, as msim_dense_t_bwd does with its two GEMM kernels -- the
+    // fork / join edges cost more than the 5-20 us of overlap they buy here: pairwise loss 0.102 -> 0.123 ms, ColbertLoss 0.188 -> 0.209)
     if (a.n_q > 0 && a.Lq > 0) {
         // tokens per wave: the pair-range lookup is per wave, so few waves per query once there are more tokens than the chip has waves
         const long long tokens = (long long)a.n_q * a.Lq;
@@ -1418,11 +1456,19 @@ int dense_t_bwd_launch(const uint16_t *Q, const uint16_t *D, const float *G, msi
                        uint16_t *dD, char *ws, const DenseTPlan &pl, msim::DenseTArgs a, hipStream_t st) {
     uint16_t *rimg = reinterpret_cast<uint16_t *>(ws + pl.rimg), *pimg = reinterpret_cast<uint16_t *>(ws + pl.pimg);
     float *partial = reinterpret_cast<float *>(ws + pl.partial);
+    SideStream *side = nullptr;
+    if (int rc = side_stream(&side)) return rc;
+    const unsigned e0 = side->next.fetch_add(2) % 8;      // two events of the pool per call (fork, join)
+    hipEvent_t fork = side->ev[e0], join = side->ev[(e0 + 1) % 8];
+    // fork: the side stream takes the page image and dR (+ its split sum), the caller's stream the document image and dP
+    hipError_t e = hipEventRecord(fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side->st, fork, 0);
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "msim_dense_t_bwd fork: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(msim::dense_t_image_kernel, dim3(a.n_d * pl.ks), dim3(256), 0, st, D, rimg, a.n_d, a.Ld, pl.ks);
-    hipLaunchKernelGGL(msim::dense_t_image_kernel, dim3(a.n_q * a.ksp), dim3(256), 0, st, Q, pimg, a.n_q, a.Lq, a.ksp);
+    hipLaunchKernelGGL(msim::dense_t_image_kernel, dim3(a.n_q * a.ksp), dim3(256), 0, side->st, Q, pimg, a.n_q, a.Lq, a.ksp);
     static std::atomic<int> conf_long[2][kMaxDevices], conf_short[4][kMaxDevices];
-    // LDS: the 3-stage operand ring + the routing bytes + the weight pairs (dP: one per document of the page, padded to whole stages;
-    // dR: one per (page of the split, document of the workgroup)); the attribute is raised once to what dense_t_supported admits
+    // LDS: the operand ring + the routing bytes + the W patterns / weight pairs (dP: one per document of the page, padded to whole
+    // stages; dR: one per (page of the split, document of the workgroup)); the attribute is raised once to what dense_t_supported admits
     constexpr int kLongRing = msim::kDenseTLongRing, kShortRing = msim::kDenseTShortRing;
     constexpr int kLongStage = msim::kDenseTLongSteps * (8192 + 128 + 144);      // image + routing bytes + W patterns (KS = 1: one document per step)
     constexpr int lds_long_max = kLongRing * kLongStage + 4 * (kDenseTMaxDocs + 4), lds_short_max = kShortRing * (16384 + 1024) + 4 * 16 * kDenseTMaxPagesPer;
@@ -1442,17 +1488,21 @@ int dense_t_bwd_launch(const uint16_t *Q, const uint16_t *D, const float *G, msi
 #define MSIM_SHORT(NSB, NC, SLOT)                                                                         \
     {                                                                                                     \
         auto k = msim::dense_t_bwd_short_kernel<F16, NSB, NC>;                                            \
-        if (int rc = allow_lds(k, lds_short_max, conf_short[SLOT])) return rc;                                \
-        hipLaunchKernelGGL(k, grid_short, dim3(512), lds_short, st, pimg, route, G, gs, partial, a);      \
+        if (int rc = allow_lds(k, lds_short_max, conf_short[SLOT])) return rc;                            \
+        hipLaunchKernelGGL(k, grid_short, dim3(512), lds_short, side->st, pimg, route, G, gs, partial, a); \
     }
     if (pl.nsb <= 1) MSIM_SHORT(1, 4, 0)
     else if (pl.nsb == 2) MSIM_SHORT(2, 2, 1)
     else MSIM_SHORT(4, 1, 2)
 #undef MSIM_SHORT
     const long long n_elems = (long long)a.n_d * a.Ld * msim::kDim;
-    hipLaunchKernelGGL(msim::dense_t_bwd_short_sum_kernel<F16>, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, st, partial, dD,
+    hipLaunchKernelGGL(msim::dense_t_bwd_short_sum_kernel<F16>, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, side->st, partial, dD,
                        n_elems, pl.n_split);
-    hipError_t e = hipGetLastError();
+    // join: the caller's stream continues when both halves are done
+    e = hipEventRecord(join, side->st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, join, 0);
+    if (e != hipSuccess) return fail(MSIM_ELAUNCH, "msim_dense_t_bwd join: %s", hipGetErrorString(e));
+    e = hipGetLastError();
     if (e != hipSuccess) return fail(MSIM_ELAUNCH, "msim_dense_t_bwd launch: %s", hipGetErrorString(e));
     return MSIM_OK;
 }

@@ -28,7 +28,7 @@ constexpr int kDenseTMaxLd = 64;          // resident documents of at most this 
 // Ring depths of the two backward kernels (stages of 16 KiB).  An LDS-DMA piece lands 1.1 - 1.8 us after its issue on this chip
 // (MI355X_MICROARCH.md: "issued -> landed ~1.1 us"; measured here: with 2 stages of prefetch every stage took 0.9 us whatever the
 // chip's load -- 56 or 224 workgroups, tools/ab_dense_t_sizes.sh), and a stage is ~0.25 us of MFMA work: 7 resp. 5 stages ahead.
-constexpr int kDenseTLongSteps = 4, kDenseTLongRing = 4, kDenseTShortRing = 4;
+constexpr int kDenseTLongSteps = 4, kDenseTLongRing = 2, kDenseTShortRing = 4;
 constexpr int kFragBytes = 1024;          // one operand fragment: 64 lanes x 16 bytes
 constexpr int kKStepBytes = 8 * kFragBytes;   // one 32-row k-step of an image: 8 column blocks
 
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void dense_t_bwd_long_kernel(const uint16_t
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 template <bool F16, int NSB, int NC>
-__global__ __launch_bounds__(512, 1) void dense_t_bwd_short_kernel(const uint16_t *__restrict__ Pimg, const uint8_t *__restrict__ route,
+__global__ __launch_bounds__(512, 4) void dense_t_bwd_short_kernel(const uint16_t *__restrict__ Pimg, const uint8_t *__restrict__ route,
                                                                     const float *__restrict__ G, GScale gs, float *__restrict__ partial,
                                                                     DenseTArgs a) {
     static_assert(NSB * NC == 4 && NC <= 4, "four (document, row block) combinations per wave pair");
@@ -450,11 +450,6 @@ __global__ __launch_bounds__(512, 1) void dense_t_bwd_short_kernel(const uint16_
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wp[j] = w_lds[(pg - page_lo) * 4 * NC + dw * NC + jd[j]];
     };
-    auto load_af = [&](bf16x8 (&af)[8], const char *st, int kk) {
-        if (kAbBuild && (dbg & 8)) return;
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const bf16x8 *>(st + (kk * 8 + mb) * kFragBytes + lane * 16);
-    };
     // the routing of this lane's 8 k-slots = page rows 32 kk + 8 l4 + e of the stage, per combination's document
     auto load_rb = [&](uint2 (&rb)[NJ], const char *rt, int kk) {
         rb[0] = *reinterpret_cast<const uint2 *>(rt + jd[0] * 64 + kk * 32 + 8 * l4);
@@ -479,18 +474,26 @@ __global__ __launch_bounds__(512, 1) void dense_t_bwd_short_kernel(const uint16_
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    // operand registers in two sets that alternate by step parity (see dense_t_bwd_long_kernel)
-    static_assert(NS % 2 == 0, "operand sets alternate by step parity");
+    // The pipeline runs in HALF steps (one k-step's column blocks 0-3, then 4-7: 2 combinations x 4 MFMAs each): the A fragments of
+    // the next half step are read under this one's MFMAs, in two alternating sets of 4 -- 32 registers instead of the 64 a whole-step
+    // double buffer takes, which keeps the kernel under 128 VGPRs: four waves per SIMD, i.e. it shares a CU with the dP kernel that
+    // msim_dense_t_bwd runs beside it on a second stream.  The routing bytes and the first W^T of the next k-step alternate by k-step.
+    auto load_af_half = [&](bf16x8 (&af)[4], const char *st, int kk, int hf) {
+        if (kAbBuild && (dbg & 8)) return;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8 *>(st + (kk * 8 + 4 * hf + m) * kFragBytes + lane * 16);
+    };
+    static_assert(NS % 2 == 0, "operand sets alternate by parity");
     uint32_t wp[NJ], wpn[NJ];
     uint2 rb[2][NJ];
-    bf16x8 af[2][8], wf0[2], wf1;
+    bf16x8 af[2][4], wf0[2], wf1;
     if (n_stages > 0) {
         publish(0);
         load_weights(wp, page_lo);
         piece(0);
         piece(kPieces);
         load_rb(rb[0], route_lds + dw * 256, 0);
-        load_af(af[0], smem, 0);
+        load_af_half(af[0], smem, 0, 0);
         wf0[0] = build_w(rb[0][0], wp[0], s2[0]);
     }
     int c_pg = page_lo, c_sp = 0, slot = 0;    // the stage being consumed
@@ -501,37 +504,45 @@ __global__ __launch_bounds__(512, 1) void dense_t_bwd_short_kernel(const uint16_
         const bool new_page = more && c_sp + 1 == st_per_page;            // wave-uniform
         if (new_page) load_weights(wpn, c_pg + 1);
 #pragma unroll
-        for (int kk = 0; kk < NS; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < NS) {
-                piece(kk + 1);                     // the rest of stage s + kRing - 1
-                load_af(af[nxt], st, kk + 1);
-                load_rb(rb[nxt], rt, kk + 1);
-            } else if (more) {                     // the switch to stage s + 1, in front of the last step's MFMAs
+        for (int hs = 0; hs < 2 * NS; ++hs) {
+            const int kk = hs >> 1, hf = hs & 1;
+            const int cur = hs & 1, nxt = cur ^ 1;         // A fragment sets
+            const int rcur = kk & 1, rnxt = rcur ^ 1;      // routing bytes / first W^T of a k-step
+            if (hf == 0) {
+                if (kk + 1 < NS) {
+                    piece(kk + 1);                         // the rest of stage s + kRing - 1
+                    load_rb(rb[rnxt], rt, kk + 1);
+                }
+                load_af_half(af[nxt], st, kk, 1);
+                wf1 = build_w(rb[rcur][1], wp[1], s2[1]);
+            } else if (kk + 1 < NS) {
+                load_af_half(af[nxt], st, kk + 1, 0);
+            } else if (more) {                             // the switch to stage s + 1, in front of the stage's last MFMAs
                 publish(s + 1);
-                next_stage();                      // stage s + kRing goes where stage s was
+                next_stage();                              // stage s + kRing goes where stage s was
                 piece(0);
                 piece(kPieces);
                 const int nslot = slot + 1 == kRing ? 0 : slot + 1;
-                load_af(af[nxt], smem + nslot * kStageBytes, 0);
-                load_rb(rb[nxt], route_lds + nslot * kRouteBytes + dw * 256, 0);
+                load_af_half(af[nxt], smem + nslot * kStageBytes, 0, 0);
+                load_rb(rb[rnxt], route_lds + nslot * kRouteBytes + dw * 256, 0);
             }
-            wf1 = build_w(rb[cur][1], wp[1], s2[1]);                               // under combination 0's MFMAs
             if (!(kAbBuild && (dbg & 2))) {
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[0][mb] = mfma16<F16>(af[cur][mb], wf0[cur], acc[0][mb]);
+                for (int m = 0; m < 4; ++m) acc[0][4 * hf + m] = mfma16<F16>(af[cur][m], wf0[rcur], acc[0][4 * hf + m]);
             }
-            // the next step's first W^T (its routing bytes were requested above; a new page brings new weights), under combination 1's
-            if (kk + 1 == NS && new_page) {
+            if (hf == 1) {
+                // the next k-step's first W^T (its routing bytes were requested above or a half step ago; a new page brings new weights)
+                if (kk + 1 == NS && new_page) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) wp[j] = wpn[j];
+                    for (int j = 0; j < NJ; ++j) wp[j] = wpn[j];
+                }
+                wf0[rnxt] = build_w(rb[rnxt][0], wp[0], s2[0]);
             }
-            wf0[nxt] = build_w(rb[nxt][0], wp[0], s2[0]);
             if (!(kAbBuild && (dbg & 2))) {
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[1][mb] = mfma16<F16>(af[cur][mb], wf1, acc[1][mb]);
+                for (int m = 0; m < 4; ++m) acc[1][4 * hf + m] = mfma16<F16>(af[cur][m], wf1, acc[1][4 * hf + m]);
             }
-            interleave_hint<16, 2, 2>();
+            interleave_hint<8, 2, 2>();
         }
         slot = slot + 1 == kRing ? 0 : slot + 1;
         if (++c_sp == st_per_page) { c_sp = 0; ++c_pg; }
