@@ -329,7 +329,7 @@ def short_docs_numbers(amd, dev):
     """The resident path on SHORT documents (round-4 review, weak 8): a token-pooled corpus -- pool factor 3 of a 1030-patch page
     (README.md:225, compression/token_pooling) = 343 rows -- and 64-row documents, 8 GiB of rows each, in the HBM-bound and the
     MFMA-bound regime.  K1b pays one chunk barrier, one table write and one pass of token sums per document: the numbers show what
-    that costs (the structural fix -- several documents per chunk -- is not built)."""
+    that costs (the structural fix -- several documents per chunk -- is not built, DESIGN.md section 8, gap 4)."""
     out = {}
     for name, doc_len in (("pooled_343_rows", 343), ("64_rows", 64)):
         n_docs = (8 << 30) // (doc_len * 256)
