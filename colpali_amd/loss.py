@@ -28,12 +28,24 @@ from .corpus import PackedCorpus
 from .scoring import maxsim_scores
 
 
+_dense_offsets_cache = _lib.StreamConstCache(32)
+_dense_lengths = {}
+
+
 def _dense_corpus(d: torch.Tensor) -> PackedCorpus:
     """View a dense [C, Ld, width] tensor as a packed corpus (no copy; zero rows stay physical rows)."""
     C, Ld, _ = d.shape
-    offsets = torch.arange(0, (C + 1) * Ld, Ld, dtype=torch.int32, device=d.device) if Ld else torch.zeros(C + 1, dtype=torch.int32, device=d.device)   # one launch
-    return PackedCorpus(blob=d.view(C * Ld, d.shape[2]), offsets=offsets, clamp0=None,
-                        lengths=torch.full((C,), Ld, dtype=torch.int64))
+    # the row offsets of a [C, Ld] box and its host-side lengths are constants of the shape: cached per (shape, device, stream) -- an
+    # eager training step is bound by its host time (the reference trainer captures no graphs), and this was a launch + two
+    # allocations per loss call
+    offsets = _dense_offsets_cache.get(("off", C, Ld), d.device, lambda: (
+        torch.arange(0, (C + 1) * Ld, Ld, dtype=torch.int32, device=d.device) if Ld else torch.zeros(C + 1, dtype=torch.int32, device=d.device)))
+    lengths = _dense_lengths.get((C, Ld))
+    if lengths is None:
+        if len(_dense_lengths) > 64:
+            _dense_lengths.clear()
+        lengths = _dense_lengths[(C, Ld)] = torch.full((C,), Ld, dtype=torch.int64, device="cpu")
+    return PackedCorpus(blob=d.view(C * Ld, d.shape[2]), offsets=offsets, clamp0=None, lengths=lengths, avg_rows=Ld)
 
 
 def _check_embeddings(q: torch.Tensor, d: torch.Tensor) -> None:
@@ -652,9 +664,11 @@ class ColbertModule(torch.nn.Module):
         pending = self.__dict__.setdefault("_bounds_pending", [])
         if len(pending) >= 64:                               # never grow without bound: wait for the oldest report
             self._flush_bounds(wait=True, only_first=True)
-        host = torch.empty((2,), dtype=torch.float32, pin_memory=True)
+        # a pinned buffer and an event per report in flight, REUSED: allocating pinned memory costs ~15 us of host time per call,
+        # which is most of what this diagnostic cost an eager training step
+        free = self.__dict__.setdefault("_bounds_free", [])
+        host, ev = free.pop() if free else (torch.empty((2,), dtype=torch.float32, pin_memory=True), torch.cuda.Event())
         host.copy_(lo_hi[-2:], non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(lo_hi.device))
         pending.append((host, ev))
         _register_bounds_flush(self)
@@ -670,6 +684,9 @@ class ColbertModule(torch.nn.Module):
                 return
             pending.pop(0)
             lo, hi = float(host[0]), float(host[1])
+            free = self.__dict__.setdefault("_bounds_free", [])
+            if len(free) < 64:
+                free.append((host, ev))
             if lo < -self.norm_tol or hi > 1 + self.norm_tol:
                 print(f"Scores out of bounds after normalization: min={lo:.4f}, max={hi:.4f}, tol={self.norm_tol}")
             if only_first:
@@ -685,6 +702,7 @@ class ColbertModule(torch.nn.Module):
         # through __reduce_ex__ and therefore through here) skip them
         state = dict(self.__dict__)
         state.pop("_bounds_pending", None)
+        state.pop("_bounds_free", None)
         return state
 
     def _aggregate(self, scores_raw: torch.Tensor, use_smooth_max: bool, dim_max: int, dim_sum: int) -> torch.Tensor:
