@@ -418,7 +418,7 @@ int ranges_per_xcd(int n_qblocks, int cus_per_xcd, int n_d, int avg_rows) {
 template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
 int launch_batch(const FwdCall &c, const FlatPlan &plan) {
     auto kern = msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
-    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes + NW * MAXU * msim::kUnitTok * 16 + NW * 8 * 8;   // ring + the per-token max table + the queries' token ranges
+    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes + (NW > 2 ? 2 : 1) * NW * MAXU * msim::kUnitTok * 16 + NW * 8 * 8;   // ring + the per-token max table(s) + the queries' token ranges
     constexpr int wg_per_cu = MAXU == 5 ? 12 / NW : 8 / NW;  // the five-unit form: 168 registers, three waves per SIMD (three 4-wave workgroups per CU)
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;

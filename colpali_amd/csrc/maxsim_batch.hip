@@ -98,7 +98,13 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     constexpr int kChunkBytes = kChunkSlabs * kSlabBytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *const tokmax = smem + kBatchRing * kChunkBytes;   // per-token max table of the workgroup: NW * MAXU units x 16 tokens x 16 B
+    // per-token max table of the workgroup: NW * MAXU units x 16 tokens x 16 B.  TWO of them (round 6), used by alternate documents:
+    // with one table a one-chunk document needs a barrier of its own between the previous document's sums and its writes -- for a
+    // corpus of 64-row documents (pooled pages) that is a second barrier per 128 MFMAs.  The pair form keeps one table (four pairs
+    // per CU: a second table would push it over 160 KiB).
+    constexpr bool kTwoTables = NW > 2;
+    constexpr int kTableBytes = kB1Waves * MAXU * kUnitTok * 16;
+    char *const tokmax = smem + kBatchRing * kChunkBytes;
 
     // ---- which (query block, document range) is this workgroup?
     const int sub = a.n_ranges >> 3;                       // ranges per XCD
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     // the reduction after every document: 8 lanes per query, query j of the block in lanes 8j .. 8j+7 of the workgroup
     // (the token range of the query waits in LDS next to the table, written by the lanes that read it back: the slab loop of the
     // ten-unit form has no two registers to spare)
-    int *const rtab = reinterpret_cast<int *>(tokmax + kB1Waves * MAXU * kUnitTok * 16);
+    int *const rtab = reinterpret_cast<int *>(tokmax + (kTwoTables ? 2 : 1) * kTableBytes);
     {
         const int rq = threadIdx.x >> 3;
         if (rq < qb_n) {
@@ -221,12 +227,12 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     unsigned long long tr[7] = {0, 0, 0, 0, 0, 0, 0};     // vmcnt, convoy, barrier, DMA issue, slabs, document epilogue, chunks
 
     // ---- the token sums of the document whose maxima are in the table (all waves have passed a barrier since they were written)
-    auto reduce_doc = [&](int doc, bool clamp) {
+    auto reduce_doc = [&](int doc, bool clamp, int tab) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));        // opaque: nothing derived from it (row pointers, table addresses) is hoisted into registers that
         const int rq = tid >> 3, ri = tid & 7;   // stay live across the slab loop (the ten-unit form spills otherwise)
         if (rq < qb_n) {
-            float tot = reduce_query_tokens<F16>(tokmax, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
+            float tot = reduce_query_tokens<F16>(tokmax + tab * kTableBytes, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
             if (round_total) tot = round_to_input<F16>(tot);
             if (ri == 0) scores[(size_t)(qb0 + rq) * a.ld + doc] = tot;
         }
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     constexpr int NUA = NU > 0 ? NU : 1;                   // array extents (no zero-length arrays)
     int pend_doc = -1;                                      // document whose maxima wait in the table (wave-uniform, the same in all waves)
     bool pend_clamp = false;
+    int pend_tab = 0, tab = 0;                              // the table they wait in; the table the current document writes
     for (int c_idx = d_lo; c_idx < d_hi; ++c_idx) {
         const int len = d_off[c_idx + 1] - d_off[c_idx];
         const int nchunk = (len + kChunkRows - 1) / kChunkRows;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
             const unsigned long long t3 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             produce();                      // refill the buffer that was read in the previous iteration
             const unsigned long long t4 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            if (ch == 0 && pend_doc >= 0) reduce_doc(pend_doc, pend_clamp);   // the previous document's token sums, behind its barrier
+            if (ch == 0 && pend_doc >= 0) reduce_doc(pend_doc, pend_clamp, pend_tab);   // the previous document's token sums, behind its barrier
 
             const int cbuf = c_slot * kChunkBytes;
             c_slot = (c_slot + 1 == kBatchRing) ? 0 : c_slot + 1;
@@ -320,20 +327,23 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
             }
         }
         const unsigned long long te0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-        // ---- document epilogue: this wave's maxima into the workgroup's table; the sums are taken behind the next barrier.  ONE table:
-        // a one-chunk document has no barrier between the previous document's sums and these writes, so it gets one
-        if (nchunk == 1) lds_barrier();
+        // ---- document epilogue: this wave's maxima into the workgroup's table; the sums are taken behind the next barrier.  With ONE
+        // table a one-chunk document has no barrier between the previous document's sums and these writes, so it gets one; with two
+        // tables the previous document's sums read the other one, and the table written here was last read two barriers ago
+        if (nchunk == 1 && !kTwoTables) lds_barrier();
         if constexpr (wave_has_units) {
 #pragma unroll
-            for (int t = 0; t < NUA; ++t) store_token_max(tokmax, wave + kB1Waves * t, m[t], lane);
+            for (int t = 0; t < NUA; ++t) store_token_max(tokmax + tab * kTableBytes, wave + kB1Waves * t, m[t], lane);
         }
         pend_doc = c_idx;
         pend_clamp = clamp;
+        pend_tab = tab;
+        if constexpr (kTwoTables) tab ^= 1;
         if (tracing) tr[5] += __builtin_amdgcn_s_memtime() - te0;
     }
     if (pend_doc >= 0) {
         lds_barrier();
-        reduce_doc(pend_doc, pend_clamp);
+        reduce_doc(pend_doc, pend_clamp, pend_tab);
     }
     if (tracing && lane == 0) {
 #pragma unroll

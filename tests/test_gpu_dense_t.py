@@ -151,3 +151,32 @@ def test_dense_losses_take_the_matrix_core_backward_and_agree_with_the_list_kern
     assert float((new[0] - old[0]).abs()) <= 2.0**-8 * float(old[0].abs()) + 1e-7
     for a, b in zip(new[1:], old[1:]):
         assert float((a - b).abs().max()) <= 2.0**-6 * float(b.abs().max())
+
+
+def test_dense_backward_abi_rejects_what_it_does_not_take(amd):
+    """include/maxsim.h: msim_dense_t_bwd / msim_fwd_transposed_route return error codes (never touch memory) for null pointers,
+    unsupported dtypes / widths / document lengths, a short leading dimension and a misaligned workspace; empty batches are a no-op."""
+    from colpali_amd import _lib
+
+    lib = _lib.lib()
+    q, d = _boxes(3, 200, 5, 24, torch.bfloat16, zero_rows=False)
+    _, _, route = _route_forward(q, d)
+    G = torch.zeros((3, 5), device="cuda")
+    dq, dd = torch.empty_like(q), torch.empty_like(d)
+    nbytes = lib.msim_dense_t_bwd_workspace_bytes(3, 200, 5, 24, 128)
+    assert nbytes > 0 and lib.msim_dense_t_bwd_workspace_bytes(0, 200, 5, 24, 128) == 0
+    ws = torch.empty((nbytes + 16,), dtype=torch.uint8, device="cuda")
+    st = _lib.current_stream_handle(q.device)
+
+    def call(dtype=0, Q=q, D=d, Ld=24, dim=128, g=G, ldg=5, r=route, out_q=dq, out_d=dd, w=ws, n_q=3, n_d=5):
+        return lib.msim_dense_t_bwd(dtype, _lib.ptr(Q), n_q, 200, _lib.ptr(D), n_d, Ld, dim, _lib.ptr(g), ldg, None, 0, _lib.ptr(r),
+                                    _lib.ptr(out_q), _lib.ptr(out_d), _lib.ptr(w), st)
+
+    assert call() == 0
+    assert call(n_q=0) == 0 and call(n_d=0) == 0                       # nothing to do
+    assert call(dtype=2) == -2 and call(dim=96) == -2 and call(Ld=65) == -2          # MSIM_EUNSUPPORTED
+    assert call(g=None) == -1 and call(r=None) == -1 and call(w=None) == -1          # MSIM_EINVAL
+    assert call(ldg=4) == -1
+    assert call(w=ws[1:]) == -1                                                       # workspace not 16-byte aligned
+    assert b"" != lib.msim_last_error()
+    torch.cuda.synchronize()
