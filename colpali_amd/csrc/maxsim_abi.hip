@@ -1086,25 +1086,32 @@ constexpr int kPanelsFlatMaxTokens = msim::kBatchWaves * kPanelsFlatMaxU * msim:
 int panels_flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
     if ((long long)hq.at(n_q) - hq.at(0) < 0) return fail(MSIM_EINVAL, "query token offsets are not non-decreasing");
     p = FlatPlan{};
-    p.nw = msim::kBatchWaves;
+    // the ladder (round 6): a batch that fits ONE block of two waves (<= 8 units, <= 16 queries) or four waves (<= 16 units, <= 32
+    // queries) takes that shape -- up to four units per wave behind a narrower barrier, two workgroups per CU; everything else the
+    // 8-wave shape (one or several blocks)
+    const long long tokens = (long long)hq.at(n_q) - hq.at(0);
+    const long long units = (tokens + msim::kUnitTok - 1) / msim::kUnitTok;
+    p.nw = (units <= 2 * kPanelsFlatMaxU && n_q <= 16) ? 2 : (units <= 4 * kPanelsFlatMaxU && n_q <= 32) ? 4 : msim::kBatchWaves;
     p.maxu = kPanelsFlatMaxU;
-    if (!fill_blocks(hq, n_q, p.nw, p.maxu, p.blk_q0))
+    if (!fill_blocks(hq, n_q, p.nw, p.maxu, p.blk_q0) || (p.nw != msim::kBatchWaves && p.n_blocks() != 1)) {
+        p.nw = msim::kBatchWaves;                     // (unit padding at query borders cannot overflow: units counts whole tokens)
+        p.blk_q0.clear();
+    }
+    if (p.blk_q0.empty() && !fill_blocks(hq, n_q, p.nw, p.maxu, p.blk_q0))
         return fail(MSIM_EUNSUPPORTED, "a query of more than %d tokens does not fit one query block of the width-320 kernels: pad the "
                     "queries to one length and call msim_fwd", kPanelsFlatMaxTokens);
     balance_blocks(hq, n_q, p.nw, p.maxu, p.blk_q0);
     return MSIM_OK;
 }
 
-template <bool F16>
-int launch_batch_panels_flat(const FwdCall &c) {
-    thread_local FlatPlan plan;
-    if (int rc = panels_flat_plan(host_q(c), c.n_q, plan)) return rc;
-    auto kern = msim::maxsim_batch_panels_flat_kernel<F16, kPanels320, kLast320, kPanelsFlatMaxU>;
-    constexpr int lds = msim::kPanelStages * kPanels320 * msim::kSlabBytes + msim::kBatchWaves * kPanelsFlatMaxU * msim::kUnitTok * 16 +
-                        msim::kBatchWaves * 8 * 8;       // stage ring + the per-token max table + the queries' token ranges
+template <bool F16, int NW, int STAGES>
+int launch_batch_panels_flat_nw(const FwdCall &c, const FlatPlan &plan) {
+    auto kern = msim::maxsim_batch_panels_flat_kernel<F16, kPanels320, kLast320, kPanelsFlatMaxU, NW, STAGES>;
+    constexpr int lds = STAGES * kPanels320 * msim::kSlabBytes + NW * kPanelsFlatMaxU * msim::kUnitTok * 16 +
+                        NW * 8 * 8;                      // stage ring + the per-token max table + the queries' token ranges
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
-    const int cus_per_xcd = c.di->cus / 8 > 0 ? c.di->cus / 8 : 1;       // one workgroup per CU
+    const int cus_per_xcd = (c.di->cus / 8 > 0 ? c.di->cus / 8 : 1) * (NW == msim::kBatchWaves ? 1 : 2);   // workgroups resident per XCD
     const int total_blocks = plan.n_blocks();
     for (int b0 = 0; b0 < total_blocks; b0 += msim::kMaxQBlocks) {
         msim::BatchArgs a{};
@@ -1119,11 +1126,20 @@ int launch_batch_panels_flat(const FwdCall &c) {
         const int slots = sub > 1 ? a.n_qblocks * sub : a.n_qblocks;
         a.convoy = nullptr;
         a.trace = nullptr;
-        hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
+        hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_panels_flat_kernel launch: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_panels_flat_kernel<%d> launch: %s", NW, hipGetErrorString(e));
     }
     return MSIM_OK;
+}
+
+template <bool F16>
+int launch_batch_panels_flat(const FwdCall &c) {
+    thread_local FlatPlan plan;
+    if (int rc = panels_flat_plan(host_q(c), c.n_q, plan)) return rc;
+    if (plan.nw == 2) return launch_batch_panels_flat_nw<F16, 2, 3>(c, plan);
+    if (plan.nw == 4) return launch_batch_panels_flat_nw<F16, 4, 3>(c, plan);
+    return launch_batch_panels_flat_nw<F16, msim::kBatchWaves, msim::kPanelStages>(c, plan);
 }
 
 // a uniform box [n_q, Lq, 320] on the flat kernel?  K1sP keeps the calls of <= 4 token tiles (HBM-bound, no barriers); K1bP keeps whole

@@ -397,8 +397,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_kernel(const uint1
 // Document stream, stage ring, swizzled panel-slab image and the MFMA chain across the panels are K1bP's; block -> (query block,
 // document range) mapping, the one-table epilogue and its barrier rule (a one-slab document gets a barrier of its own between the
 // previous document's sums and its writes) are K1b's, with the 32-row slab in the place of K1b's chunk.
-template <bool F16, int PANELS, int KS_LAST, int MAXU>
-__global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const uint16_t *__restrict__ Qt, const uint16_t *__restrict__ D,
+// NW / STAGES (round 6): the plan ladder of width 320.  The 8-wave shape is a barrier per 32-row slab with 20 MFMAs per unit behind it:
+// right for full blocks (32 units), barrier-bound for the small batches of the HBM-bound end (10 units over 8 waves = 20-40 MFMAs per
+// barrier: 4 x 40 tokens reached 0.49 of the HBM bound where width 128 reaches 0.79, profiles/r06_logs/ab_wide_ladder.log).  NW = 4
+// (<= 16 units) and NW = 2 (<= 8 units) give every wave up to four units, halve / quarter the barrier's width and -- with a 3-stage
+// ring of 72 KiB -- put two workgroups on a CU; a wave issues 8 / NW of the stage's eight 4-row DMA groups.
+template <bool F16, int PANELS, int KS_LAST, int MAXU, int NW = kBatchWaves, int STAGES = kPanelStages>
+__global__ __launch_bounds__(NW * 64, 2) void maxsim_batch_panels_flat_kernel(const uint16_t *__restrict__ Qt, const uint16_t *__restrict__ D,
                                                                            const int32_t *__restrict__ d_off,
                                                                            const uint8_t *__restrict__ clamp0,
                                                                            float *__restrict__ scores, BatchArgs a) {
@@ -406,14 +411,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const 
     constexpr int DIM = KT * 16;
     constexpr int ROW_BYTES = DIM * 2;
     constexpr int kStage = PANELS * kSlabBytes;
-    constexpr int NW = kBatchWaves;
+    constexpr int kGroups = 8 / NW;                        // 4-row DMA groups of a stage per wave
+    static_assert(NW == 2 || NW == 4 || NW == 8, "2, 4 or 8 waves share a stage");
     static_assert(KS_LAST % 2 == 0, "the last panel must hold whole k-steps of 32");
     static_assert(MAXU >= 1 && MAXU <= 4, "a wave holds up to four units: 4 x KT / 2 operand registers each");
     constexpr int KT32 = KT / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *const tokmax = smem + kPanelStages * kStage;                       // per-token max table: NW * MAXU units x 16 tokens x 16 B
+    char *const tokmax = smem + STAGES * kStage;                             // per-token max table: NW * MAXU units x 16 tokens x 16 B
     int *const rtab = reinterpret_cast<int *>(tokmax + NW * MAXU * kUnitTok * 16);   // the queries' token ranges: 64 x 2 ints
 
     // ---- which (query block, document range) is this workgroup?  (K1b's XCD-aware mapping)
@@ -437,10 +443,18 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const 
     const int n_units = (n_tok + kUnitTok - 1) / kUnitTok;
     const int my_nu = wave < n_units ? (n_units - 1 - wave) / NW + 1 : 0;    // wave-uniform
 
-    // ---- this wave's share of a stage's 8 * PANELS LDS-DMA wave-instructions (K1bP): rows 4 * wave .. + 3 of every panel-slab
-    const int my_src_full = panel_src_off(lane, wave & 3, ROW_BYTES, 16) + wave * 4 * ROW_BYTES;
-    const int my_src_last = panel_src_off(lane, wave & 3, ROW_BYTES, 2 * KS_LAST) + wave * 4 * ROW_BYTES;
-    const int my_lds = wave * 1024;
+    // ---- this wave's share of a stage's 8 * PANELS LDS-DMA wave-instructions (K1bP): rows 4 g .. + 3 of every panel-slab for the
+    // row groups g = wave, wave + NW, ...
+    // (arrays of the fixed size 4, of which kGroups are used: with the dependent extent [kGroups] hipcc's HOST pass silently drops the
+    // kernel's definition -- the handle stays an undefined symbol of the library; ROCm 7.2)
+    int my_src_full[4], my_src_last[4], my_lds[4];
+#pragma unroll
+    for (int i = 0; i < kGroups; ++i) {
+        const int grp = wave + NW * i;
+        my_src_full[i] = panel_src_off(lane, grp & 3, ROW_BYTES, 16) + grp * 4 * ROW_BYTES;
+        my_src_last[i] = panel_src_off(lane, grp & 3, ROW_BYTES, 2 * KS_LAST) + grp * 4 * ROW_BYTES;
+        my_lds[i] = grp * 1024;
+    }
     int rd_off[2][kKSteps16];
     slab_rd_offsets16(lane, rd_off);
 
@@ -466,10 +480,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const 
         char *dst = smem + p_slot * kStage;
         const int soff = p_row * ROW_BYTES;               // rows past the document end read as zeros (bounds check)
 #pragma unroll
-        for (int u = 0; u < PANELS; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + my_lds + u * kSlabBytes), 16,
-                                                     u == PANELS - 1 ? my_src_last : my_src_full, soff + u * kPanelBytes, 0, 0);
-        p_slot = (p_slot + 1 == kPanelStages) ? 0 : p_slot + 1;
+        for (int i = 0; i < kGroups; ++i)
+#pragma unroll
+            for (int u = 0; u < PANELS; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + my_lds[i] + u * kSlabBytes), 16,
+                                                         u == PANELS - 1 ? my_src_last[i] : my_src_full[i], soff + u * kPanelBytes, 0, 0);
+        p_slot = (p_slot + 1 == STAGES) ? 0 : p_slot + 1;
         p_row += kSlabRows;
         if (p_row >= p_len) {
             ++p_idx;
@@ -478,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const 
         return true;
     };
 #pragma unroll
-    for (int i = 0; i < kPanelStages - 1; ++i) produce();
+    for (int i = 0; i < STAGES - 1; ++i) produce();
 
     // ---- the block's units (B operands, [unit][k-step of 32]), loaded behind the first stages' LDS-DMA requests
     bf16x8 qf[MAXU][KT32];
@@ -552,12 +568,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch_panels_flat_kernel(const 
         for (int t = 0; t < NUA; ++t) m[t] = -INFINITY;
         for (int s = 0; s < nslab; ++s) {
             // my share of this stage has landed once at most (stages - 2) later stages of mine are still in flight
-            if (p_idx < d_hi) wait_vmcnt<PANELS * (kPanelStages - 2)>(); else wait_vmcnt<0>();
+            if (p_idx < d_hi) wait_vmcnt<PANELS * kGroups * (STAGES - 2)>(); else wait_vmcnt<0>();
             lds_barrier();                  // everyone's share landed; everyone is done reading the previous stage (and has written its maxima)
             produce();                      // refill the stage that was read in the previous iteration
             if (s == 0 && pend_doc >= 0) reduce_doc(pend_doc, pend_clamp);   // the previous document's token sums, behind its barrier
             const char *st = smem + c_slot * kStage;
-            c_slot = (c_slot + 1 == kPanelStages) ? 0 : c_slot + 1;
+            c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
             if constexpr (NU > 0) {
                 UnitAcc acc[NUA];
 #pragma unroll

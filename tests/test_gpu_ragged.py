@@ -258,7 +258,8 @@ def test_flat_forward_captures_in_a_hipgraph(amd):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Width 320 (ColQwen3: colpali_engine/models/qwen3/colqwen3/modeling_colqwen3.py:48) on the flat layout: K1bPF (maxsim_panels.hip),
-# one shape -- 8 waves x <= 4 units per query block (512 tokens, 64 queries) -- plus K1sP for a uniform call of <= 4 token tiles.
+# 8 waves x <= 4 units per query block (512 tokens, 64 queries) and, since round 6, ONE block of 2 waves (<= 8 units, <= 16 queries) or
+# 4 waves (<= 16 units, <= 32 queries) for the small batches -- plus K1sP for a uniform call of <= 4 token tiles.
 WIDE = 320
 PLANS_WIDE = [
     ([5], "one query, one unit"),
@@ -277,6 +278,14 @@ PLANS_WIDE = [
     ([512], "one query filling a block"),
     ([0, 19, 0, 40], "empty queries score 0"),
     ([40] * 40, "1600 tokens: four blocks"),
+    ([40] * 4, "160 tokens = 10 units: the four-wave shape, 3 + 3 + 2 + 2"),
+    ([25] * 8, "200 tokens = 13 units on four waves, queries straddling units"),
+    ([16] * 16, "16 units and 16 queries: four waves, every wave holds 4"),
+    ([8] * 32, "32 queries of 8 tokens: the four-wave shape at its query limit"),
+    ([8] * 33, "33 queries: one more than four waves reduce -- the eight-wave shape"),
+    ([7] * 17, "119 tokens = 8 units but 17 queries: four waves, not two"),
+    ([64, 64], "128 tokens = 8 units in two queries: the two-wave shape, every wave holds 4"),
+    ([1] * 16, "16 one-token queries in one unit on two waves (the second wave idles)"),
 ]
 
 

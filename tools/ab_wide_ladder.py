@@ -8,13 +8,14 @@ import colpali_amd as amd
 from colpali_amd.corpus import PackedCorpus
 
 dev = torch.device("cuda:0")
-for dim, n_docs in ((320, 4096), (128, 10240)):
+import os as _os
+for dim, n_docs in (((320, 4096),) if _os.environ.get('AB_ONLY_320') else ((320, 4096), (128, 10240))):
     g = torch.Generator(device=dev).manual_seed(11)
     blob = torch.nn.functional.normalize(torch.randn((n_docs * 1024, dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
     corpus = PackedCorpus(blob=blob, offsets=(torch.arange(n_docs + 1, dtype=torch.int64) * 1024).to(torch.int32).to(dev), clamp0=None,
                           lengths=torch.full((n_docs,), 1024, dtype=torch.int64))
-    for nq in (4, 8, 10, 12, 16, 20, 32, 40, 64, 1000):
-        for L in (32, 40):
+    for nq in ((4, 5, 8, 10, 12, 16) if _os.environ.get('AB_ONLY_320') else (4, 8, 10, 12, 16, 20, 32, 40, 64, 1000)):
+        for L in ((25, 32, 40) if _os.environ.get('AB_ONLY_320') else (32, 40)):
             tok = torch.nn.functional.normalize(torch.randn((nq * L, dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
             q = amd.pack_queries(list(tok.split([L] * nq)), dev)
             scores = torch.empty((nq, n_docs), dtype=torch.float32, device=dev)
