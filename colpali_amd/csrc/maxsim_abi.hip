@@ -1078,7 +1078,7 @@ int panels_dispatch(const FwdCall &c) {
 }
 
 
-// ---- K1bPF: the flat token layout at width 320 (maxsim_panels.hip).  One shape: 8 waves x <= 4 units, query blocks of whole queries
+// ---- K1bPF: the flat token layout at width 320 (maxsim_panels.hip).  8 waves x <= 4 units (round 6: or ONE block of 2 / 4 waves for small batches), query blocks of whole queries
 // (<= 512 tokens, <= 64 queries), filled greedily in query order and re-cut evenly like K1b's.
 constexpr int kPanelsFlatMaxU = 4;
 constexpr int kPanelsFlatMaxTokens = msim::kBatchWaves * kPanelsFlatMaxU * msim::kUnitTok;      // 512

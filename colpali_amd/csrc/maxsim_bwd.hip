@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dd_kernel(const char *__restri
 // (Round 6, measured and NOT kept: a "sorted" form of the kernel above -- the document's entries sorted once by (winning row, entry) with
 // a bitonic sort in LDS, then every output row adding exactly its own entries -- one pass over the entries instead of one per 64-row
 // range.  74.9 us against 61.3 us under ColbertLoss's dense gradient at config 5's shape and 59.7 against 14.4 us under the pairwise
-// loss: 55 barrier-separated sort steps plus a chain of dependent LDS / L2 reads per row are worse than re-scanning 1024 entries.)
+// loss: 55 barrier-separated sort steps plus a chain of dependent LDS / L2 reads per row are worse than re-scanning 1024 entries.  Also measured and not kept: four hit lists by row class r & 3, one per wave, every lane two
+// columns per hit (4-byte loads), eight hits in flight, the document's pair info cached in LDS -- 60.3 us against 61.8 (ColbertLoss) and 16.5
+// against 14.4 (pairwise): the hit loop is not where this kernel's time goes.)
 
 // ---- dD, dense form: SHORT documents (<= kBwdRows rows: one row range) with LONG entry lists -- the symmetric direction of the
 // reference trainer (trainer/contrastive_trainer.py:202-206: pages as query_embeddings [B, 780, 128], queries as doc_embeddings
