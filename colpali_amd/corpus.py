@@ -13,6 +13,7 @@ The reference re-pads and re-uploads every passage block for every query block
 from __future__ import annotations
 
 import ctypes
+import operator
 import os
 import threading
 from dataclasses import dataclass
@@ -309,14 +310,32 @@ def copy_stream(device: torch.device) -> torch.cuda.Stream:
     return st
 
 
+_dim_of = torch.Tensor.dim
+_dtype_of = operator.attrgetter("dtype")
+_shape_of = operator.attrgetter("shape")
+_is_cpu = operator.attrgetter("is_cpu")
+_is_contig = torch.Tensor.is_contiguous
+_data_ptr = torch.Tensor.data_ptr
+
+
 def host_list_image(ps: Sequence[torch.Tensor], what: str = "passages"):
     """ONE pass over a list of host tensors: the reference's checks (2-D, one dtype, one width) and what the upload needs --
     (keep-alive list, source addresses uint64 [n], rows int64 [n], dim, dtype) -- or None when a tensor does not live on the host.
     (A thousand pages x a handful of attribute reads each is ~1 ms of Python: it is done once, not once per helper.)"""
-    import numpy as np
-
     first = ps[0]
     dtype, dim = first.dtype, (first.shape[1] if first.dim() == 2 else -1)
+    # the common case in C-speed passes (round 6): a per-page Python loop with seven attribute reads was 0.6 ms of a 4-7 ms call for
+    # 1000 pages; `map` over attrgetters is ~2.5 x faster.  Anything unusual (a non-2-D page, a second dtype or width, a device tensor,
+    # a non-contiguous page) falls through to the loop below, which raises the reference's errors in the reference's order.
+    if dim > 0 and type(ps) in (list, tuple):
+        n = len(ps)
+        if (set(map(_dim_of, ps)) == {2} and set(map(_dtype_of, ps)) == {dtype} and all(map(_is_cpu, ps))
+                and all(map(_is_contig, ps))):
+            shapes = np.array(list(map(_shape_of, ps)), dtype=np.int64).reshape(n, 2)
+            if bool((shapes[:, 1] == dim).all()):
+                _check_embeddings(first, what)
+                srcs = np.fromiter(map(_data_ptr, ps), dtype=np.uint64, count=n)
+                return list(ps), srcs, np.ascontiguousarray(shapes[:, 0]), int(dim), dtype
     keep = []
     for p in ps:
         if p.dim() != 2:
