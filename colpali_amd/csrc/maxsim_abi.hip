@@ -2108,7 +2108,7 @@ int msim_pool_cluster(int dtype, const void *E, const int32_t *d_off, int n_page
     if (pool_factor < 1) return fail(MSIM_EINVAL, "pool_factor must be >= 1");
     static const int32_t dummy_off[2] = {0, 0};
     if (int rc = check_smooth(E, E, dummy_off, dtype, dim, 1, 1.0f)) return rc;      // row layout contract of the generic kernels
-    if (max_rows > msim::kPoolMaxN) return fail(MSIM_EUNSUPPORTED, "a page of %d rows: at most %d are supported", max_rows, msim::kPoolMaxN);
+    if (max_rows > msim::kPoolMaxRows) return fail(MSIM_EUNSUPPORTED, "a page of %d rows: at most %d are supported", max_rows, msim::kPoolMaxRows);
     if (n_pages > 65535) return fail(MSIM_EUNSUPPORTED, "at most 65535 pages per call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     msim::PoolArgs a{n_pages, dim, dim * elem_bytes(dtype), pool_factor};
@@ -2123,10 +2123,19 @@ int msim_pool_cluster(int dtype, const void *E, const int32_t *d_off, int n_page
         const int tiles = (max_rows + 15) / 16;
         hipLaunchKernelGGL(msim::pool_pdist_kernel, dim3(tiles, tiles, n_pages), dim3(256), 0, st, d_off, ws_off, X_ws, D_ws);
     }
-    static std::atomic<int> configured[kMaxDevices];
-    if (int rc = allow_lds(msim::pool_cluster_kernel, (int)sizeof(msim::PoolLds), configured)) return rc;
-    hipLaunchKernelGGL(msim::pool_cluster_kernel, dim3(n_pages), dim3(msim::kPoolThreads), sizeof(msim::PoolLds), st, d_off, ws_off, D_ws,
-                       labels, n_clusters, pool_factor);
+    // pages of at most kPoolMaxN rows keep the clustering state in LDS; a call with a longer page runs the variant whose long pages
+    // keep it in their (by then dead) region of X_ws
+    if (max_rows > msim::kPoolMaxN) {
+        static std::atomic<int> configured_big[kMaxDevices];
+        if (int rc = allow_lds(msim::pool_cluster_kernel<true>, (int)sizeof(msim::PoolLds), configured_big)) return rc;
+        hipLaunchKernelGGL(msim::pool_cluster_kernel<true>, dim3(n_pages), dim3(msim::kPoolThreads), sizeof(msim::PoolLds), st, d_off, ws_off,
+                           X_ws, D_ws, labels, n_clusters, pool_factor);
+    } else {
+        static std::atomic<int> configured[kMaxDevices];
+        if (int rc = allow_lds(msim::pool_cluster_kernel<false>, (int)sizeof(msim::PoolLds), configured)) return rc;
+        hipLaunchKernelGGL(msim::pool_cluster_kernel<false>, dim3(n_pages), dim3(msim::kPoolThreads), sizeof(msim::PoolLds), st, d_off, ws_off,
+                           X_ws, D_ws, labels, n_clusters, pool_factor);
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(MSIM_ELAUNCH, "token pooling launch: %s", hipGetErrorString(err));
     return MSIM_OK;

@@ -24,6 +24,7 @@
 namespace msim {
 
 constexpr int kPoolMaxN = 2048;           // rows of one page the cluster kernel holds in LDS
+constexpr int kPoolMaxRows = 32768;       // rows of one page at all (n^2 int32 grid / workspace arithmetic; 12.9 GB of workspace at the cap)
 constexpr int kPoolThreads = 256;
 
 struct PoolArgs {
@@ -124,6 +125,15 @@ struct PoolLds {
     double bcast_d;
 };
 
+// A page above kPoolMaxN rows keeps the same state in global memory: the page's own region of the fp32 workspace X, which nothing reads
+// after pool_pdist_kernel (4 n^2 bytes; the state is at most 72 n).  The reduction scratch stays in LDS.
+struct PoolBig {
+    double *zdist, *mc;
+    int *zx, *zy, *zorder, *size, *chain, *parent;
+    double *red_val;
+    int *red_idx;
+};
+
 // Ward's Lance-Williams update exactly as scipy's _ward evaluates it (left to right, no contraction)
 __device__ __forceinline__ double ward_update(double d_xi, double d_yi, double d_xy, int nx, int ny, int ni) {
 #pragma clang fp contract(off)
@@ -143,27 +153,10 @@ __device__ __forceinline__ double ward_update(double d_xi, double d_yi, double d
     return sqrt(r);
 }
 
-__global__ __launch_bounds__(kPoolThreads) void pool_cluster_kernel(const int32_t *__restrict__ d_off,
-                                                                    const int64_t *__restrict__ ws_off, double *__restrict__ Dm,
-                                                                    int32_t *__restrict__ labels,      // [total rows], 0-based
-                                                                    int32_t *__restrict__ n_clusters,  // [n_pages]
-                                                                    int pool_factor) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PoolLds &L = *reinterpret_cast<PoolLds *>(smem_raw);
-    const int c = blockIdx.x;
-    const int r0 = d_off[c];
-    const int n = d_off[c + 1] - r0;
+template <class State>
+__device__ __forceinline__ void pool_cluster_page(State &L, const int n, const int t_max, double *__restrict__ D, int32_t *__restrict__ lab,
+                                                  int32_t *__restrict__ n_cluster_out) {
     const int tid = threadIdx.x;
-    int32_t *lab = labels + r0;
-    if (n <= 0) { if (tid == 0) n_clusters[c] = 0; return; }
-    int t_max = n / pool_factor;
-    t_max = t_max < 1 ? 1 : t_max;
-    if (n == 1 || pool_factor == 1 || t_max >= n) {        // nothing to merge: every row is its own cluster, in index order
-        for (int i = tid; i < n; i += kPoolThreads) lab[i] = i;
-        if (tid == 0) n_clusters[c] = n;
-        return;
-    }
-    double *D = Dm + ws_off[c];
 
     for (int i = tid; i < n; i += kPoolThreads) L.size[i] = 1;
     __syncthreads();
@@ -355,8 +348,57 @@ __global__ __launch_bounds__(kPoolThreads) void pool_cluster_kernel(const int32_
             if (leader == root) leader = -1;
             --sp;
         }
-        n_clusters[c] = n_cluster;
+        *n_cluster_out = n_cluster;
     }
+}
+
+// One workgroup per page.  BIG = false: every page has at most kPoolMaxN rows and its state lives in LDS (dynamic, sizeof(PoolLds)).
+// BIG = true: longer pages carve the same arrays out of their X region (see PoolBig); shorter pages of the same call still use LDS.
+template <bool BIG>
+__global__ __launch_bounds__(kPoolThreads) void pool_cluster_kernel(const int32_t *__restrict__ d_off,
+                                                                    const int64_t *__restrict__ ws_off, float *__restrict__ X,
+                                                                    double *__restrict__ Dm,
+                                                                    int32_t *__restrict__ labels,      // [total rows], 0-based
+                                                                    int32_t *__restrict__ n_clusters,  // [n_pages]
+                                                                    int pool_factor) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PoolLds &L = *reinterpret_cast<PoolLds *>(smem_raw);
+    const int c = blockIdx.x;
+    const int r0 = d_off[c];
+    const int n = d_off[c + 1] - r0;
+    const int tid = threadIdx.x;
+    int32_t *lab = labels + r0;
+    if (n <= 0) { if (tid == 0) n_clusters[c] = 0; return; }
+    int t_max = n / pool_factor;
+    t_max = t_max < 1 ? 1 : t_max;
+    if (n == 1 || pool_factor == 1 || t_max >= n) {        // nothing to merge: every row is its own cluster, in index order
+        for (int i = tid; i < n; i += kPoolThreads) lab[i] = i;
+        if (tid == 0) n_clusters[c] = n;
+        return;
+    }
+    double *D = Dm + ws_off[c];
+    if constexpr (BIG) {
+        if (n > kPoolMaxN) {
+            int p2 = 1;
+            while (p2 < n - 1) p2 <<= 1;                     // the bitonic sort pads the merge list to a power of two
+            char *p = reinterpret_cast<char *>(X + ws_off[c]);
+            p += (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+            PoolBig B;
+            B.zdist = reinterpret_cast<double *>(p);  p += (size_t)p2 * 8;
+            B.mc = reinterpret_cast<double *>(p);     p += (size_t)p2 * 8;
+            B.zx = reinterpret_cast<int *>(p);        p += (size_t)p2 * 4;
+            B.zy = reinterpret_cast<int *>(p);        p += (size_t)p2 * 4;
+            B.zorder = reinterpret_cast<int *>(p);    p += (size_t)p2 * 4;
+            B.size = reinterpret_cast<int *>(p);      p += (size_t)n * 4;
+            B.chain = reinterpret_cast<int *>(p);     p += (size_t)n * 4;
+            B.parent = reinterpret_cast<int *>(p);
+            B.red_val = L.red_val;
+            B.red_idx = L.red_idx;
+            pool_cluster_page(B, n, t_max, D, lab, n_clusters + c);
+            return;
+        }
+    }
+    pool_cluster_page(L, n, t_max, D, lab, n_clusters + c);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .scoring import get_torch_device
 
-_MAX_ROWS = 2048
+_MAX_ROWS = 32768                   # msim_pool_cluster's cap (a page above 2048 rows keeps its clustering state in HBM instead of LDS)
 _WS_BUDGET_BYTES = 4 << 30          # fp32 + fp64 [n, n] workspaces of the pages clustered in one launch
 
 
@@ -55,7 +55,8 @@ def cluster_pages(blob: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tens
     if n_pages == 0:
         return labels[:0], n_clusters[:0]
     if int(lengths.max()) > _MAX_ROWS:
-        raise NotImplementedError(f"token pooling: a page of {int(lengths.max())} rows; at most {_MAX_ROWS} are supported")
+        raise NotImplementedError(f"token pooling: a page of {int(lengths.max())} rows; at most {_MAX_ROWS} are supported "
+                                  "(the [n, n] float64 distance matrix of such a page is above 8 GiB)")
     sq = lengths.to(torch.int64) ** 2
     start = 0
     offs_host = torch.zeros(n_pages + 1, dtype=torch.int64)

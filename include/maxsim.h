@@ -425,7 +425,8 @@ int msim_sim_matrix(int dtype, const void *A, int n_a, const void *B, int n_b, i
  * msim_pool_cluster: labels[r0 + i] = 0-based flat cluster of row i of page c (r0 = d_off[c]), numbered as SciPy numbers
  *   them; n_clusters[c] = number of clusters (<= max(n_c / pool_factor, 1)).
  *   E [rows, dim] packed pages (bf16 | f16 | f32, rows a multiple of 32 bytes), d_off int32 [n_pages + 1];
- *   max_rows >= the longest page (<= 2048); ws_off int64 [n_pages + 1] = exclusive prefix sums of n_c * n_c (element offsets
+ *   max_rows >= the longest page (<= 32768; pages of at most 2048 rows keep the clustering state in LDS, longer ones in their own
+ *   region of X_ws, which is dead after the distance pass); ws_off int64 [n_pages + 1] = exclusive prefix sums of n_c * n_c (element offsets
  *   of page c in both workspaces); X_ws fp32 and D_ws fp64 each of ws_off[n_pages] elements.
  * msim_pool_reduce: out[out_off[c] + k, :] = normalize(mean of the rows of page c labelled k), k < out_off[c+1] - out_off[c],
  *   in E's dtype; `dim` logical columns, ld_in / ld_out = elements between consecutive rows of E / out.

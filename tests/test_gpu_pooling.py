@@ -125,3 +125,38 @@ def test_tensor_input_padding_and_api_contract(amd):
         pooler.pool_embeddings([a[:1].cuda()], pool_factor=2)
     with pytest.raises(ValueError, match="list of 2D tensors or a 3D tensor"):
         pooler.pool_embeddings(a.cuda(), pool_factor=2)
+
+
+def test_pages_above_the_lds_capacity_keep_their_state_in_hbm(amd):
+    """The reference has no page-size limit (hierarchical_token_pooling.py:83-146).  Pages above 2048 rows run the cluster kernel
+    with its state in HBM; a short page of the same call still takes the LDS form.  Labels must equal SciPy's: once on a
+    page with real cluster structure, once on exact-Gram inputs with massive ties."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+
+    warnings.simplefilter("ignore")
+    g = torch.Generator().manual_seed(2600)
+    proto = torch.nn.functional.normalize(torch.randn(90, 128, generator=g), dim=-1)
+    big = torch.nn.functional.normalize(proto[torch.randint(0, 90, (2600,), generator=g)] + 0.2 * torch.randn(2600, 128, generator=g), dim=-1)
+    rng = np.random.default_rng(11)
+    ties = torch.from_numpy((rng.integers(-2, 3, size=(2300, 16)) / 4.0).astype(np.float32))
+    small = big[:300].clone()
+    pages = [big, small, ties]
+    pooler = amd.HierarchicalTokenPooler()
+    res = pooler.pool_embeddings([big.cuda(), small.cuda()], pool_factor=3, return_dict=True)
+    res2 = pooler.pool_embeddings([ties.cuda()], pool_factor=3, return_dict=True)              # (another width: a call of its own)
+    res.pooled_embeddings.extend(res2.pooled_embeddings)
+    res.cluster_id_to_indices.extend(res2.cluster_id_to_indices)
+    for i, page in enumerate(pages):
+        m = page.shape[0]
+        X = np.float32(1) - torch.mm(page, page.t()).numpy()
+        want = fcluster(linkage(X, metric="euclidean", method="ward"), t=max(m // 3, 1), criterion="maxclust") - 1
+        got = _labels_from_mapping(res.cluster_id_to_indices[i], m)
+        np.testing.assert_array_equal(got, want, err_msg=f"page {i} of {m} rows")
+        k = int(want.max()) + 1
+        assert res.pooled_embeddings[i].shape == (k, page.shape[1])
+        if i < 2:
+            pooled = torch.stack([torch.nn.functional.normalize(page[torch.from_numpy(want == c)].mean(dim=0), p=2, dim=-1) for c in range(k)])
+            assert _pooled_close(res.pooled_embeddings[i], pooled.numpy(), torch.float32)
+    with pytest.raises(NotImplementedError, match="at most 32768"):
+        amd.pooling.cluster_pages(torch.zeros((1, 128), device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"),
+                                  torch.tensor([40000]), 3)

@@ -68,7 +68,7 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
     if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
     if (rows < 256LL * 8 * 5 * 32) return fail(MSIM_EINVAL, "the MFMA probe needs at least %d rows of operands", 256 * 8 * 5 * 32);
     if (variant >= 8 && rows < 256LL * 16 * 3 * 32) return fail(MSIM_EINVAL, "MFMA probe variants 8..11 need at least %d rows of operands", 256 * 16 * 3 * 32);
-    if (iters <= 0 || variant < 0 || variant > 24) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
+    if (iters <= 0 || variant < 0 || variant > 28) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X);
     int rc;
@@ -100,6 +100,12 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
         case 22: rc = run_probe_mix<6, 4, true, true, 1>(x, iters, sink, st); break;
         case 23: rc = run_probe_mix<8, 4, false, false, 1>(x, iters, sink, st); break;  // A in registers, deferred folds
         case 24: rc = run_probe_mix<5, 8, true>(x, iters, sink, st); break;              // two waves per SIMD x FIVE tiles (4 of them in AGPRs)
+        // round 6, the ridge (10 queries x 32 tokens = 20 units = 10 tiles): ONE 512-register wave per SIMD holding all of them
+        // (320 B-operand registers, 192 of them AGPRs), the body a barrier-free band would run -- no DMA, no barrier: an upper bound
+        case 25: rc = run_probe_mix<10, 4, true>(x, iters, sink, st); break;
+        case 26: rc = run_probe_mix<10, 4, true, true>(x, iters, sink, st); break;
+        case 27: rc = run_probe_mix<10, 4, true, true, 1>(x, iters, sink, st); break;
+        case 28: rc = run_probe_mix<10, 4, false, false, 1>(x, iters, sink, st); break;
         default: rc = run_probe_mfma<true, true>(x, iters, sink, st); break;
     }
     if (rc) return fail(MSIM_ELAUNCH, "probe_mfma_kernel launch failed (variant %d)", variant);
