@@ -70,7 +70,7 @@ def dropin_numbers(amd):
             h2d = min(h2d, time.perf_counter() - t0)
         del pin, devb
         breakdown = {"p95_ms": calls[int(len(calls) * 0.95)] * 1e3, "max_ms": calls[-1] * 1e3, "min_ms": calls[0] * 1e3, "calls": len(calls),
-                     "pack_queries_ms": med(0), "checks_ms": med(1), "gather_and_h2d_issue_loop_ms": med(2), "gpu_tail_ms_last_h2d_kernel_d2h": med(3),
+                     "query_checks_ms": med(0), "checks_ms": med(1), "gather_and_h2d_issue_loop_ms": med(2), "gpu_tail_ms_last_h2d_kernel_d2h": med(3),
                      "corpus_mb": nbytes / 1e6, "pinned_h2d_gbs_this_box": nbytes / h2d / 1e9, "h2d_floor_ms": h2d * 1e3,
                      "frac_of_h2d_roof": h2d / ours,
                      "what": "the call's floor is the PCIe upload of the corpus; checks, native gather and the MaxSim launches overlap it"}

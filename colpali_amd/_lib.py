@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 def dtype_code(dtype) -> int:
@@ -114,6 +114,10 @@ def lib() -> ctypes.CDLL:
     L.msim_dense_t_bwd.restype = i32
     L.msim_host_gather_range.argtypes = [vp, vp, vp, i64, i64, i64, i32]
     L.msim_host_gather_range.restype = i32
+    L.msim_host_gather_range_begin.argtypes = [vp, vp, vp, i64, i64, i64, i32]
+    L.msim_host_gather_range_begin.restype = i32
+    L.msim_host_gather_range_wait.argtypes = []
+    L.msim_host_gather_range_wait.restype = i32
     L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.msim_pairs_argmax.restype = i32
     L.msim_allpairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, vp, vp]

@@ -126,6 +126,8 @@ _EDGE_CHUNK_BYTES = _env_int("COLPALI_AMD_EDGE_CHUNK_MB", 16, 0, 1024) << 20    
 # next chunk are memcpy'd into the other, so a call costs max(host memcpy, PCIe upload) instead of their sum -- 32 MiB per half
 # is large enough for both to run at full speed and small enough for a 264 MB corpus (1000 ColPali pages) to overlap almost fully
 STAGING_BYTES = _env_int("COLPALI_AMD_STAGING_MB", 64, 2, 16384) << 20
+# 0: every chunk's gather blocks the calling thread before its copy is issued, as before round 6 (A/B knob: tools/dropin_phases.py)
+_ASYNC_GATHER = _env_int("COLPALI_AMD_ASYNC_GATHER", 1, 0, 1) == 1
 
 
 class _Staging:
@@ -221,35 +223,68 @@ class _Staging:
         return dev
 
 
-    def upload_image(self, srcs, prefix, n: int, dst_bytes: torch.Tensor, side_stream, on_chunk=None) -> None:
+    def upload_image(self, srcs, prefix, n: int, dst_bytes: Optional[torch.Tensor], side_stream, on_chunk=None, prepare=None) -> None:
         """The byte image of n host buffers (buffer i = image bytes prefix[i] .. prefix[i+1]-1 at address srcs[i]; numpy uint64 /
-        int64 arrays) -> `dst_bytes` (a uint8 device view of the same length), through the two pinned halves: native threads gather
-        chunk k + 1 into one half (msim_host_gather_range: a persistent pool, one call per chunk, nothing per page on the Python side)
-        while the other half is on its way to the GPU on `side_stream`.  The halves alternate ACROSS calls too, so back-to-back
-        uploads keep overlapping.  `on_chunk(bytes_uploaded_so_far)` runs after each chunk's copy has been issued (the caller
-        launches work on what has arrived: scoring.py)."""
+        int64 arrays) -> `dst_bytes` (a uint8 device view of the same length), through the two pinned halves: a native thread gathers
+        chunk k + 1 into one half (msim_host_gather_range_begin / _wait: a persistent pool, one request per chunk, nothing per page on
+        the Python side) while the other half is on its way to the GPU on `side_stream` AND while this thread issues that copy and runs
+        `on_chunk(bytes_uploaded_so_far)` -- the caller launches work on what has arrived (scoring.py).  The halves alternate ACROSS calls
+        too, so back-to-back uploads keep overlapping.  `prepare()`, if given, runs on this thread while the FIRST chunk is being
+        gathered (nothing else can overlap that gather: no upload is running yet) and returns the destination when `dst_bytes` is None
+        -- the drop-in packs its queries and allocates its device buffers there (round 6: 0.2-0.3 ms off the front of the call)."""
         total = int(prefix[n])
         if total == 0:
+            if prepare is not None:
+                prepare()
             return
         L = _lib_mod.lib()
         with self.lock:
             half = self._halves(total)
             base = self.buf.data_ptr()
-            for c0, c1 in _chunk_schedule(total, half):
+            chunks = _chunk_schedule(total, half)
+            in_flight = False
+
+            def begin(k: int) -> int:
                 h = self.next_half
                 self.next_half ^= 1
                 if self.events[h] is not None:
                     self.events[h].synchronize()          # the previous upload has left this half
-                rc = L.msim_host_gather_range(base + h * half, srcs.ctypes.data, prefix.ctypes.data, n, c0, c1, _COPY_THREADS)
+                c0, c1 = chunks[k]
+                rc = L.msim_host_gather_range_begin(base + h * half, srcs.ctypes.data, prefix.ctypes.data, n, c0, c1, _COPY_THREADS)
                 if rc != 0:
-                    raise RuntimeError(f"msim_host_gather_range failed: {L.msim_host_last_error().decode()}")
-                with torch.cuda.stream(side_stream):
-                    dst_bytes[c0:c1].copy_(self.buf[h * half : h * half + (c1 - c0)], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(side_stream)
-                self.events[h] = ev
-                if on_chunk is not None:
-                    on_chunk(c1)
+                    raise RuntimeError(f"msim_host_gather_range_begin failed: {L.msim_host_last_error().decode()}")
+                return h
+
+            try:
+                if not _ASYNC_GATHER and prepare is not None:
+                    got = prepare()
+                    dst_bytes = got if dst_bytes is None else dst_bytes
+                h = begin(0)
+                in_flight = True
+                if _ASYNC_GATHER and prepare is not None:
+                    got = prepare()
+                    dst_bytes = got if dst_bytes is None else dst_bytes
+                for k, (c0, c1) in enumerate(chunks):
+                    rc = L.msim_host_gather_range_wait()
+                    in_flight = False
+                    if rc != 0:
+                        raise RuntimeError(f"msim_host_gather_range failed: {L.msim_host_last_error().decode()}")
+                    with torch.cuda.stream(side_stream):
+                        dst_bytes[c0:c1].copy_(self.buf[h * half : h * half + (c1 - c0)], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side_stream)
+                    self.events[h] = ev
+                    if _ASYNC_GATHER and k + 1 < len(chunks):   # the copy of chunk k is queued: gather k + 1 into the other half (waits
+                        h = begin(k + 1)                        # for chunk k - 1's copy to have left it) while this thread goes on below
+                        in_flight = True
+                    if on_chunk is not None:
+                        on_chunk(c1)
+                    if not _ASYNC_GATHER and k + 1 < len(chunks):
+                        h = begin(k + 1)
+                        in_flight = True
+            finally:
+                if in_flight:                             # never leave with the native thread still writing / reading the caller's pages
+                    L.msim_host_gather_range_wait()
 
 
 def _chunk_schedule(total: int, half: int):
@@ -567,8 +602,23 @@ def _flat_from_device_box(box: torch.Tensor, compact: bool) -> Optional["PackedQ
     return PackedQueries(tokens=tokens, offsets=off, offsets_host=oh)
 
 
+def check_query_list(qs: Sequence[torch.Tensor]) -> None:
+    """The checks pack_queries makes on a list of queries, on their own (the drop-in validates first and packs later, under the
+    first chunk of the corpus upload)."""
+    if len(qs) == 0:
+        raise ValueError("No queries provided")
+    for q in qs:
+        if q.dim() != 2:
+            raise ValueError("each query must be 2-D (sequence_length, dim)")
+        _check_embeddings(q, "queries")
+        if q.dtype != qs[0].dtype:
+            raise RuntimeError(f"expected queries of one dtype, got {qs[0].dtype} and {q.dtype}")
+        if q.shape[1] != qs[0].shape[1]:
+            raise RuntimeError(f"expected queries of one embedding width, got {qs[0].shape[1]} and {q.shape[1]}")
+
+
 def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.device, *, layout: str = "auto",
-                 compact: bool = True) -> Union[torch.Tensor, "PackedQueries"]:
+                 compact: bool = True, _checked: bool = False) -> Union[torch.Tensor, "PackedQueries"]:
     """Queries for the device.
 
     layout="flat" (what "auto" picks on the GPU for bf16 / f16 embeddings of width 128 or 320): a `PackedQueries` -- every query's
@@ -593,16 +643,8 @@ def pack_queries(qs: Union[torch.Tensor, Sequence[torch.Tensor]], device: torch.
             raise NotImplementedError("the flat query layout takes bf16 / f16 embeddings of width 128 (320) on the GPU, at most "
                                       f"{MAX_FLAT_QUERY_TOKENS} ({MAX_FLAT_QUERY_TOKENS_WIDE}) tokens per query")
         return _widen(qs.to(device, non_blocking=True)).contiguous()
-    if len(qs) == 0:
-        raise ValueError("No queries provided")
-    for q in qs:
-        if q.dim() != 2:
-            raise ValueError("each query must be 2-D (sequence_length, dim)")
-        _check_embeddings(q, "queries")
-        if q.dtype != qs[0].dtype:
-            raise RuntimeError(f"expected queries of one dtype, got {qs[0].dtype} and {q.dtype}")
-        if q.shape[1] != qs[0].shape[1]:
-            raise RuntimeError(f"expected queries of one embedding width, got {qs[0].shape[1]} and {q.shape[1]}")
+    if not _checked:
+        check_query_list(qs)
     dim = int(qs[0].shape[1])
     if layout != "box" and device.type == "cuda" and _is_flat_shape(qs[0].dtype, dim):
         if all(q.device.type == "cpu" for q in qs):

@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/maxsim.h"
@@ -549,6 +550,77 @@ static int host_gather_range_impl(void *dst, const void *const *src, const int64
     return MSIM_OK;
 }
 
+// The same gather, started and collected in two calls: the caller's thread (Python: the one that also issues the H2D copies and the
+// kernel launches of the chunks that have arrived) is free while chunk k + 1 is gathered.  ONE persistent driver thread runs the
+// requests in order (it is the "caller" of the pool's parallel region); one request may be in flight per process.  Failures are kept
+// for `wait`, which reports them on the waiting thread's error slot.
+class AsyncGather {
+   public:
+    static AsyncGather &get() {
+        static AsyncGather *g = new AsyncGather();       // leaked on purpose, like the pool
+        return *g;
+    }
+    int begin(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads) {
+        std::unique_lock<std::mutex> lk(m_);
+        if (busy_) return fail_host(MSIM_EINVAL, "a gather is already in flight: call msim_host_gather_range_wait first");
+        if (!started_ || pid_ != getpid()) {             // first use, or a forked child (threads do not survive a fork)
+            std::thread(&AsyncGather::driver, this).detach();
+            started_ = true;
+            pid_ = getpid();
+        }
+        req_ = Req{dst, src, prefix, n, lo, hi, n_threads};
+        busy_ = true;
+        have_ = true;
+        cv_.notify_all();
+        return MSIM_OK;
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        if (!busy_) return fail_host(MSIM_EINVAL, "no gather in flight");
+        done_.wait(lk, [&] { return !have_; });
+        busy_ = false;
+        if (rc_ != MSIM_OK) snprintf(g_host_err, sizeof(g_host_err), "%s", err_);
+        return rc_;
+    }
+
+   private:
+    struct Req {
+        void *dst;
+        const void *const *src;
+        const int64_t *prefix;
+        int64_t n, lo, hi;
+        int n_threads;
+    };
+    void driver() {
+        for (;;) {
+            Req r;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return have_; });
+                r = req_;
+            }
+            int rc;
+            try {
+                rc = host_gather_range_impl(r.dst, r.src, r.prefix, r.n, r.lo, r.hi, r.n_threads);
+            } catch (...) {
+                rc = fail_host(MSIM_ELAUNCH, "unexpected C++ exception in the gather thread");
+            }
+            std::unique_lock<std::mutex> lk(m_);
+            rc_ = rc;
+            if (rc != MSIM_OK) snprintf(err_, sizeof(err_), "%s", g_host_err);   // the driver's own thread-local message
+            have_ = false;
+            done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    Req req_{};
+    bool busy_ = false, have_ = false, started_ = false;
+    pid_t pid_ = 0;
+    int rc_ = MSIM_OK;
+    char err_[256] = "";
+};
+
 extern "C" {
 
 // nothing may unwind across the C ABI (through ctypes that terminates the process): allocation failures become an error code
@@ -580,5 +652,11 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
 int msim_host_gather_range(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads) {
     MSIM_HOST_GUARD(host_gather_range_impl(dst, src, prefix, n, lo, hi, n_threads))
 }
+
+int msim_host_gather_range_begin(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads) {
+    MSIM_HOST_GUARD(AsyncGather::get().begin(dst, src, prefix, n, lo, hi, n_threads))
+}
+
+int msim_host_gather_range_wait(void) { MSIM_HOST_GUARD(AsyncGather::get().wait()) }
 
 }  // extern "C"

@@ -15,8 +15,8 @@ from typing import List, Optional, Union
 import torch
 
 from . import _lib
-from .corpus import (PackedCorpus, PackedQueries, _check_embeddings, _staging, _widen, block_clamp0, copy_stream, host_list_image,
-                     pack_passages, pack_queries)
+from .corpus import (PackedCorpus, PackedQueries, _check_embeddings, _staging, _widen, block_clamp0, check_query_list, copy_stream,
+                     host_list_image, pack_passages, pack_queries)
 
 logger = logging.getLogger(__name__)
 
@@ -222,12 +222,18 @@ def score_multi_vector(
     # staging buffers (first touched here) and the thread that issues the copies -- runs on the GPU's own NUMA node for the length
     # of the call (colpali_amd/_lib.py: gpu_local_cpus); the caller's affinity is restored on the way out.
     with _lib.on_gpu_local_cpus(dev):
-        q = pack_queries(qs, dev)
+        checked = False
         if not isinstance(ps, torch.Tensor):
-            scores = _score_host_list_pipelined(q, ps, dev, batch_size, ref_rounding)
+            if not isinstance(qs, torch.Tensor):
+                check_query_list(qs)                  # the queries' errors come first, as before; they are PACKED under the first chunk's gather
+                checked = True
+            elif qs.dim() != 3:
+                raise ValueError("a query tensor must be 3-D (n_queries, max_len, dim)")
+            scores = _score_host_list_pipelined(qs, ps, dev, batch_size, ref_rounding, checked)
             if scores is not None:
                 assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
                 return scores
+        q = pack_queries(qs, dev, _checked=checked)
         cols = []
         for lo, hi in passage_ranges(ps, batch_size, _corpus_budget_bytes(dev)):
             corpus = pack_passages(ps[lo:hi], dev, batch_size=batch_size)
@@ -251,14 +257,15 @@ def _stamp(label: str) -> None:
 _PIPE_RANGE_BYTES = 48 << 20      # passage sub-ranges of about this size are scored while the next ones upload
 
 
-def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_rounding: bool) -> Optional[torch.Tensor]:
+def _score_host_list_pipelined(qs, ps, dev: torch.device, batch_size: int, ref_rounding: bool, qs_checked: bool = False) -> Optional[torch.Tensor]:
     """The drop-in call as evaluators make it -- a Python list of per-page HOST tensors (README.md:121-126) -- as one pipeline:
 
         one pass of checks -> [native gather of chunk k+1 into pinned memory | H2D of chunk k on a copy stream | MaxSim of the passage
         sub-ranges that have arrived, on the caller's stream] -> one D2H of the [n_q, n_p] matrix.
 
     The corpus is a 264 MB PCIe upload at BASELINE config 2's geometry (1000 pages x 1030 patches): the call's floor is that upload
-    (4.7 ms at the 57 GB/s this host's pinned H2D reaches); checks, gather and the kernels hide under it.  Sub-ranges are cut at
+    (4.7 ms at the 57 GB/s this host's pinned H2D reaches); checks, gather and the kernels hide under it.  The queries are packed and
+    every device buffer is allocated while the first chunk is being gathered (round 6).  Sub-ranges are cut at
     multiples of `batch_size`, and the clamp0 flags come from the same blocking, so every passage keeps the block mates the reference
     pads it with (processing_utils.py:175-178): results are bit-identical to scoring the packed corpus in one launch.  Returns None
     for inputs this road does not take (a tensor that is not on the host; a corpus above the device budget; rows that need zero
@@ -270,8 +277,13 @@ def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_ro
     if info is None:
         return None
     keep, srcs, rows, dim, dtype = info
-    if q.dtype != dtype:
-        raise RuntimeError(f"expected queries and passages of one dtype, got {q.dtype} and {dtype}")
+    q_is_box = isinstance(qs, torch.Tensor)
+    q_dtype = qs.dtype if q_is_box else qs[0].dtype
+    q_dim = int(qs.shape[2]) if q_is_box else int(qs[0].shape[1])
+    if q_is_box:
+        _check_embeddings(qs, "queries")
+    if q_dtype != dtype:
+        raise RuntimeError(f"expected queries and passages of one dtype, got {q_dtype} and {dtype}")
     if _lib.kernel_width(dim, dtype) != dim:
         return None
     n = len(keep)
@@ -284,33 +296,42 @@ def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_ro
         return None
     lengths = torch.from_numpy(rows)
     flags = block_clamp0(lengths, batch_size)
-    if bool((lengths == 0).any()):
+    if bool((rows == 0).any()):
         for j in range(0, n, batch_size):          # an all-empty block makes the reference's max() over an empty dim raise
-            if int(lengths[j: j + batch_size].max()) == 0:
+            if int(rows[j: j + batch_size].max()) == 0:
                 raise RuntimeError("max(): Expected reduction dim 3 to have non-zero size.")
-    n_q = len(q)
-    q_dim = q.tokens.shape[1] if isinstance(q, PackedQueries) else q.shape[2]
+    n_q = len(qs)
     if q_dim != dim:
         raise RuntimeError(f"queries have embedding width {q_dim}, the corpus {dim}")
     _stamp("checked")
     main = torch.cuda.current_stream(dev)
     side = copy_stream(dev)
+    # passage sub-ranges: whole blocks of `batch_size`, about _PIPE_RANGE_BYTES each, at most eight
+    n_blocks = (n + batch_size - 1) // batch_size
+    n_sub = max(1, min(n_blocks, 8, total // _PIPE_RANGE_BYTES))
+    cuts = sorted({min(n, ((n_blocks * i + n_sub - 1) // n_sub) * batch_size) for i in range(1, n_sub + 1)} | {n})
+    state = [0, 0]                               # first passage not yet scored, next cut
+    dv = {}                                      # what prepare() makes: q, blob, offsets, clamp0, out
+
     with torch.cuda.device(dev):
-        blob = torch.empty((total_rows, dim), dtype=dtype, device=dev)
-        blob.record_stream(side)   # written on the copy stream: whatever happens below, its memory is not reused before that stream is done
-        off_host = torch.zeros(n + 1, dtype=torch.int32)
-        off_host[1:] = torch.from_numpy((prefix[1:] // row_bytes).astype(np.int32))
-        offsets = off_host.to(dev, non_blocking=True)
-        clamp0 = flags.to(dev, non_blocking=True) if bool(flags.any()) else None
-        out = torch.empty((n_q, n), dtype=torch.float32, device=dev)
-        side.wait_stream(main)                       # the blob's memory may still be in use by earlier work of the caller's stream
-        # passage sub-ranges: whole blocks of `batch_size`, about _PIPE_RANGE_BYTES each, at most eight
-        n_blocks = (n + batch_size - 1) // batch_size
-        n_sub = max(1, min(n_blocks, 8, total // _PIPE_RANGE_BYTES))
-        cuts = sorted({min(n, ((n_blocks * i + n_sub - 1) // n_sub) * batch_size) for i in range(1, n_sub + 1)} | {n})
-        state = [0, 0]                               # first passage not yet scored, next cut
+
+        def prepare() -> torch.Tensor:
+            # runs while the native thread gathers the first chunk: query packing (its own small upload) and every allocation
+            dv["q"] = pack_queries(qs, dev, _checked=qs_checked)
+            blob = torch.empty((total_rows, dim), dtype=dtype, device=dev)
+            blob.record_stream(side)   # written on the copy stream: whatever happens below, its memory is not reused before that stream is done
+            off_host = torch.zeros(n + 1, dtype=torch.int32)
+            off_host[1:] = torch.from_numpy((prefix[1:] // row_bytes).astype(np.int32))
+            dv["blob"] = blob
+            dv["offsets"] = off_host.to(dev, non_blocking=True)
+            dv["clamp0"] = flags.to(dev, non_blocking=True) if bool(flags.any()) else None
+            dv["out"] = torch.empty((n_q, n), dtype=torch.float32, device=dev)
+            side.wait_stream(main)                       # the blob's memory may still be in use by earlier work of the caller's stream
+            _stamp("prepared")
+            return blob.view(torch.uint8).view(-1)
 
         def score_arrived(bytes_done: int) -> None:
+            q, blob, offsets, clamp0, out = dv["q"], dv["blob"], dv["offsets"], dv["clamp0"], dv["out"]
             while state[1] < len(cuts) and int(prefix[cuts[state[1]]]) <= bytes_done:
                 lo, hi = state[0], cuts[state[1]]
                 ev = torch.cuda.Event()
@@ -325,9 +346,9 @@ def _score_host_list_pipelined(q, ps, dev: torch.device, batch_size: int, ref_ro
                 state[0] = hi
                 state[1] += 1
 
-        _staging.of(dev).upload_image(srcs, prefix, n, blob.view(torch.uint8).view(-1), side, on_chunk=score_arrived)
+        _staging.of(dev).upload_image(srcs, prefix, n, None, side, on_chunk=score_arrived, prepare=prepare)
         _stamp("issued")
-        scores = out.cpu()
+        scores = dv["out"].cpu()
         _stamp("done")
     del keep
     return scores

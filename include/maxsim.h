@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 19
+#define MSIM_ABI_VERSION 20
 
 /* error codes */
 #define MSIM_OK 0
@@ -451,6 +451,12 @@ int msim_host_gather(void *dst, const void *const *src, const int64_t *dst_off, 
  * threads (no thread is started per call).  The upload path sends the image through a bounded pinned staging buffer chunk by chunk:
  * one call per chunk, nothing per page on the Python side. */
 int msim_host_gather_range(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads);
+/* The same gather in two calls: `begin` hands the request to a persistent native thread and returns at once, `wait` blocks until it is
+ * done and returns its result.  One request in flight per process (a second `begin` before `wait` is MSIM_EINVAL); the buffers must
+ * stay valid until `wait` returns.  The upload path gathers chunk k + 1 this way while the calling thread issues chunk k's H2D copy
+ * and the MaxSim launches of the passages that have arrived (colpali_amd/corpus.py: upload_image). */
+int msim_host_gather_range_begin(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads);
+int msim_host_gather_range_wait(void);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

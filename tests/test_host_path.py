@@ -202,6 +202,38 @@ def test_host_gather_range_copies_any_byte_range_of_the_virtual_concatenation():
     assert L.msim_host_gather_range(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), 5, 4, 2) == -1
 
 
+def test_host_gather_range_begin_wait_is_the_same_copy_on_a_native_thread():
+    """msim_host_gather_range_begin / _wait (round 6: the upload path gathers chunk k + 1 while the Python thread issues chunk k's copy
+    and launches): same bytes as the blocking call, one request in flight, failures reported by `wait`."""
+    import numpy as np
+
+    from colpali_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    sizes = [int(x) for x in rng.integers(1, 400_000, size=41)]
+    bufs = [rng.integers(0, 256, size=n, dtype=np.uint8) for n in sizes]
+    whole = np.concatenate(bufs)
+    srcs = np.asarray([b.ctypes.data for b in bufs], dtype=np.uint64)
+    prefix = np.zeros(len(bufs) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=prefix[1:])
+    total = int(prefix[-1])
+    assert L.msim_host_gather_range_wait() == -1 and b"no gather in flight" in L.msim_host_last_error()
+    for rep in range(20):                                 # back-to-back requests through the one driver thread
+        lo = (rep * 7919) % (total // 2)
+        hi = min(total, lo + 1 + (rep * 104729) % (total // 2))
+        dst = np.full(hi - lo + 8, 0xCD, dtype=np.uint8)
+        assert L.msim_host_gather_range_begin(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), lo, hi, 4) == 0
+        if rep == 0:                                      # a second request before the wait is refused, the first one is unharmed
+            assert L.msim_host_gather_range_begin(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), lo, hi, 4) == -1
+        assert L.msim_host_gather_range_wait() == 0
+        assert np.array_equal(dst[: hi - lo], whole[lo:hi]) and (dst[hi - lo:] == 0xCD).all()
+    dst = np.zeros(16, dtype=np.uint8)
+    assert L.msim_host_gather_range_begin(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, len(bufs), 0, total + 1, 2) == 0
+    assert L.msim_host_gather_range_wait() == -1 and b"range beyond the image" in L.msim_host_last_error()
+    assert L.msim_host_gather_range_wait() == -1          # nothing left in flight
+
+
 def test_thread_counts_follow_what_the_container_grants():
     """_lib.effective_cpus(): affinity and cgroup CPU quota, never more than the host reports (a GPU box shows 256 CPUs and grants 16:
     native thread counts taken from the host's count ran the quota dry and froze the process -- profiles/r05_logs/dropin_stalls.log)."""
