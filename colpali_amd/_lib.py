@@ -118,6 +118,8 @@ def lib() -> ctypes.CDLL:
     L.msim_host_gather_range_begin.restype = i32
     L.msim_host_gather_range_wait.argtypes = []
     L.msim_host_gather_range_wait.restype = i32
+    L.msim_host_threads_affinity.argtypes = [vp, i32]
+    L.msim_host_threads_affinity.restype = i32
     L.msim_pairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.msim_pairs_argmax.restype = i32
     L.msim_allpairs_argmax.argtypes = [i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i64, vp, vp]
@@ -302,6 +304,76 @@ class on_gpu_local_cpus:
             except Exception:
                 pass
         return False
+
+
+_SYS_MOVE_PAGES = 279          # x86-64
+
+
+def nodes_of_addresses(addrs) -> list:
+    """NUMA node of the page behind every address (move_pages(2) with a NULL node list only asks); [] when the kernel does not say."""
+    try:
+        n = len(addrs)
+        if n == 0:
+            return []
+        libc = ctypes.CDLL(None, use_errno=True)
+        pages = (ctypes.c_void_p * n)(*[int(a) & ~4095 for a in addrs])
+        status = (ctypes.c_int * n)()
+        libc.syscall.restype = ctypes.c_long
+        rc = libc.syscall(ctypes.c_long(_SYS_MOVE_PAGES), ctypes.c_int(0), ctypes.c_ulong(n), pages, ctypes.c_void_p(0), status, ctypes.c_int(0))
+        if rc != 0:
+            return []
+        return [int(x) for x in status if x >= 0]
+    except Exception:
+        return []
+
+
+_node_cpus = {}
+
+
+def node_cpus(node: int):
+    """CPUs of a NUMA node this process may run on (frozenset), or None."""
+    if node in _node_cpus:
+        return _node_cpus[node]
+    cpus = None
+    try:
+        local = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) & os.sched_getaffinity(0)
+        if len(local) >= 2:
+            cpus = frozenset(local)
+    except Exception:
+        cpus = None
+    _node_cpus[node] = cpus
+    return cpus
+
+
+_gather_threads_on = [None]      # the CPU set the library's host threads were last moved to (None: wherever they were created)
+GATHER_NODE_POLICY = os.environ.get("COLPALI_AMD_GATHER_NODE", "gpu")     # "gpu" | "pages" (tools/dropin_numa_pages.py flips it per run)
+
+
+def place_gather_threads(device, sample_addrs) -> None:
+    """The library's host threads (gather pool + driver thread) onto the NUMA node of the GPU THIS call targets -- explicitly, through
+    msim_host_threads_affinity, so that a process that drives GPUs on both sockets moves them per call and nothing depends on which
+    thread happened to start them (round-5 advisor finding).  Policy "pages" puts them next to the CALLER'S pages instead (one
+    move_pages(2) query of a few addresses): the round-5 review's suggestion, measured in round 6 and NOT the default -- with the page
+    tensors migrated to the other socket the call takes 6.5-7.0 ms with the threads on the GPU's node and 8.3 ms with the threads on
+    the pages' node (config 2 geometry; pages on the GPU's node: 6.1 ms; profiles/r06_logs/dropin_numa_pages.log): a gather that
+    WRITES the pinned staging buffer across the socket link loses more than one that reads the pages across it.  A hint only: any
+    failure leaves the threads where they are."""
+    if os.environ.get("COLPALI_AMD_NUMA", "1") == "0":
+        return
+    try:
+        want = gpu_local_cpus(device)
+        if GATHER_NODE_POLICY == "pages":
+            nodes = nodes_of_addresses(sample_addrs)
+            if nodes:
+                node = max(set(nodes), key=nodes.count)
+                want = node_cpus(node) or want
+        if want is None or want == _gather_threads_on[0]:
+            return
+        arr = (ctypes.c_int32 * len(want))(*sorted(want))
+        if lib().msim_host_threads_affinity(arr, len(want)) == 0:
+            _gather_threads_on[0] = want
+    except Exception:
+        pass
 
 
 def ptr(t) -> int:

@@ -15,6 +15,7 @@
 // generic vector type and cloned for AVX-512 / AVX2 / baseline x86-64 (resolved at load time); documents are dealt to a persistent pool
 // of native threads in contiguous chunks.
 #include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
 #include <cmath>
@@ -304,6 +305,14 @@ class HostPool {
         body_ = nullptr;
     }
 
+    // every worker, present and future, runs on `set` from now on (the drop-in moves its gather threads next to the caller's pages)
+    void set_affinity(const cpu_set_t &set) {
+        std::unique_lock<std::mutex> lk(m_);
+        aff_ = set;
+        has_aff_ = true;
+        for (pthread_t h : handles_) pthread_setaffinity_np(h, sizeof(aff_), &aff_);
+    }
+
    private:
     static std::atomic<HostPool *> &instance() {
         static std::atomic<HostPool *> p{nullptr};
@@ -321,6 +330,11 @@ class HostPool {
         }
     }
     void worker() {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            handles_.push_back(pthread_self());
+            if (has_aff_) pthread_setaffinity_np(pthread_self(), sizeof(aff_), &aff_);
+        }
         unsigned long seen = 0;
         for (;;) {
             const std::function<void(int)> *body = nullptr;
@@ -338,6 +352,9 @@ class HostPool {
             }
         }
     }
+    std::vector<pthread_t> handles_;
+    cpu_set_t aff_;
+    bool has_aff_ = false;
     std::mutex region_, m_;
     std::condition_variable cv_, done_;
     const std::function<void(int)> *body_ = nullptr;
@@ -574,6 +591,12 @@ class AsyncGather {
         cv_.notify_all();
         return MSIM_OK;
     }
+    void set_affinity(const cpu_set_t &set) {
+        std::unique_lock<std::mutex> lk(m_);
+        aff_ = set;
+        has_aff_ = true;
+        if (have_driver_ && pid_ == getpid()) pthread_setaffinity_np(driver_, sizeof(aff_), &aff_);
+    }
     int wait() {
         std::unique_lock<std::mutex> lk(m_);
         if (!busy_) return fail_host(MSIM_EINVAL, "no gather in flight");
@@ -592,6 +615,12 @@ class AsyncGather {
         int n_threads;
     };
     void driver() {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            driver_ = pthread_self();
+            have_driver_ = true;
+            if (has_aff_) pthread_setaffinity_np(driver_, sizeof(aff_), &aff_);
+        }
         for (;;) {
             Req r;
             {
@@ -615,7 +644,9 @@ class AsyncGather {
     std::mutex m_;
     std::condition_variable cv_, done_;
     Req req_{};
-    bool busy_ = false, have_ = false, started_ = false;
+    bool busy_ = false, have_ = false, started_ = false, have_driver_ = false, has_aff_ = false;
+    pthread_t driver_{};
+    cpu_set_t aff_;
     pid_t pid_ = 0;
     int rc_ = MSIM_OK;
     char err_[256] = "";
@@ -658,5 +689,18 @@ int msim_host_gather_range_begin(void *dst, const void *const *src, const int64_
 }
 
 int msim_host_gather_range_wait(void) { MSIM_HOST_GUARD(AsyncGather::get().wait()) }
+
+int msim_host_threads_affinity(const int32_t *cpus, int n_cpus) {
+    if (!cpus || n_cpus <= 0) return fail_host(MSIM_EINVAL, "an empty CPU list");
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int i = 0; i < n_cpus; ++i) {
+        if (cpus[i] < 0 || cpus[i] >= CPU_SETSIZE) return fail_host(MSIM_EINVAL, "CPU number out of range");
+        CPU_SET(cpus[i], &set);
+    }
+    HostPool::get().set_affinity(set);
+    AsyncGather::get().set_affinity(set);
+    return MSIM_OK;
+}
 
 }  // extern "C"

@@ -303,6 +303,7 @@ def _score_host_list_pipelined(qs, ps, dev: torch.device, batch_size: int, ref_r
     n_q = len(qs)
     if q_dim != dim:
         raise RuntimeError(f"queries have embedding width {q_dim}, the corpus {dim}")
+    _lib.place_gather_threads(dev, srcs[:: max(1, n // 8)][:8])      # next to the caller's pages (one move_pages query of 8 addresses)
     _stamp("checked")
     main = torch.cuda.current_stream(dev)
     side = copy_stream(dev)

@@ -457,6 +457,10 @@ int msim_host_gather_range(void *dst, const void *const *src, const int64_t *pre
  * and the MaxSim launches of the passages that have arrived (colpali_amd/corpus.py: upload_image). */
 int msim_host_gather_range_begin(void *dst, const void *const *src, const int64_t *prefix, int64_t n, int64_t lo, int64_t hi, int n_threads);
 int msim_host_gather_range_wait(void);
+/* The library's host threads (the gather pool's workers and the driver thread above, present and future) run on the listed CPUs from
+ * now on.  The upload path calls it when the caller's pages turn out to live on another NUMA node than the one the threads sit on
+ * (colpali_amd/_lib.py: gather_cpus_for): a memcpy that READS across the socket link is the slower direction. */
+int msim_host_threads_affinity(const int32_t *cpus, int n_cpus);
 
 /*
  * Row-wise top-k of a score matrix with the deterministic order

@@ -234,6 +234,37 @@ def test_host_gather_range_begin_wait_is_the_same_copy_on_a_native_thread():
     assert L.msim_host_gather_range_wait() == -1          # nothing left in flight
 
 
+def test_host_threads_affinity_and_the_page_node_query():
+    """msim_host_threads_affinity moves the library's host threads (present and future) onto a CPU list and the gather still copies
+    the same bytes; _lib.nodes_of_addresses (move_pages with a NULL node list) names a node for touched pages or returns []."""
+    import ctypes
+    import os
+
+    import numpy as np
+
+    from colpali_amd import _lib
+
+    L = _lib.lib()
+    assert L.msim_host_threads_affinity(None, 0) == -1
+    bad = (ctypes.c_int32 * 1)(1 << 20)
+    assert L.msim_host_threads_affinity(bad, 1) == -1 and b"out of range" in L.msim_host_last_error()
+    allowed = sorted(os.sched_getaffinity(0))
+    rng = np.random.default_rng(5)
+    bufs = [rng.integers(0, 256, size=3_000_000, dtype=np.uint8) for _ in range(4)]
+    whole = np.concatenate(bufs)
+    srcs = np.asarray([b.ctypes.data for b in bufs], dtype=np.uint64)
+    prefix = np.arange(5, dtype=np.int64) * 3_000_000
+    for cpus in (allowed[:1], allowed[-2:], allowed):
+        arr = (ctypes.c_int32 * len(cpus))(*cpus)
+        assert L.msim_host_threads_affinity(arr, len(cpus)) == 0
+        dst = np.zeros(whole.size, dtype=np.uint8)
+        assert L.msim_host_gather_range_begin(dst.ctypes.data, srcs.ctypes.data, prefix.ctypes.data, 4, 0, whole.size, 4) == 0
+        assert L.msim_host_gather_range_wait() == 0
+        assert np.array_equal(dst, whole)
+    nodes = _lib.nodes_of_addresses([b.ctypes.data for b in bufs])
+    assert nodes == [] or (len(nodes) == 4 and all(n >= 0 for n in nodes))
+
+
 def test_thread_counts_follow_what_the_container_grants():
     """_lib.effective_cpus(): affinity and cgroup CPU quota, never more than the host reports (a GPU box shows 256 CPUs and grants 16:
     native thread counts taken from the host's count ran the quota dry and froze the process -- profiles/r05_logs/dropin_stalls.log)."""
