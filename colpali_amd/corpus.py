@@ -122,6 +122,7 @@ def _env_int(name: str, default: int, lo: int, hi: int) -> int:
 # half of what the container grants, at most 8; COLPALI_AMD_COPY_THREADS: tuning knob (tools/dropin_profile.py)
 _COPY_THREADS = _env_int("COLPALI_AMD_COPY_THREADS", max(1, min(8, _lib_mod.effective_cpus() // 2)), 1, 256)
 _EDGE_CHUNK_BYTES = _env_int("COLPALI_AMD_EDGE_CHUNK_MB", 16, 0, 1024) << 20     # first and last chunk of a pipelined upload (0: off)
+_EDGE_LAST_BYTES = (lambda mb: -1 if mb < 0 else mb << 20)(_env_int("COLPALI_AMD_EDGE_LAST_MB", -1, -1, 1024))   # the last chunk on its own (-1: as the first)
 # pinned host memory per staging buffer = two halves that alternate: while one half is on its way to the GPU the passages of the
 # next chunk are memcpy'd into the other, so a call costs max(host memcpy, PCIe upload) instead of their sum -- 32 MiB per half
 # is large enough for both to run at full speed and small enough for a 264 MB corpus (1000 ColPali pages) to overlap almost fully
@@ -294,13 +295,14 @@ def _chunk_schedule(total: int, half: int):
     interleaved (tools/ab_dropin_edge.py, profiles/r05_logs/ab_dropin_edge.log): 16 MiB edges 7.65 -> 7.19 ms and 8.18 -> 7.97 ms
     (2 / 4 / 8 MiB: -0.0 .. -0.2 ms: their per-chunk cost eats what the shorter head and tail give)."""
     edge = min(_EDGE_CHUNK_BYTES, half)
-    if edge <= 0 or total <= 2 * half:
+    last = min(_EDGE_LAST_BYTES, half) if _EDGE_LAST_BYTES >= 0 else edge
+    if edge <= 0 or last <= 0 or total <= 2 * half:
         return [(c0, min(total, c0 + half)) for c0 in range(0, total, half)]
     cuts = [0, edge]
-    while total - cuts[-1] > half + edge:
+    while total - cuts[-1] > half + last:
         cuts.append(cuts[-1] + half)
-    if total - cuts[-1] > edge:
-        cuts.append(total - edge)
+    if total - cuts[-1] > last:
+        cuts.append(total - last)
     cuts.append(total)
     return list(zip(cuts[:-1], cuts[1:]))
 
@@ -351,6 +353,8 @@ _shape_of = operator.attrgetter("shape")
 _is_cpu = operator.attrgetter("is_cpu")
 _is_contig = torch.Tensor.is_contiguous
 _data_ptr = torch.Tensor.data_ptr
+_stride_of = torch.Tensor.stride
+_numel_of = torch.Tensor.numel
 
 
 def host_list_image(ps: Sequence[torch.Tensor], what: str = "passages"):
@@ -364,13 +368,16 @@ def host_list_image(ps: Sequence[torch.Tensor], what: str = "passages"):
     # a non-contiguous page) falls through to the loop below, which raises the reference's errors in the reference's order.
     if dim > 0 and type(ps) in (list, tuple):
         n = len(ps)
+        # contiguous + stride (dim, 1) + at least two rows <=> shape (rows, dim) -- read without building a thousand torch.Size tuples
+        # (that pass alone was 0.7 of 1.2 ms); a page of fewer than two rows (its stride says nothing) takes the loop below
         if (set(map(_dim_of, ps)) == {2} and set(map(_dtype_of, ps)) == {dtype} and all(map(_is_cpu, ps))
-                and all(map(_is_contig, ps))):
-            shapes = np.array(list(map(_shape_of, ps)), dtype=np.int64).reshape(n, 2)
-            if bool((shapes[:, 1] == dim).all()):
+                and all(map(_is_contig, ps)) and set(map(_stride_of, ps)) == {(dim, 1)}):
+            numel = np.fromiter(map(_numel_of, ps), dtype=np.int64, count=n)
+            rows = numel // dim
+            if bool((rows >= 2).all()) and bool((rows * dim == numel).all()):
                 _check_embeddings(first, what)
                 srcs = np.fromiter(map(_data_ptr, ps), dtype=np.uint64, count=n)
-                return list(ps), srcs, np.ascontiguousarray(shapes[:, 0]), int(dim), dtype
+                return list(ps), srcs, rows, int(dim), dtype
     keep = []
     for p in ps:
         if p.dim() != 2:
