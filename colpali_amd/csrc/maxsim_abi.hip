@@ -750,6 +750,22 @@ void launch_bwd_kernels(const char *Q, const char *D, const int32_t *d_off, int 
                            dim3(256), 0, st, partial, d_off, pairs, order_by_doc, dD, a.n_d, a.n_pairs, dim, max_doc_rows, splits);
         return;
     }
+    // round 6: documents whose entry lists fit the LDS lists of the row-list kernel (a bound the host can know: a document meets every
+    // query at most twice in the lists the losses make) are bucketed by row once instead of re-scanned per 64-row range
+    static const bool rows_off = ab_env("MSIM_DD_ROWS", 1) == 0;          // tuning knob (A/B), not part of the ABI
+    const long long pairs_per_doc = std::min<long long>(a.n_pairs, 2LL * a.n_q);
+    // (a list with a handful of entries per document -- the pairwise loss: 2B pairs over C documents -- stays with the kernel below,
+    // whose eight small workgroups per CU zero-fill the untouched documents faster: 13.5 against 18 us at config 5's shape)
+    const bool dense_enough = (long long)a.n_pairs * a.Lq >= 64LL * a.n_d;
+    if (!rows_off && dense_enough && pairs_per_doc <= msim::kRowsMaxPairs && pairs_per_doc * a.Lq <= msim::kRowsMaxEnt) {
+        int sy = (2 * cus + a.n_d - 1) / a.n_d;                            // about two 512-thread workgroups per CU
+        const int by_rows = (max_doc_rows + 63) / 64, need = (max_doc_rows + msim::kRowsMaxRows - 1) / msim::kRowsMaxRows;
+        sy = sy > by_rows ? by_rows : sy;
+        sy = sy < need ? need : (sy < 1 ? 1 : sy);
+        hipLaunchKernelGGL((msim::maxsim_bwd_dd_rows_kernel<DT, OUT16>), dim3(a.n_d, sy, zc), dim3(msim::kRowsThreads), 0, st, Q, d_off, pairs,
+                           order_by_doc, g, argmax, dD, a, dim, gs);
+        return;
+    }
     // row ranges per workgroup: about eight workgroups per CU in total (each looks its document's pair range up once)
     int gy = (8 * cus + a.n_d - 1) / a.n_d;
     gy = gy < 1 ? 1 : (gy > ry ? ry : gy);
@@ -1161,6 +1177,12 @@ bool box_on_panels_flat(int dtype, int dim, int n_q, int Lq) {
 extern "C" {
 
 int msim_abi_version(void) { return MSIM_ABI_VERSION; }
+#ifdef MSIM_AB
+int msim_ab_rows_trace(unsigned long long *out16) {      // measurement builds only
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(msim::g_rows_trace), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 
 const char *msim_last_error(void) { return g_err; }
 

@@ -341,6 +341,338 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dd_kernel(const char *__restri
 // columns per hit (4-byte loads), eight hits in flight, the document's pair info cached in LDS -- 60.3 us against 61.8 (ColbertLoss) and 16.5
 // against 14.4 (pairwise): the hit loop is not where this kernel's time goes.)
 
+// ---- dD, row-list form (round 6): LONG documents with SHORT entry lists -- the forward direction of the trainer (pages as documents:
+// 780 rows; ColbertLoss's dense gradient gives every page 32 pairs x 32 tokens = 1024 entries, ~1.3 per row; the pairwise loss gives
+// 2B pages 32 entries each and every other page none).  The kernel above re-scans a document's entries once per 64-row range (13 scans
+// of 1024 entries, each a chain of dependent global loads, two barriers per 256 entries).  Here a workgroup reads the entries ONCE,
+// buckets them by winning row with a counting sort in LDS (integer LDS atomics for the counts and the slots, then every row's short
+// segment is put into entry order by ranking: the float sums see the entries in list order whatever order the atomics ran in), and
+// then walks its rows -- 16 lanes per row, 8 columns per lane, 64 rows of the workgroup in flight -- adding each row's own entries and
+// storing the row once (zeros where nothing landed: no tile, no zero-fill pass, no write-out pass).
+// Grid: (document, row split, 128-column chunk).  Limits (the host checks the bound it can know, the kernel the real counts; a
+// document beyond them takes the slow direct walk at the end): kRowsMaxEnt entries and kRowsMaxPairs pairs per document, kRowsMaxRows rows.
+constexpr int kRowsThreads = 512;
+constexpr int kRowsMaxEnt = 4096, kRowsMaxPairs = 1024, kRowsMaxRows = 1024;      // (rows: two per thread in the scan)
+constexpr int kRowsCountPairs = 16384;     // pair lists up to this length: the document's pair range by ONE counting pass of the workgroup
+#ifdef MSIM_AB
+__device__ unsigned long long g_rows_trace[16];      // measurement builds: s_memtime stamps of workgroup (1, 0, 0)'s phases
+#define ROWS_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_rows_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ROWS_STAMP(i) do { } while (0)
+#endif
+
+template <int DT, bool OUT16>
+__global__ __launch_bounds__(kRowsThreads) void maxsim_bwd_dd_rows_kernel(const char *__restrict__ Q, const int32_t *__restrict__ d_off,
+                                                                          const int32_t *__restrict__ pairs,
+                                                                          const int32_t *__restrict__ order_by_doc, const float *__restrict__ g,
+                                                                          const int32_t *__restrict__ argmax, void *__restrict__ dD,
+                                                                          PairsArgs a, int dim, GScale gs) {
+    constexpr int ES = elem_size<DT>();
+    constexpr int OES = OUT16 ? 2 : 4;
+    constexpr int LPR = 4;                               // lanes per row
+    constexpr int GPL = 4;                               // 8-column groups per lane: l4, l4 + 4, l4 + 8, l4 + 12
+    __shared__ int16_t ent_row[kRowsMaxEnt];             // winning row of entry j (document-relative), -1: not in this workgroup's rows
+    __shared__ int16_t slot[kRowsMaxEnt], seg[kRowsMaxEnt];   // entries bucketed by row: in atomic order, then in entry order
+    __shared__ int cnt[kRowsMaxRows + 1];                // per row: count, then the scatter cursor
+    __shared__ uint16_t start[kRowsMaxRows + 1];
+    __shared__ int pq[kRowsMaxPairs], pp[kRowsMaxPairs];  // per pair of this document: query index, pair index
+    __shared__ float pg[kRowsMaxPairs];
+    __shared__ int wsum[kRowsThreads / 64], wsum2[kRowsThreads / 64];
+    __shared__ int guess_ok;
+    __shared__ int cls_cnt[8];
+    __shared__ uint16_t row_pos[kRowsMaxRows], row_perm[kRowsMaxRows];
+    const int c = blockIdx.x;
+    const int len = d_off[c + 1] - d_off[c];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (len + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r_lo = (int)blockIdx.y * per;
+    const int r_hi = r_lo + per < len ? r_lo + per : len;
+    if (r_lo >= r_hi) return;
+    const int n_rows = r_hi - r_lo;
+    const int col0 = blockIdx.z * 128;
+    const int ncol = dim - col0 < 128 ? dim - col0 : 128;
+    const int groups = ncol >> 3;                        // 8-column groups per row of this chunk (<= 16)
+    ROWS_STAMP(0);
+    const float up = load_gscale(gs);
+    auto doc_of = [&](int k) { return pairs[2 * order_by_doc[k] + 1]; };
+    // ---- the document's range [s, e) in the by-document order.  First a GUESS that four probes can prove: when the list gives every
+    // document the same number of pairs (all pairs: ColbertLoss; every explicit-negative list) document c owns positions c * per_doc ..;
+    // the list is sorted by document, so doc(s - 1) < c == doc(s) == doc(e - 1) < doc(e) proves it.  The pairs of the guessed range are
+    // loaded in the same round trip.  Otherwise one counting pass of the workgroup (short lists) or two wave-wide binary searches
+    // (6 + 6 dependent round trips for 8192 pairs: ~8 us in front of everything else -- what the guess is for).
+    int s = 0, e = 0;
+    bool have = false;
+    const int per_doc = a.n_d > 0 ? a.n_pairs / a.n_d : 0;
+    if (per_doc > 0 && per_doc * a.n_d == a.n_pairs && per_doc <= kRowsMaxPairs) {
+        const int gs0 = c * per_doc, ge0 = gs0 + per_doc;
+        if (t == 0) guess_ok = 1;
+        __syncthreads();
+        if (t < 4) {
+            const int pos = t == 0 ? gs0 - 1 : t == 1 ? gs0 : t == 2 ? ge0 - 1 : ge0;
+            bool ok = true;
+            if (pos >= 0 && pos < a.n_pairs) {
+                const int d = doc_of(pos);
+                ok = t == 0 ? d < c : t == 3 ? d > c : d == c;
+            }
+            if (!ok) guess_ok = 0;
+        }
+        for (int k = t; k < per_doc; k += kRowsThreads) {
+            const int p = order_by_doc[gs0 + k];
+            pp[k] = p;
+            pq[k] = pairs[2 * p];
+            pg[k] = g[p] * up;
+        }
+        __syncthreads();
+        if (guess_ok) { s = gs0; e = ge0; have = true; }
+        __syncthreads();
+    }
+    const bool pairs_loaded = have;
+    if (!have && a.n_pairs <= kRowsCountPairs) {
+        int below = 0, mine = 0;
+        for (int k0 = t; k0 < a.n_pairs; k0 += 8 * kRowsThreads) {
+            int d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                // eight independent (order -> pair) chains in flight
+                const int k = k0 + u * kRowsThreads;
+                d[u] = k < a.n_pairs ? doc_of(k) : 0x7fffffff;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                below += d[u] < c;
+                mine += d[u] == c;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            below += __shfl_xor(below, o);
+            mine += __shfl_xor(mine, o);
+        }
+        if (lane == 0) { wsum[wave] = below; wsum2[wave] = mine; }
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int w = 0; w < kRowsThreads / 64; ++w) { s += wsum[w]; m += wsum2[w]; }
+        e = s + m;
+        have = true;
+        __syncthreads();                                 // wsum is used again by the scan
+    }
+    if (!have) {
+        s = lower_bound_wave(a.n_pairs, c, lane, doc_of);
+        e = lower_bound_wave(a.n_pairs, c + 1, lane, doc_of);
+    }
+    ROWS_STAMP(1);
+    const int n_pd = e - s;
+    const int n_ent = n_pd * a.Lq;
+    char *out_doc = static_cast<char *>(dD) + (size_t)d_off[c] * dim * OES;
+    const int l4 = t & (LPR - 1);                        // this lane's 8-column groups: l4 + 4 * u
+    auto store8 = [&](int r, int grp, const float *acc) {
+        char *o = out_doc + ((size_t)r * dim + col0 + grp * 8) * OES;
+        if constexpr (OUT16) {
+            *reinterpret_cast<uint4 *>(o) = pack8<DT>(acc);
+        } else {
+            *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4 *>(o + 16) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    };
+    auto store_row = [&](int r, const float *acc) {
+#pragma unroll
+        for (int u = 0; u < GPL; ++u)
+            if (l4 + LPR * u < groups) store8(r, l4 + LPR * u, acc + 8 * u);
+    };
+    // 8 columns of a query row as floats
+    auto load8 = [&](size_t qrow, int grp, float *f) {
+        const char *p = Q + (qrow * dim + col0 + grp * 8) * ES;
+        if constexpr (DT == kDtypeF32) {
+            const float4 x = *reinterpret_cast<const float4 *>(p), y = *reinterpret_cast<const float4 *>(p + 16);
+            f[0] = x.x; f[1] = x.y; f[2] = x.z; f[3] = x.w; f[4] = y.x; f[5] = y.y; f[6] = y.z; f[7] = y.w;
+        } else {
+            piece_to_floats<DT>(*reinterpret_cast<const uint4 *>(p), f);
+        }
+    };
+    // the lane's 32 columns of a query row (groups beyond the chunk: zeros)
+    auto load_row = [&](size_t qrow, float *f) {
+#pragma unroll
+        for (int u = 0; u < GPL; ++u) {
+            if (l4 + LPR * u < groups) {
+                load8(qrow, l4 + LPR * u, f + 8 * u);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) f[8 * u + v] = 0.0f;
+            }
+        }
+    };
+    if (n_ent == 0) {                                    // nothing lands in this document: rows of zeros
+        float z[8 * GPL];
+#pragma unroll
+        for (int u = 0; u < 8 * GPL; ++u) z[u] = 0.0f;
+        for (int r = r_lo + t / LPR; r < r_hi; r += kRowsThreads / LPR) store_row(r, z);
+        return;
+    }
+    if (n_ent > kRowsMaxEnt || n_pd > kRowsMaxPairs || n_rows > kRowsMaxRows) {
+        // beyond the LDS lists (a pair list with many duplicates; the host routes every list it can bound to the right kernel): the
+        // direct walk, correct and slow -- every row scans the document's entries in list order
+        for (int r = r_lo + t / LPR; r < r_hi; r += kRowsThreads / LPR) {
+            float acc[8 * GPL];
+#pragma unroll
+            for (int u = 0; u < 8 * GPL; ++u) acc[u] = 0.0f;
+            for (int k = 0; k < n_pd; ++k) {
+                const int p = order_by_doc[s + k];
+                const float gp = g[p] * up;
+                const int qb = pairs[2 * p];
+                for (int i = 0; i < a.Lq; ++i)
+                    if (argmax[(size_t)p * a.Lq + i] == r) {
+                        float f[8 * GPL];
+                        load_row((size_t)qb * a.Lq + i, f);
+#pragma unroll
+                        for (int u = 0; u < 8 * GPL; ++u) acc[u] += gp * f[u];
+                    }
+            }
+            store_row(r, acc);
+        }
+        return;
+    }
+    // ---- the document's pairs and counts
+    if (!pairs_loaded) {
+        for (int k = t; k < n_pd; k += kRowsThreads) {
+            const int p = order_by_doc[s + k];
+            pp[k] = p;
+            pq[k] = pairs[2 * p];
+            pg[k] = g[p] * up;
+        }
+    }
+    for (int r = t; r <= n_rows; r += kRowsThreads) cnt[r] = 0;
+    __syncthreads();
+    ROWS_STAMP(2);
+    // ---- entries: winning rows, histogram of this workgroup's rows
+    for (int j = t; j < n_ent; j += kRowsThreads) {
+        const int k = j / a.Lq, i = j - k * a.Lq;
+        const int r = argmax[(size_t)pp[k] * a.Lq + i] - r_lo;
+        const bool mine = r >= 0 && r < n_rows;
+        ent_row[j] = mine ? (int16_t)r : (int16_t)-1;
+        if (mine) atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    ROWS_STAMP(3);
+    // ---- exclusive scan of the counts: thread t owns rows 2t, 2t + 1 (kRowsMaxRows = 2 * kRowsThreads)
+    {
+        const int c0 = 2 * t < n_rows ? cnt[2 * t] : 0, c1 = 2 * t + 1 < n_rows ? cnt[2 * t + 1] : 0;
+        int v = c0 + c1;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int excl = base + incl - v;
+        if (2 * t < n_rows) { start[2 * t] = (uint16_t)excl; cnt[2 * t] = excl; }
+        if (2 * t + 1 < n_rows) { start[2 * t + 1] = (uint16_t)(excl + c0); cnt[2 * t + 1] = excl + c0; }
+        if (2 * t == n_rows || 2 * t + 1 == n_rows) start[n_rows] = (uint16_t)(2 * t == n_rows ? excl : excl + c0);
+    }
+    __syncthreads();
+    ROWS_STAMP(4);
+    // ---- scatter into the rows' segments (atomic order), then every segment into entry order
+    for (int j = t; j < n_ent; j += kRowsThreads) {
+        const int r = ent_row[j];
+        if (r >= 0) slot[atomicAdd(&cnt[r], 1)] = (int16_t)j;
+    }
+    __syncthreads();
+    // ---- rows grouped by their number of entries (0, 1, 2, 3, 4+): the 16 rows a wave works on at a time then loop equally often -- with
+    // the rows in natural order a wave's loop ran for its LONGEST row (4-5 entries where the average is 1.3) and the kernel, which is
+    // bound by instruction issue (sixteen waves per CU, ~500 instructions per 16 rows), spent two thirds of its slots on masked lanes.
+    // Which row of a class comes first is irrelevant to the result (rows are independent), so atomic slots are fine here.
+    if (t < 8) cls_cnt[t] = 0;
+    __syncthreads();
+    for (int r = t; r < n_rows; r += kRowsThreads) {
+        const int n = start[r + 1] - start[r];
+        const int cl = n < 4 ? n : 4;
+        row_pos[r] = (uint16_t)(atomicAdd(&cls_cnt[cl], 1) | (cl << 12));        // position inside the class, class in the top bits
+    }
+    __syncthreads();
+    for (int r = t; r < n_rows; r += kRowsThreads) {
+        const int cl = row_pos[r] >> 12;
+        int base = 0;                                    // classes in descending order of work: 4+, 3, 2, 1, 0
+#pragma unroll
+        for (int k = 4; k > 0; --k) base += k > cl ? cls_cnt[k] : 0;
+        row_perm[base + (row_pos[r] & 0xfff)] = (uint16_t)r;
+    }
+    __syncthreads();
+    ROWS_STAMP(5);
+    const bool lq_pow2 = (a.Lq & (a.Lq - 1)) == 0;
+    const int lq_shift = 31 - __builtin_clz(a.Lq | 1);
+    const float inv_lq = 1.0f / (float)a.Lq;
+    auto split_entry = [&](int j, int &k, int &i) {      // j = k * Lq + i, j < 4096: a shift, or an exact float quotient with one correction
+        if (lq_pow2) {
+            k = j >> lq_shift;
+        } else {
+            k = (int)(((float)j + 0.5f) * inv_lq);
+            k -= k * a.Lq > j;
+            k += (k + 1) * a.Lq <= j;
+        }
+        i = j - k * a.Lq;
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int idx = t / LPR; idx < n_rows; idx += kRowsThreads / LPR) {
+        const int r = row_perm[idx];
+        const int b0 = start[r], n = start[r + 1] - b0;
+        // rank every entry of the segment among the segment (entries are distinct): seg[b0 + rank] = entry; the lanes share the work
+        if (n > 1) {
+            for (int x = l4; x < n; x += LPR) {
+                const int mine = slot[b0 + x];
+                int rank = 0;
+                for (int y = 0; y < n; ++y) rank += slot[b0 + y] < mine;
+                seg[b0 + rank] = (int16_t)mine;
+            }
+        }
+        // (the same wave wrote and reads: LDS operations of a wave complete in order)
+        f32x2 acc[4 * GPL];
+#pragma unroll
+        for (int u = 0; u < 4 * GPL; ++u) acc[u] = f32x2{0.f, 0.f};
+        for (int x = 0; x < n; ++x) {
+            const int j = n > 1 ? seg[b0 + x] : slot[b0];
+            int k, i;
+            split_entry(j, k, i);
+            const float gp = pg[k];
+            const size_t qrow = (size_t)pq[k] * a.Lq + i;
+            if constexpr (DT == kDtypeF32) {
+                float f[8 * GPL];
+                load_row(qrow, f);
+#pragma unroll
+                for (int u = 0; u < 4 * GPL; ++u) acc[u] += f32x2{gp, gp} * f32x2{f[2 * u], f[2 * u + 1]};
+            } else {
+                uint4 raw[GPL];
+#pragma unroll
+                for (int u = 0; u < GPL; ++u)
+                    raw[u] = l4 + LPR * u < groups ? *reinterpret_cast<const uint4 *>(Q + (qrow * dim + col0 + (l4 + LPR * u) * 8) * ES)
+                                                   : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < GPL; ++u) {
+                    const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        f32x2 q2;
+                        if constexpr (DT == kDtypeF16) {
+                            q2 = f32x2{elem_to_float<true>((uint16_t)(w[v] & 0xffffu)), elem_to_float<true>((uint16_t)(w[v] >> 16))};
+                        } else {
+                            q2 = f32x2{__uint_as_float(w[v] << 16), __uint_as_float(w[v] & 0xffff0000u)};
+                        }
+                        acc[4 * u + v] += f32x2{gp, gp} * q2;
+                    }
+                }
+            }
+        }
+        float out[8 * GPL];
+#pragma unroll
+        for (int u = 0; u < 4 * GPL; ++u) { out[2 * u] = acc[u].x; out[2 * u + 1] = acc[u].y; }
+        store_row(r_lo + r, out);
+        ROWS_STAMP(6 + (idx >= kRowsThreads / LPR ? 1 : 0));
+    }
+    ROWS_STAMP(8);
+}
+
 // ---- dD, dense form: SHORT documents (<= kBwdRows rows: one row range) with LONG entry lists -- the symmetric direction of the
 // reference trainer (trainer/contrastive_trainer.py:202-206: pages as query_embeddings [B, 780, 128], queries as doc_embeddings
 // [B, 32, 128]), where a document of 32 rows collects B x 780 (pair, token) entries and the launch above has n_d workgroups to

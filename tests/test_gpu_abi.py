@@ -369,11 +369,12 @@ def test_probe_mfma_runs_and_validates_arguments(amd):
     x = torch.nn.functional.normalize(torch.randn((rows, 128), device=dev), dim=-1).to(torch.bfloat16)
     sink = torch.zeros(4, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    for variant in range(25):               # 12..24: K1b's exact slab body under the round-3 register plans (probe_mfma.hip)
+    for variant in range(29):               # 12..24: K1b's exact slab body under the round-3 register plans; 25..28: the ridge's ten-tile body (round 6)
         assert L.msim_probe_mfma(variant, x.data_ptr(), rows, 50, sink.data_ptr(), st) == 0, L.msim_probe_last_error()
     torch.cuda.synchronize()
     assert float(sink.abs().sum()) == 0.0
-    assert L.msim_probe_mfma(25, x.data_ptr(), rows, 50, sink.data_ptr(), st) != 0
+    assert L.msim_probe_mfma(29, x.data_ptr(), rows, 50, sink.data_ptr(), st) != 0
+    assert L.msim_probe_mfma(25, x.data_ptr(), 256 * 4 * 11 * 32 - 1, 50, sink.data_ptr(), st) != 0   # ten tiles + the operand rows per wave
     assert L.msim_probe_mfma(7, x.data_ptr(), rows_small, 50, sink.data_ptr(), st) == 0      # variants 0..7 take the smaller matrix
     assert L.msim_probe_mfma(8, x.data_ptr(), rows_small, 50, sink.data_ptr(), st) != 0      # the 12 / 16-wave shapes do not
     assert L.msim_probe_mfma(0, x.data_ptr(), rows_small - 1, 50, sink.data_ptr(), st) != 0

@@ -632,6 +632,57 @@ def test_dense_dd_form_equals_the_row_range_form_and_the_float64_scatter(amd, dt
         assert float((dd.double() - want).abs().max()) <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("case", ["dense_bf16", "dense_f32", "width320", "duplicates_overflow", "two_row_splits"])
+def test_row_list_dd_form_against_the_float64_scatter(amd, case):
+    """The row-list dD kernel (round 6: long documents, short entry lists -- the entries bucketed by winning row with a counting sort
+    in LDS, every row adding its own entries in list order): dense all-pairs lists at widths 128 / 320, a list whose duplicates
+    overflow the LDS lists at run time (the in-kernel direct walk), documents without pairs (rows of zeros), several row splits.
+    fp32 output against the float64 scatter-add of g[p] * Q[b_p, i, :] into row argmax[p, i] of document c_p; run twice: bit-stable."""
+    from colpali_amd import _lib, loss as L_
+
+    g = torch.Generator().manual_seed(11)
+    dtype, dim = torch.bfloat16, 128
+    if case == "dense_f32":
+        dtype = torch.float32
+    if case == "width320":
+        dim = 320
+    B, C, Lq, Ld = (4, 3, 128, 200) if case == "duplicates_overflow" else (6, 3, 32, 1500) if case == "two_row_splits" else (12, 10, 32, 300)
+    q = torch.nn.functional.normalize(torch.randn(B, Lq, dim, generator=g), dim=-1).to(dtype).cuda()
+    d = torch.nn.functional.normalize(torch.randn(C, Ld, dim, generator=g), dim=-1).to(dtype).cuda()
+    if case == "duplicates_overflow":
+        lst = [(b, 0) for b in range(B) for _ in range(12)] + [(b, 1) for b in range(B)]      # document 2: no pairs at all
+        lst.sort(key=lambda bc: bc[0])
+        pairs = torch.tensor(lst, dtype=torch.int32).cuda()
+        order = torch.sort(pairs[:, 1].to(torch.int64), stable=True).indices.to(torch.int32).contiguous()
+    else:
+        pairs, order = L_._all_pairs(B, C, q.device), L_._all_pairs_order(B, C, q.device)
+    n_pairs = pairs.shape[0]
+    gp = torch.randn(n_pairs, generator=g).cuda()
+    offsets = L_._dense_corpus(d).offsets
+    _, argmax = L_.maxsim_pairs(q, d, offsets, pairs, want_scores=False)
+    lib = _lib.lib()
+    assert lib.msim_pairs_bwd_workspace_bytes(B, Lq, C, dim, Ld, n_pairs) == 0          # long documents: no scratch, the row forms
+    outs = []
+    for _ in range(2):
+        dq = torch.full((B, Lq, dim), float("nan"), device=q.device)
+        dd = torch.full((C, Ld, dim), float("nan"), device=q.device)
+        rc = lib.msim_pairs_bwd(_lib.dtype_code(dtype), _lib.ptr(q), B, Lq, _lib.ptr(d), _lib.ptr(offsets), C, dim, Ld, _lib.ptr(pairs),
+                                _lib.ptr(order), _lib.ptr(gp), None, 0, _lib.ptr(argmax), n_pairs, 2, _lib.ptr(dq), _lib.ptr(dd), None,
+                                _lib.current_stream_handle(q.device))
+        _lib.check(rc, "msim_pairs_bwd")
+        outs.append(dd.cpu())
+    assert torch.equal(outs[0], outs[1])
+    want = torch.zeros(C, Ld, dim, dtype=torch.float64)
+    am, pr, gg, qq = argmax.cpu().long(), pairs.cpu().long(), gp.cpu().double(), q.cpu().double()
+    for p in range(n_pairs):
+        b, c = int(pr[p, 0]), int(pr[p, 1])
+        want[c].index_add_(0, am[p], gg[p] * qq[b])
+    assert torch.isfinite(outs[0]).all()
+    assert float((outs[0].double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    if case == "duplicates_overflow":
+        assert float(outs[0][2].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(6, 11, 32, 300), (5, 9, 780, 32), (3, 4, 45, 70)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gradients_in_the_embedding_dtype_with_the_upstream_scalar_folded_in(amd, shape, dtype):

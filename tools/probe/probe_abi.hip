@@ -68,6 +68,7 @@ int msim_probe_mfma(int variant, const void *X, int64_t rows, int iters, float *
     if (reinterpret_cast<uintptr_t>(X) & 15) return fail(MSIM_EINVAL, "X must be 16-byte aligned");
     if (rows < 256LL * 8 * 5 * 32) return fail(MSIM_EINVAL, "the MFMA probe needs at least %d rows of operands", 256 * 8 * 5 * 32);
     if (variant >= 8 && rows < 256LL * 16 * 3 * 32) return fail(MSIM_EINVAL, "MFMA probe variants 8..11 need at least %d rows of operands", 256 * 16 * 3 * 32);
+    if (variant >= 25 && rows < 256LL * 4 * 11 * 32) return fail(MSIM_EINVAL, "MFMA probe variants 25..28 need at least %d rows of operands", 256 * 4 * 11 * 32);
     if (iters <= 0 || variant < 0 || variant > 28) return fail(MSIM_EINVAL, "bad probe arguments (variant=%d iters=%d)", variant, iters);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *x = static_cast<const uint16_t *>(X);
