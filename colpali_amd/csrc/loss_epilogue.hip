@@ -358,6 +358,98 @@ __device__ __forceinline__ EpiRow epi_row_pairwise_half(int b, int l32, const fl
     return EpiRow{row_loss, lo, hi, doc0, doc1};
 }
 
+// The dense-gradient rows (InfoNCE, sigmoid) on HALF a wave with the row's values kept in registers (round 6): one read of the row,
+// one division / filter decision / exp per element instead of one per pass (epi_row re-derives `value(c)` in each of its five
+// passes: ~1300 instructions per row and wave, 17 us for 32 x 256 scores on the small kernel's 16 waves), and two rows per wave at a
+// time.  The same formulas as epi_row; sums run lane-strided over 32 lanes and a fixed 5-step butterfly.  C <= 32 * NE.
+template <int NE>
+__device__ __forceinline__ EpiRow epi_row_dense_half(int b, int l32, const float *srow, int length, float *__restrict__ G, const EpiArgs &a) {
+    const float len_f = (float)length;
+    const int pos_idx = a.offset + b;
+    auto norm = [&](float raw) { return a.normalize ? raw / len_f : raw; };
+    const float pos = norm(srow[pos_idx]);
+    const float limit = a.filter_threshold * pos;
+    const float inv_B = 1.0f / (float)a.B;
+    float v[NE];
+    unsigned fmask = 0;
+    float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int c = l32 + 32 * u;
+        const bool ok = c < a.C;
+        const float s = norm(srow[ok ? c : pos_idx]);
+        if (ok) { lo = fminf(lo, s); hi = fmaxf(hi, s); }
+        const bool f = a.filter && c != pos_idx && s > limit;
+        v[u] = f ? s * a.filter_factor : s;
+        fmask |= (f ? 1u : 0u) << u;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    float *grow = G != nullptr ? G + (size_t)b * a.ld : nullptr;
+    float row_loss;
+    if (a.mode == kEpiSigmoid) {
+        const float inv_C = 1.0f / (float)a.C;
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int c = l32 + 32 * u;
+            if (c < a.C) {
+                const float sign = c == pos_idx ? 1.0f : -1.0f;
+                const float x = -v[u] * a.inv_T * sign;
+                acc += x > 20.0f ? x : log1pf(expf(x));                   // F.softplus (beta 1, threshold 20)
+                if (grow != nullptr) {
+                    const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+                    float g = -sign * a.inv_T * sig * inv_B * inv_C;
+                    if ((fmask >> u) & 1u) g *= a.filter_factor;
+                    if (a.normalize) g /= len_f;
+                    grow[c] = g;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        row_loss = acc * inv_C;
+    } else {
+        float m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            v[u] = __fmul_rn(v[u], a.inv_T);                              // the logit: ONE rounded product (see epi_row)
+            if (l32 + 32 * u < a.C) m = fmaxf(m, v[u]);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float se_others = 0.f;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int c = l32 + 32 * u;
+            v[u] = expf(v[u] - m);
+            if (c < a.C && c != pos_idx) se_others += v[u];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) se_others += __shfl_xor(se_others, o);
+        const float d_pos = __fmul_rn(pos, a.inv_T) - m;                  // the positive is never filtered
+        const float se = se_others + expf(d_pos);
+        row_loss = logf(se) - d_pos;
+        if (grow != nullptr) {
+            const float scale = a.inv_T * inv_B / se;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int c = l32 + 32 * u;
+                if (c < a.C) {
+                    float g = (c == pos_idx ? -se_others : v[u]) * scale;
+                    if ((fmask >> u) & 1u) g *= a.filter_factor;
+                    if (a.normalize) g /= len_f;
+                    grow[c] = g;
+                }
+            }
+        }
+    }
+    return EpiRow{row_loss, lo, hi, 0, 0};
+}
+
 // ---- the same for SMALL batches (B <= kEpiSmallRows rows, B * C scores that one workgroup reads in a few microseconds -- BASELINE
 // config 5: 32 x 256): ONE workgroup of 16 waves.  Phase 1, one round trip to memory: the whole score matrix is copied into LDS (when
 // it fits kEpiStageFloats) and every wave counts the tokens of its rows.  Phase 2: one wave per row at a time (shuffle reductions
@@ -425,6 +517,18 @@ __global__ __launch_bounds__(kEpiSmallThreads) void loss_epilogue_small_kernel(c
                 row_hi[b] = r.hi;
                 pair_doc[2 * b] = r.doc0;
                 pair_doc[2 * b + 1] = r.doc1;
+            }
+        }
+    } else if (a.C <= 512) {
+        // dense gradients, rows of at most 512 documents: a row per HALF wave, its values in registers (32 rows at a time)
+        const int l32 = lane & 31;
+        for (int b = tid >> 5; b < a.B; b += kEpiSmallThreads / 32) {
+            const float *srow = staged ? stage + (size_t)b * a.C : scores + (size_t)b * a.ld;
+            const EpiRow r = a.C <= 256 ? epi_row_dense_half<8>(b, l32, srow, row_len[b], G, a) : epi_row_dense_half<16>(b, l32, srow, row_len[b], G, a);
+            if (l32 == 0) {
+                row_loss[b] = r.loss;
+                row_lo[b] = r.lo;
+                row_hi[b] = r.hi;
             }
         }
     } else {
