@@ -724,9 +724,13 @@ void launch_bwd_kernels(const char *Q, const char *D, const int32_t *d_off, int 
         const long long tokens = (long long)a.n_q * a.Lq;
         int tpw = (int)((tokens + 4095) / 4096);
         tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
-        const int chunks = (a.Lq + 4 * tpw - 1) / (4 * tpw);
+        // few tokens with long pair lists (a dense gradient: 1024 tokens x 256 pairs at config 5's shape): the four waves of a workgroup
+        // share the tokens and split the pairs (maxsim_bwd.hip: psplit)
+        const int psplit = (tokens <= 2048 && (long long)a.n_pairs >= 64LL * a.n_q) ? 1 : 0;
+        if (psplit) tpw = 1;
+        const int chunks = psplit ? a.Lq : (a.Lq + 4 * tpw - 1) / (4 * tpw);
         hipLaunchKernelGGL((msim::maxsim_bwd_dq_kernel<DT, OUT16>), dim3((unsigned)a.n_q * chunks), dim3(256), 0, st, D, d_off, pairs, g,
-                           argmax, dQ, a, row_bytes, tpw, gs);
+                           argmax, dQ, a, row_bytes, tpw, gs, psplit);
     }
     const int ry = (max_doc_rows + msim::kBwdRows - 1) / msim::kBwdRows;
     const int zc = (dim + 127) / 128;

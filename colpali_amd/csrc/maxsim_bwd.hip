@@ -70,19 +70,48 @@ template <int DT, bool OUT16>
 __global__ __launch_bounds__(256) void maxsim_bwd_dq_kernel(const char *__restrict__ D, const int32_t *__restrict__ d_off,
                                                             const int32_t *__restrict__ pairs, const float *__restrict__ g,
                                                             const int32_t *__restrict__ argmax, void *__restrict__ dQ,
-                                                            PairsArgs a, int row_bytes, int tpw, GScale gs) {
+                                                            PairsArgs a, int row_bytes, int tpw, GScale gs, int psplit) {
     constexpr int ES = elem_size<DT>();
     constexpr int EPP = 16 / ES;                         // elements per 16-byte piece
     static_assert(!OUT16 || DT != kDtypeF32, "OUT16 is the 16-bit embedding dtypes' own output");
+    // psplit (round 6): the workgroup's four waves take the SAME tokens and a quarter of the query's pairs each; their partial rows
+    // meet in LDS and wave 0 adds them in wave order.  A dense gradient at config 5's shape is 1024 tokens x 256 pairs: with a wave per
+    // token the chip holds one wave per SIMD and every wave walks 16 steps of three dependent loads (21 us); split four ways it holds
+    // four waves per SIMD with 4 steps each.
+    __shared__ float part[3][64][EPP];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunks = (a.Lq + 4 * tpw - 1) / (4 * tpw);
+    const int chunks = psplit ? (a.Lq + tpw - 1) / tpw : (a.Lq + 4 * tpw - 1) / (4 * tpw);
     const int b = blockIdx.x / chunks;
-    const int i0 = (blockIdx.x - b * chunks) * 4 * tpw + wave * tpw;
+    const int i0 = psplit ? (blockIdx.x - b * chunks) * tpw : (blockIdx.x - b * chunks) * 4 * tpw + wave * tpw;
     if (b >= a.n_q || i0 >= a.Lq) return;
     const float up = load_gscale(gs);
-    const int s = lower_bound_wave(a.n_pairs, b, lane, [&](int k) { return pairs[2 * k]; });
-    const int e = lower_bound_wave(a.n_pairs, b + 1, lane, [&](int k) { return pairs[2 * k]; });
+    // the query's pair range: a guess four probes can prove (every query owns the same number of pairs -- any all-pairs or
+    // explicit-negative list: q(s - 1) < b == q(s) == q(e - 1) < q(e) in a list sorted by query), else two wave-wide binary searches
+    // (3 + 3 dependent round trips for 8192 pairs)
+    int s = 0, e = 0;
+    bool have = false;
+    const int per_q = a.n_q > 0 ? a.n_pairs / a.n_q : 0;
+    if (per_q > 0 && per_q * a.n_q == a.n_pairs) {
+        const int gs0 = b * per_q, ge0 = gs0 + per_q;
+        const int pos = lane == 0 ? gs0 - 1 : lane == 1 ? gs0 : lane == 2 ? ge0 - 1 : ge0;
+        bool ok = true;
+        if (lane < 4 && pos >= 0 && pos < a.n_pairs) {
+            const int qv = pairs[2 * pos];
+            ok = lane == 0 ? qv < b : lane == 3 ? qv > b : qv == b;
+        }
+        if (__ballot(!ok) == 0) { s = gs0; e = ge0; have = true; }
+    }
+    if (!have) {
+        s = lower_bound_wave(a.n_pairs, b, lane, [&](int k) { return pairs[2 * k]; });
+        e = lower_bound_wave(a.n_pairs, b + 1, lane, [&](int k) { return pairs[2 * k]; });
+    }
+    if (psplit) {                                        // this wave's quarter of the pairs (the host only asks for it on long lists)
+        const int per = (e - s + 3) >> 2;
+        const int ws = s + wave * per;
+        e = ws + per < e ? ws + per : e;
+        s = ws < e ? ws : e;
+    }
     const int pieces = row_bytes >> 4;
     int pp_log = 1;
     while ((1 << pp_log) < pieces && pp_log < 6) ++pp_log;
@@ -90,7 +119,7 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dq_kernel(const char *__restri
     const int G = 64 >> pp_log;                          // pairs per wave-step
     const int sub = lane >> pp_log, pc = lane & (pp - 1);
     const int i_end = i0 + tpw < a.Lq ? i0 + tpw : a.Lq;
-    if (e - s <= 8 && G > 1) {
+    if (!psplit && e - s <= 8 && G > 1) {
         // FEW pairs per query (the pairwise loss: two): the lane groups take different TOKENS instead of different pairs -- G tokens'
         // (argmax -> offset -> row) chains in flight per wave and no cross-group fold.  (With the groups on pairs, 14 of 16 gather
         // slots idled and a wave walked its tokens one dependent chain at a time: 17 us for the 25 000 tokens of the trainer's
@@ -162,43 +191,66 @@ __global__ __launch_bounds__(256) void maxsim_bwd_dq_kernel(const char *__restri
             float acc[EPP];
 #pragma unroll
             for (int k = 0; k < EPP; ++k) acc[k] = 0.0f;
-            for (int p0 = s; p0 < e; p0 += 4 * G) {
-                int pj[4], arg[4], doc[4], off[4];
-                float w[4];
-                bool ok[4];
+            // U pairs per lane group and step: the step's three rounds of dependent loads (routing / pair -> row offset -> row) are
+            // issued for all U pairs before any is used
+            auto steps = [&](auto u_c) {
+                constexpr int U = decltype(u_c)::value;
+                for (int p0 = s; p0 < e; p0 += U * G) {
+                    int pj[U], arg[U], doc[U], off[U];
+                    float w[U];
+                    bool ok[U];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int p = p0 + j * G + sub;
-                    ok[j] = p < e;
-                    pj[j] = ok[j] ? p : e - 1;                                   // clamped: every load is a valid address
+                    for (int j = 0; j < U; ++j) {
+                        const int p = p0 + j * G + sub;
+                        ok[j] = p < e;
+                        pj[j] = ok[j] ? p : e - 1;                                   // clamped: every load is a valid address
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        arg[j] = argmax[(size_t)pj[j] * a.Lq + i];
+                        doc[j] = pairs[2 * pj[j] + 1];
+                        w[j] = g[pj[j]] * up;
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) off[j] = d_off[doc[j]];
+                    uint4 v[U];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const bool use = ok[j] && arg[j] >= 0;                        // arg < 0: the zero padding row won the max
+                        w[j] = use ? w[j] : 0.0f;                                     // the weight is selected, never the loaded row
+                        const int row = off[j] + (arg[j] >= 0 ? arg[j] : 0);
+                        v[j] = *reinterpret_cast<const uint4 *>(D + (size_t)row * row_bytes + boff);
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        float f[EPP];
+                        piece_to_floats<DT>(v[j], f);
+#pragma unroll
+                        for (int k = 0; k < EPP; ++k) acc[k] += w[j] * f[k];
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    arg[j] = argmax[(size_t)pj[j] * a.Lq + i];
-                    doc[j] = pairs[2 * pj[j] + 1];
-                    w[j] = g[pj[j]] * up;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) off[j] = d_off[doc[j]];
-                uint4 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool use = ok[j] && arg[j] >= 0;                        // arg < 0: the zero padding row won the max
-                    w[j] = use ? w[j] : 0.0f;                                     // the weight is selected, never the loaded row
-                    const int row = off[j] + (arg[j] >= 0 ? arg[j] : 0);
-                    v[j] = *reinterpret_cast<const uint4 *>(D + (size_t)row * row_bytes + boff);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float f[EPP];
-                    piece_to_floats<DT>(v[j], f);
-#pragma unroll
-                    for (int k = 0; k < EPP; ++k) acc[k] += w[j] * f[k];
-                }
-            }
+            };
+            // (psplit with U = 16 -- a wave's quarter of 256 pairs as ONE step -- measured 19.1 us against 15.4 with U = 4: 262 144 scattered
+            // 256-byte row reads from a 51 MB box are 67 MB in 15 us = 4.4 TB/s; the kernel is at the memory system, not at a latency chain)
+            steps(std::integral_constant<int, 4>{});
             for (int m = pp; m < 64; m <<= 1)
 #pragma unroll
                 for (int k = 0; k < EPP; ++k) acc[k] += __shfl_xor(acc[k], m);
+            if (psplit) {                                // (every wave of the workgroup is here: same tokens, same rounds)
+                if (wave > 0 && sub == 0) {
+#pragma unroll
+                    for (int k = 0; k < EPP; ++k) part[wave - 1][pc][k] = acc[k];
+                }
+                __syncthreads();
+                if (wave == 0 && sub == 0) {
+#pragma unroll
+                    for (int w2 = 0; w2 < 3; ++w2)
+#pragma unroll
+                        for (int k = 0; k < EPP; ++k) acc[k] += part[w2][pc][k];
+                }
+                __syncthreads();
+                if (wave > 0) continue;
+            }
             if (sub == 0 && col_ok) {
                 if constexpr (OUT16) {
                     *reinterpret_cast<uint4 *>(static_cast<char *>(dQ) + tok * row_bytes + ((size_t)piece << 4)) = pack8<DT>(acc);
