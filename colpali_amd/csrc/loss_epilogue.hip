@@ -474,10 +474,23 @@ __global__ __launch_bounds__(kEpiSmallThreads) void loss_epilogue_small_kernel(c
     __shared__ EpiShared unused;                    // the wave-level reductions never touch it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kEpiSmallThreads / 64;
-    if (staged) {
-        // the whole matrix in one round trip: up to eight loads in flight per thread before the first LDS write
-        constexpr int kInFlight = 8;
-        const int n = a.B * a.C;
+    // Phase 1 is ONE round trip to memory when the matrix fits eight loads per thread (config 5: 32 x 256): the scores are loaded
+    // into registers, the token counts' loads are issued behind them (a row per HALF wave: all rows of a 32-row batch at once -- with a
+    // row per wave the second row's round trip followed the first's), and only then are the scores written to LDS.
+    constexpr int kInFlight = 8;
+    const int n = a.B * a.C;
+    const bool one_round = staged && n <= kEpiSmallThreads * kInFlight;
+    float v0[kInFlight];
+    if (one_round) {
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+            const int i = tid + j * kEpiSmallThreads;
+            const int ic = i < n ? i : 0;
+            const int r = ic / a.C, c = ic - r * a.C;
+            v0[j] = scores[(size_t)r * a.ld + c];
+        }
+    } else if (staged) {
+        // the whole matrix, up to eight loads in flight per thread before the first LDS write
         for (int i0 = tid; i0 < n; i0 += kEpiSmallThreads * kInFlight) {
             float v[kInFlight];
 #pragma unroll
@@ -497,11 +510,19 @@ __global__ __launch_bounds__(kEpiSmallThreads) void loss_epilogue_small_kernel(c
     if (lengths != nullptr) {
         for (int b = tid; b < a.B; b += kEpiSmallThreads) row_len[b] = lengths[b];
     } else {
-        for (int b = wave; b < a.B; b += kWaves) {
-            int cnt = epi_count_tokens(b, lane, 64, Q, a);
+        const int l32 = lane & 31;
+        for (int b = tid >> 5; b < a.B; b += kEpiSmallThreads / 32) {
+            int cnt = epi_count_tokens(b, l32, 32, Q, a);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-            if (lane == 0) row_len[b] = cnt;
+            for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (l32 == 0) row_len[b] = cnt;
+        }
+    }
+    if (one_round) {
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+            const int i = tid + j * kEpiSmallThreads;
+            if (i < n) stage[i] = v0[j];
         }
     }
     __syncthreads();
