@@ -276,7 +276,10 @@ __global__ __launch_bounds__(256, 2) void maxsim_allpairs_argmax_kernel(const ui
         int am[TPQ];
 #pragma unroll
         for (int t = 0; t < TPQ; ++t) { m[t] = -INFINITY; am[t] = -1; }
-        for (int s = 0; s < nslab; ++s) {
+        // one slab; kTail: rows past the document's end are masked -- only the LAST slab can have any, and the two extra VALU
+        // operations per element (this kernel is bound by its VALU work: 3 per element for the running arg-max) are kept out of the others
+        auto slab_body = [&](int s, auto tail_c) {
+            constexpr bool kTail = decltype(tail_c)::value;
             if (produce()) wait_vmcnt<8 * (kPairsRing - 1)>(); else wait_vmcnt<0>();
             const char *src = ring + c_slot * kSlabBytes;
             c_slot = (c_slot + 1 == kPairsRing) ? 0 : c_slot + 1;
@@ -292,11 +295,13 @@ __global__ __launch_bounds__(256, 2) void maxsim_allpairs_argmax_kernel(const ui
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {                  // rows in increasing order inside a lane: strict '>' keeps the first maximum
                     const int row = row0 + acc_row(r, lane);
-                    const float v = (row < len) ? acc[r] : -INFINITY;
+                    const float v = (!kTail || row < len) ? acc[r] : -INFINITY;
                     if (v > m[t]) { m[t] = v; am[t] = row; }
                 }
             }
-        }
+        };
+        for (int s = 0; s + 1 < nslab; ++s) slab_body(s, std::false_type{});
+        if (nslab > 0) slab_body(nslab - 1, std::true_type{});
         bool clamp = false;
         if (clamp0 != nullptr) {
             const uint64_t addr = reinterpret_cast<uint64_t>(clamp0) + (uint64_t)c;
