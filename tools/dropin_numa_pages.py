@@ -45,8 +45,12 @@ for geom, lens in (("config 2 (1000 x 1030)", [1030] * 1000), ("config 3 (1000 x
         for t in qs + ps:
             migrate(t, node_of_cpus(cpus))
         nodes = _lib.nodes_of_addresses([p.data_ptr() for p in ps[::125]])
-        for policy in ("gpu", "pages", "gpu", "pages"):
+        from colpali_amd import corpus as _C
+        runs = [("gpu", 8), ("pages", 8), ("gpu", 8), ("pages", 8)] if os.environ.get("NUMA_THREADS_SWEEP") != "1" else \
+               [("gpu", 8), ("gpu", 12), ("gpu", 16), ("gpu", 6), ("gpu", 8), ("gpu", 12), ("gpu", 16), ("gpu", 6)]
+        for policy, threads in runs:
             _lib.GATHER_NODE_POLICY = policy
+            _C._COPY_THREADS = threads
             for _ in range(3):
                 amd.score_multi_vector(qs, ps, device="cuda:0")
             ts = []
@@ -55,5 +59,5 @@ for geom, lens in (("config 2 (1000 x 1030)", [1030] * 1000), ("config 3 (1000 x
                 out = amd.score_multi_vector(qs, ps, device="cuda:0")
                 ts.append((time.perf_counter() - t0) * 1e3)
             ts.sort()
-            print(f"{geom:30s} pages on the {where} (move_pages says nodes {sorted(set(nodes))})  gather threads: {policy:5s}  median {ts[7]:6.2f} ms  p95 {ts[13]:6.2f}  min {ts[0]:6.2f}  checksum {float(out.double().sum()):.4f}", flush=True)
+            print(f"{geom:30s} pages on the {where} (move_pages says nodes {sorted(set(nodes))})  gather threads: {policy:5s} x {threads:2d}  median {ts[7]:6.2f} ms  p95 {ts[13]:6.2f}  min {ts[0]:6.2f}  checksum {float(out.double().sum()):.4f}", flush=True)
         del qs, ps
