@@ -16,6 +16,7 @@
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
+#include "maxsim_batch_packed.hip"
 #include "maxsim_batch_t.hip"
 #include "maxsim_dense_t.hip"
 #include "maxsim_pairs.hip"
@@ -147,6 +148,7 @@ struct FwdCall {
     int avg_rows = 0;                      // the caller's hint: average rows per document (MSIM_FLAG_AVG_ROWS), 0 = unknown
 };
 
+constexpr int kPackedMaxAvgRows = 512;        // K1b's eight-wave plans go to K1bK (several documents per chunk) up to this average document length
 constexpr size_t kFwdWorkspaceBytes = 4096;   // K1b's convoy counters: n_ranges * n_qblocks <= 8 * 64 ints
 
 constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup (launch_stream picks 2 for 5-8 units)
@@ -415,10 +417,21 @@ int ranges_per_xcd(int n_qblocks, int cus_per_xcd, int n_d, int avg_rows) {
     return sub;
 }
 
-template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8>
+// PACKED: K1bK (maxsim_batch_packed.hip), the eight-wave form whose chunks hold several short documents
+template <bool F16, int NW, int RING, int AUX, int MAXU, bool PACKED>
+auto batch_kernel_ptr() {
+    if constexpr (PACKED) return msim::maxsim_batch_packed_kernel<F16, AUX, MAXU>;
+    else return msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
+}
+
+template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8, bool PACKED = false>
 int launch_batch(const FwdCall &c, const FlatPlan &plan) {
-    auto kern = msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
-    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes + (NW > 2 ? 2 : 1) * NW * MAXU * msim::kUnitTok * 16 + NW * 8 * 8;   // ring + the per-token max table(s) + the queries' token ranges
+    static_assert(!PACKED || (NW == 8 && RING == 3), "K1bK is the eight-wave form");
+    auto kern = batch_kernel_ptr<F16, NW, RING, AUX, MAXU, PACKED>();
+    // ring + the per-token max table(s) + the queries' token ranges
+    constexpr int lds = RING * (NW / 2) * msim::kSlabBytes +
+                        (PACKED ? 2 * msim::kPackMaxEnds * NW * MAXU * msim::kUnitTok * 4 : (NW > 2 ? 2 : 1) * NW * MAXU * msim::kUnitTok * 16) +
+                        NW * 8 * 8;
     constexpr int wg_per_cu = MAXU == 5 ? 12 / NW : 8 / NW;  // the five-unit form: 168 registers, three waves per SIMD (three 4-wave workgroups per CU)
     static std::atomic<int> configured[kMaxDevices];
     if (int rc = allow_lds(kern, lds, configured)) return rc;
@@ -474,9 +487,15 @@ int launch_batch(const FwdCall &c, const FlatPlan &plan) {
 #endif
         hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(NW * 64), lds, c.st, c.Q, c.D, c.d_off, c.clamp0, c.scores, a);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch_kernel<%d,%d> launch: %s", NW, MAXU, hipGetErrorString(e));
+        if (e != hipSuccess) return fail(MSIM_ELAUNCH, "maxsim_batch%s_kernel<%d,%d> launch: %s", PACKED ? "_packed" : "", NW, MAXU, hipGetErrorString(e));
     }
     return MSIM_OK;
+}
+
+// K1bK or K1b for an eight-wave plan: from the caller's hint alone
+bool packed_chunks(int avg_rows) {
+    static const int packed_env = ab_env("MSIM_BATCH_PACKED", -1);          // measurement builds: 0 / 1 force the choice
+    return packed_env >= 0 ? packed_env != 0 : (avg_rows > 0 && avg_rows <= kPackedMaxAvgRows);
 }
 
 template <bool F16>
@@ -518,6 +537,11 @@ int fwd_dispatch(const FwdCall &c) {
     if (plan.nw == 4 && plan.maxu == 8 && !single) return launch_batch<F16, 4, 3, 0, 8>(c, plan);
 #endif
     if (plan.nw == 4) return plan.maxu == 10 ? launch_batch<F16, 4, 3, 2, 10>(c, plan) : launch_batch<F16, 4, 3, 2, 8>(c, plan);
+    // short documents (the caller's MSIM_FLAG_AVG_ROWS hint): chunks that hold several documents (K1bK); the same bits either way
+    if (packed_chunks(c.avg_rows)) {
+        if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10, true>(c, plan) : launch_batch<F16, 8, 3, 0, 10, true>(c, plan);
+        return single ? launch_batch<F16, 8, 3, 2, 8, true>(c, plan) : launch_batch<F16, 8, 3, 0, 8, true>(c, plan);
+    }
     if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10>(c, plan) : launch_batch<F16, 8, 3, 0, 10>(c, plan);
     return single ? launch_batch<F16, 8, 3, 2, 8>(c, plan) : launch_batch<F16, 8, 3, 0, 8>(c, plan);
 }
@@ -1216,6 +1240,12 @@ int msim_fwd_plan(const int32_t *q_off_host, int n_q, int Lq, int32_t *out5) {
     out5[3] = plan.stream ? 1 : plan.n_blocks();
     out5[4] = plan.stream ? plan.nu : heaviest_wave_units(hq, plan.blk_q0, plan.nw);
     return MSIM_OK;
+}
+
+int msim_fwd_plan_packed(const int32_t *q_off_host, int n_q, int Lq, uint32_t flags) {
+    int32_t out5[5];
+    if (int rc = msim_fwd_plan(q_off_host, n_q, Lq, out5)) return rc;
+    return (out5[0] == 1 && out5[1] == 8 && packed_chunks((int)((flags >> 8) & 0xffffu))) ? 1 : 0;
 }
 
 size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim) {

@@ -170,13 +170,21 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     };
     p_open();
     int p_slot = 0;
+    // A share of a chunk that lies wholly past the document's end is NOT requested (round 6): an LDS-DMA instruction costs its wave ~100 cycles whether or not its rows exist -- with 64-row
+    // documents waves 4..7 spent 700 cycles per document fetching zeros that nobody reads (slabs past the end are never computed, and
+    // the rows of a tail slab past the end are masked after the MFMA: what the ring holds there does not matter)
+    unsigned p_hist = 0;                                     // bit k: the produce() k calls ago made its four requests (wave-uniform)
     auto produce = [&]() -> bool {
+        p_hist <<= 1;
         if (p_idx >= d_hi) return false;
         char *dst = smem + p_slot * kChunkBytes + my_lds_off;
         const int soff = (p_row + my_row_off) * kRowBytes;   // rows past the document end read as zeros (bounds check)
+        if (p_row + my_row_off < p_len) {
+            p_hist |= 1u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, AUX);
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, MSIM_LDS(dst + j * 1024), 16, src_off[j], soff + j * 1024, 0, AUX);
+        }
         p_slot = (p_slot + 1 == kBatchRing) ? 0 : p_slot + 1;
         p_row += kChunkRows;
         if (p_row >= p_len) {
@@ -282,8 +290,15 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
 
         for (int ch = 0; ch < nchunk; ++ch) {
             const unsigned long long t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
-            // my share of chunk `ch` has landed once at most (ring-2) later chunks of mine are still in flight
-            if (p_idx < d_hi) wait_vmcnt<4 * (kBatchRing - 2)>(); else wait_vmcnt<0>();
+            // my share of chunk `ch` has landed once nothing but the requests of the (ring-2) chunks produced after it is in flight:
+            // 4 each if they were made at all
+            if constexpr (kBatchRing == 2) wait_vmcnt<0>();
+            else if constexpr (kBatchRing == 3) { if (p_hist & 1u) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+            else {
+                static_assert(kBatchRing <= 4, "the request history below covers two chunks");
+                const int later = __builtin_popcount(p_hist & 3u);
+                if (later == 2) wait_vmcnt<8>(); else if (later == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            }
             const unsigned long long t1 = tracing ? __builtin_amdgcn_s_memtime() : 0;
             if (convoy_on && wave == 0 && (g_chunk & (kConvoyEvery - 1)) == 0) {
                 if (lane == 0) __hip_atomic_store(my_prog + qblock, g_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -11,7 +11,8 @@ trace = torch.zeros(8 * 8, dtype=torch.int64, device=dev)
 os.environ["MSIM_BATCH_TRACE_PTR"] = str(trace.data_ptr())
 import bench, colpali_amd as amd
 docs = int(os.environ.get("AB_DOCS", "32768"))
-corpus = bench.make_shard(docs, 1024, dev, 1234)
+doc_len = int(os.environ.get("AB_DOC_LEN", "1024"))
+corpus = bench.make_shard(docs, doc_len, dev, 1234)
 if os.environ.get("AB_ZERO") == "1":
     corpus.blob.zero_()
 for nq in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,16,32,256").split(",")]:
@@ -24,11 +25,12 @@ for nq in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,16,32,256")
     a.record(); amd.maxsim_scores(q, corpus, out=out); e.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(e)
     t = trace.view(8, 8).cpu()
-    print(f"nq={nq}: {ms:.3f} ms  {2*nq*32*docs*1024*128/ms/1e9:.0f} TF; ticks per chunk and wave of workgroup 0 (100 MHz s_memtime? compare with ms):")
+    print(f"nq={nq}: {ms:.3f} ms  {2*nq*32*docs*doc_len*128/ms/1e9:.0f} TF; ticks per chunk and wave of workgroup 0 (100 MHz s_memtime? compare with ms):")
     for w in range(8):
         n = int(t[w, 6])
         if n == 0:
             continue
         tot = sum(int(t[w, i]) for i in range(6))
-        print(f"  wave {w}: chunks {n:6d}  vmcnt {int(t[w,0])/n:7.1f}  convoy {int(t[w,1])/n:7.1f}  barrier {int(t[w,2])/n:7.1f}  issue {int(t[w,3])/n:7.1f}  "
-              f"slabs {int(t[w,4])/n:8.1f}  epilogue {int(t[w,5])/n:6.1f}  total {tot/n:8.1f}  (sum {tot} ticks)")
+        names = (("vmcnt+convoy", "barrier", "issue", "token sums", "slabs", "doc ends") if doc_len <= 512 and os.environ.get("MSIM_BATCH_PACKED") != "0"
+                 else ("vmcnt", "convoy", "barrier", "issue", "slabs", "epilogue"))       # K1bK (several documents per chunk) / K1b
+        print(f"  wave {w}: chunks {n:6d}  " + "  ".join(f"{nm} {int(t[w, i]) / n:7.1f}" for i, nm in enumerate(names)) + f"  total {tot / n:8.1f}  (sum {tot} ticks)")
