@@ -202,12 +202,12 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
 #pragma unroll
     for (int t = 0; t < MAXU; ++t)
         load_query_unit(qu[t], Qt + (size_t)tok0 * kDim, (wave + kB1Waves * t) * kUnitTok, n_tok, lane, t < my_nu);
-    // the reduction after every document: 8 lanes per query, query j of the block in lanes 8j .. 8j+7 of the workgroup
+    // the reduction after every document: 8 lanes per query, query j of the block in the workgroup's lanes 504 - 8j .. 511 - 8j (reduce_doc)
     // (the token range of the query waits in LDS next to the table, written by the lanes that read it back: the slab loop of the
     // ten-unit form has no two registers to spare)
     int *const rtab = reinterpret_cast<int *>(tokmax + (kTwoTables ? 2 : 1) * kTableBytes);
     {
-        const int rq = threadIdx.x >> 3;
+        const int rq = (kB1Waves * 64 - 1 - (int)threadIdx.x) >> 3;
         if (rq < qb_n) {
             const int s = flat_qoff(a.fq, qb0 + rq) - tok0, e = flat_qoff(a.fq, qb0 + rq + 1) - tok0;
             rtab[2 * rq] = s;
@@ -238,9 +238,11 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     auto reduce_doc = [&](int doc, bool clamp, int tab) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));        // opaque: nothing derived from it (row pointers, table addresses) is hoisted into registers that
-        const int rq = tid >> 3, ri = tid & 7;   // stay live across the slab loop (the ten-unit form spills otherwise)
+        // query j of the block is summed by the workgroup's LAST lanes (512 - 8j - 8 ..): the first waves are the ones the matrix pipe
+        // serves first and, on short documents, the ones that issue the chunk's LDS-DMA requests; the sums go to their SIMD partners
+        const int rq = (kB1Waves * 64 - 1 - tid) >> 3, ri = tid & 7;   // stay live across the slab loop (the ten-unit form spills otherwise)
         if (rq < qb_n) {
-            float tot = reduce_query_tokens<F16>(tokmax + tab * kTableBytes, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
+            float tot = reduce_query_tokens_lane0<F16>(tokmax + tab * kTableBytes, rtab[2 * rq], rtab[2 * rq + 1], ri, clamp, ref_bf16);
             if (round_total) tot = round_to_input<F16>(tot);
             if (ri == 0) scores[(size_t)(qb0 + rq) * a.ld + doc] = tot;
         }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
         if (nchunk == 0) {          // a document without rows never enters the ring: every token's max is over nothing (-inf, or 0 under clamp0)
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int rq = tid >> 3;
+            const int rq = (kB1Waves * 64 - 1 - tid) >> 3;
             if (rq < qb_n && (tid & 7) == 0)
                 scores[(size_t)(qb0 + rq) * a.ld + c_idx] = (rtab[2 * rq + 1] > rtab[2 * rq] && !clamp) ? -INFINITY : 0.0f;
             continue;

@@ -360,4 +360,35 @@ __device__ __forceinline__ float reduce_query_tokens(const char *tokmax, int s, 
     return acc;
 }
 
+// The same sum -- the same bits in the lane that is read, lane i == 0 of the query's eight -- with shorter latency chains (round 6,
+// K1b on short documents: the token sums of a document sit between two chunk barriers):
+//   * four table reads in flight per step instead of one (a token past the end adds +0.0 to a sum that starts at +0.0: no bit changes);
+//   * the fold over the 8 lanes on DPP row shifts instead of three ds_bpermute round trips: lane 0 adds (a0+a4) + (a2+a6), then
+//     + ((a1+a5) + (a3+a7)) -- exactly what the xor butterfly leaves in lane 0 (the other lanes hold partial sums: read lane 0 only).
+template <int N>
+__device__ __forceinline__ float row_shl_add(float acc) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x100 | N, 0xf, 0xf, true);   // lane l reads lane l + N of its row of 16
+    return acc + __builtin_bit_cast(float, moved);
+}
+template <bool F16>
+__device__ __forceinline__ float reduce_query_tokens_lane0(const char *tokmax, int s, int e, int i, bool clamp, bool ref_round) {
+    float acc = 0.0f;
+    for (int t = s + i; t < e; t += 32) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4 *>(tokmax + ((t + 8 * k < e ? t + 8 * k : s) << 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = fmaxf(fmaxf(v[k][0], v[k][1]), fmaxf(v[k][2], v[k][3]));
+            if (clamp) x = fmaxf(x, 0.0f);
+            if (ref_round) x = round_to_input<F16>(x);
+            if (t + 8 * k < e) acc += x;
+        }
+    }
+    acc = row_shl_add<4>(acc);
+    acc = row_shl_add<2>(acc);
+    acc = row_shl_add<1>(acc);
+    return acc;
+}
+
 }  // namespace msim
