@@ -29,7 +29,7 @@ def _lib_path() -> str:
 LIB_PATH = _lib_path()
 
 MSIM_FLAG_REF_ROUNDING = 0x1
-ABI_VERSION = 21
+ABI_VERSION = 20
 
 
 def dtype_code(dtype) -> int:
@@ -90,8 +90,6 @@ def lib() -> ctypes.CDLL:
     L.msim_sim_matrix_host.restype = i32
     L.msim_fwd_plan.argtypes = [vp, i32, i32, vp]
     L.msim_fwd_plan.restype = i32
-    L.msim_fwd_plan_packed.argtypes = [vp, i32, i32, ctypes.c_uint32]
-    L.msim_fwd_plan_packed.restype = i32
     L.msim_fwd_ragged_workspace_bytes.argtypes = [i32, vp, i32, i32, i32]
     L.msim_fwd_ragged_workspace_bytes.restype = sz
     L.msim_fwd_ragged.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, u32, vp, vp]

@@ -16,7 +16,9 @@
 #include "../../include/maxsim.h"
 #include "maxsim_stream.hip"
 #include "maxsim_batch.hip"
-#include "maxsim_batch_packed.hip"
+#if defined(MSIM_AB) || defined(MSIM_TRACE)
+#include "maxsim_batch_packed.hip"     // K1bK: several short documents per chunk -- measured, slower than K1b, measurement builds only
+#endif
 #include "maxsim_batch_t.hip"
 #include "maxsim_dense_t.hip"
 #include "maxsim_pairs.hip"
@@ -148,7 +150,6 @@ struct FwdCall {
     int avg_rows = 0;                      // the caller's hint: average rows per document (MSIM_FLAG_AVG_ROWS), 0 = unknown
 };
 
-constexpr int kPackedMaxAvgRows = 512;        // K1b's eight-wave plans go to K1bK (several documents per chunk) up to this average document length
 constexpr size_t kFwdWorkspaceBytes = 4096;   // K1b's convoy counters: n_ranges * n_qblocks <= 8 * 64 ints
 
 constexpr int kStreamRing = 4;  // default slabs per wave-private ring: 4 waves x 4 x 8 KiB = 128 KiB per workgroup (launch_stream picks 2 for 5-8 units)
@@ -417,11 +418,14 @@ int ranges_per_xcd(int n_qblocks, int cus_per_xcd, int n_d, int avg_rows) {
     return sub;
 }
 
-// PACKED: K1bK (maxsim_batch_packed.hip), the eight-wave form whose chunks hold several short documents
+// PACKED (measurement builds): K1bK (maxsim_batch_packed.hip), the eight-wave form whose chunks hold several short documents
 template <bool F16, int NW, int RING, int AUX, int MAXU, bool PACKED>
 auto batch_kernel_ptr() {
+#if defined(MSIM_AB) || defined(MSIM_TRACE)
     if constexpr (PACKED) return msim::maxsim_batch_packed_kernel<F16, AUX, MAXU>;
-    else return msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
+    else
+#endif
+    return msim::maxsim_batch_kernel<F16, NW, RING, AUX, MAXU>;
 }
 
 template <bool F16, int NW, int RING = 3, int AUX = 0, int MAXU = 8, bool PACKED = false>
@@ -430,7 +434,7 @@ int launch_batch(const FwdCall &c, const FlatPlan &plan) {
     auto kern = batch_kernel_ptr<F16, NW, RING, AUX, MAXU, PACKED>();
     // ring + the per-token max table(s) + the queries' token ranges
     constexpr int lds = RING * (NW / 2) * msim::kSlabBytes +
-                        (PACKED ? 2 * msim::kPackMaxEnds * NW * MAXU * msim::kUnitTok * 4 : (NW > 2 ? 2 : 1) * NW * MAXU * msim::kUnitTok * 16) +
+                        (PACKED ? 2 * (NW / 2) * NW * MAXU * msim::kUnitTok * 4 : (NW > 2 ? 2 : 1) * NW * MAXU * msim::kUnitTok * 16) +
                         NW * 8 * 8;
     constexpr int wg_per_cu = MAXU == 5 ? 12 / NW : 8 / NW;  // the five-unit form: 168 registers, three waves per SIMD (three 4-wave workgroups per CU)
     static std::atomic<int> configured[kMaxDevices];
@@ -492,12 +496,6 @@ int launch_batch(const FwdCall &c, const FlatPlan &plan) {
     return MSIM_OK;
 }
 
-// K1bK or K1b for an eight-wave plan: from the caller's hint alone
-bool packed_chunks(int avg_rows) {
-    static const int packed_env = ab_env("MSIM_BATCH_PACKED", -1);          // measurement builds: 0 / 1 force the choice
-    return packed_env >= 0 ? packed_env != 0 : (avg_rows > 0 && avg_rows <= kPackedMaxAvgRows);
-}
-
 template <bool F16>
 int fwd_dispatch(const FwdCall &c) {
     thread_local FlatPlan plan;
@@ -537,11 +535,15 @@ int fwd_dispatch(const FwdCall &c) {
     if (plan.nw == 4 && plan.maxu == 8 && !single) return launch_batch<F16, 4, 3, 0, 8>(c, plan);
 #endif
     if (plan.nw == 4) return plan.maxu == 10 ? launch_batch<F16, 4, 3, 2, 10>(c, plan) : launch_batch<F16, 4, 3, 2, 8>(c, plan);
-    // short documents (the caller's MSIM_FLAG_AVG_ROWS hint): chunks that hold several documents (K1bK); the same bits either way
-    if (packed_chunks(c.avg_rows)) {
+#if defined(MSIM_AB) || defined(MSIM_TRACE)
+    // measurement builds only (round 6, short documents): MSIM_BATCH_PACKED=1 -- chunks that hold several documents (K1bK); the same
+    // bits, 4-9 % slower than K1b at 64 / 343 rows (profiles/r06_logs/ab_short_docs_packed.log)
+    static const int packed_env = ab_env("MSIM_BATCH_PACKED", 0);
+    if (packed_env != 0) {
         if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10, true>(c, plan) : launch_batch<F16, 8, 3, 0, 10, true>(c, plan);
         return single ? launch_batch<F16, 8, 3, 2, 8, true>(c, plan) : launch_batch<F16, 8, 3, 0, 8, true>(c, plan);
     }
+#endif
     if (plan.maxu == 10) return single ? launch_batch<F16, 8, 3, 2, 10>(c, plan) : launch_batch<F16, 8, 3, 0, 10>(c, plan);
     return single ? launch_batch<F16, 8, 3, 2, 8>(c, plan) : launch_batch<F16, 8, 3, 0, 8>(c, plan);
 }
@@ -1240,12 +1242,6 @@ int msim_fwd_plan(const int32_t *q_off_host, int n_q, int Lq, int32_t *out5) {
     out5[3] = plan.stream ? 1 : plan.n_blocks();
     out5[4] = plan.stream ? plan.nu : heaviest_wave_units(hq, plan.blk_q0, plan.nw);
     return MSIM_OK;
-}
-
-int msim_fwd_plan_packed(const int32_t *q_off_host, int n_q, int Lq, uint32_t flags) {
-    int32_t out5[5];
-    if (int rc = msim_fwd_plan(q_off_host, n_q, Lq, out5)) return rc;
-    return (out5[0] == 1 && out5[1] == 8 && packed_chunks((int)((flags >> 8) & 0xffffu))) ? 1 : 0;
 }
 
 size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim) {

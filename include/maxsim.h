@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 21
+#define MSIM_ABI_VERSION 20
 
 /* error codes */
 #define MSIM_OK 0
@@ -157,11 +157,6 @@ int msim_sim_matrix_host(int dtype, const void *A, int n_a, const void *B, int n
  * HBM-bound regime) | 1 = K1b (waves share a document stream),  K1s: 16-token units per wave | K1b: waves per stream (2, 4, 8),
  * K1b: units a wave holds at most (8, 10),  query blocks (passes over a document range),  units of the heaviest wave }. */
 int msim_fwd_plan(const int32_t *q_off_host, int n_q, int Lq, int32_t *out5);
-/* Whether that call, made with `flags`, takes K1bK -- K1b's eight-wave form with SEVERAL SHORT DOCUMENTS PER CHUNK (a chunk = the next
- * four 32-row slabs of the document sequence, whatever documents they belong to) -- instead of K1b, whose chunks belong to one
- * document: 1 / 0, or an error code.  Chosen from MSIM_FLAG_AVG_ROWS alone (an average of 1 .. 512 rows on an eight-wave plan);
- * the scores are the same bits either way (ABI 21). */
-int msim_fwd_plan_packed(const int32_t *q_off_host, int n_q, int Lq, uint32_t flags);
 size_t msim_fwd_ragged_workspace_bytes(int dtype, const int32_t *q_off_host, int n_q, int n_d, int dim);
 int msim_fwd_ragged(int dtype, const void *Qt, const int32_t *q_off, const int32_t *q_off_host, int n_q,
                     const void *D, const int32_t *d_off, const uint8_t *d_clamp0,

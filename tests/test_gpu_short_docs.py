@@ -1,8 +1,12 @@
-"""GPU parity of K1bK (maxsim_batch_packed.hip): K1b's eight-wave form with several short documents per chunk.
+"""GPU parity of K1b on SHORT documents (pooled pages, 64-row documents): document ends at every position of a chunk's four 32-row
+slabs, tails of every size, documents without rows, clamp flags, a slice of a larger corpus.
 
-The host picks it from the caller's MSIM_FLAG_AVG_ROWS hint (average document length <= 512 rows); the hint is a launch-shape
-hint and never a result, so the same corpus scored with a short and with a long hint must give the SAME BITS (K1bK against K1b),
-and both must sit within 1e-5 of the float64-accumulating oracle (processing_utils.py:179).
+Round 6 changed what K1b's producer requests -- a wave's share of a chunk that lies wholly past the document's end is no longer
+fetched (the ring keeps whatever it held there; those rows are masked or never computed) -- and how the token sums are folded (DPP
+row shifts); both must leave every bit where it was.  MSIM_FLAG_AVG_ROWS is a launch-shape hint and never a result: the same corpus
+scored under a short and under a long hint must give the SAME BITS (run against a measurement build with
+MSIM_BATCH_PACKED=1 the same file checks K1bK, the several-documents-per-chunk form that was measured and not kept), and both must sit within 1e-5 of
+the float64 truth (processing_utils.py:179).
 """
 import dataclasses
 
@@ -41,26 +45,10 @@ def _oracle(qs, ps, batch_size=128):
 
 
 def _both(amd, q, corpus, **kw):
-    """the same call on K1bK (short hint) and on K1b (long hint)"""
-    packed = amd.maxsim_scores(q, dataclasses.replace(corpus, avg_rows=32), **kw).cpu()
+    """the same call under a short and under a long average-length hint"""
+    short_hint = amd.maxsim_scores(q, dataclasses.replace(corpus, avg_rows=32), **kw).cpu()
     plain = amd.maxsim_scores(q, dataclasses.replace(corpus, avg_rows=4096), **kw).cpu()
-    return packed, plain
-
-
-def _takes_packed(amd, q_lens, avg_rows):
-    L = amd._lib.lib()
-    off = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
-    rc = L.msim_fwd_plan_packed(off.ctypes.data, len(q_lens), 0, min(65535, avg_rows) << 8)
-    assert rc in (0, 1), L.msim_last_error()
-    return rc == 1
-
-
-def test_the_host_rule_packed_chunks_only_for_short_documents_on_eight_wave_plans(amd):
-    assert _takes_packed(amd, [32] * 100, 64) and _takes_packed(amd, [32] * 100, 32) and _takes_packed(amd, [32] * 100, 512)
-    assert not _takes_packed(amd, [32] * 100, 4096)
-    assert not _takes_packed(amd, [32] * 100, 0)          # no hint: K1b
-    assert not _takes_packed(amd, [32] * 12, 64)          # the pair / four-wave forms keep K1b
-    assert not _takes_packed(amd, [32] * 4, 64)           # K1s
+    return short_hint, plain
 
 
 # every position of a document end inside a chunk of four 32-row slabs, tails of every size
@@ -78,9 +66,9 @@ def test_slab_edges_against_oracle_and_bitwise_against_k1b(amd, n_q, lq, ragged)
     dev = torch.device("cuda:0")
     corpus = amd.pack_passages(ps, dev, batch_size=None)
     q = amd.pack_queries(qs, dev)
-    packed, plain = _both(amd, q, corpus)
-    assert torch.equal(packed, plain)
-    assert _close(packed.numpy(), _truth(qs, ps))
+    short_hint, plain = _both(amd, q, corpus)
+    assert torch.equal(short_hint, plain)
+    assert _close(short_hint.numpy(), _truth(qs, ps))
 
 
 def _truth(qs, ps):
@@ -100,23 +88,22 @@ def test_uniform_short_documents_bitwise_and_against_oracle(amd, doc_len):
     qs, ps = _rows(g, [32] * 70), _rows(g, [doc_len] * 1500)
     dev = torch.device("cuda:0")
     corpus, q = amd.pack_passages(ps, dev), amd.pack_queries(qs, dev)
-    packed, plain = _both(amd, q, corpus)
-    assert torch.equal(packed, plain)
-    assert _close(packed.numpy(), _oracle(qs, ps))
+    short_hint, plain = _both(amd, q, corpus)
+    assert torch.equal(short_hint, plain)
+    assert _close(short_hint.numpy(), _oracle(qs, ps))
 
 
 def test_block_padding_clamp_flags_and_the_literal_tier(amd):
-    # reference blocks of 7 passages: the shorter ones of a block see its zero padding rows (clamp0) -- the flags travel through the
-    # offset window's second register
+    # reference blocks of 7 passages: the shorter ones of a block see its zero padding rows (clamp0) -- the flags are per document
     g = torch.Generator().manual_seed(77)
     d_lens = torch.randint(1, 150, (700,), generator=g).tolist()
     qs, ps = _rows(g, torch.randint(1, 33, (90,), generator=g).tolist()), _rows(g, d_lens)
     dev = torch.device("cuda:0")
     corpus, q = amd.pack_passages(ps, dev, batch_size=7), amd.pack_queries(qs, dev)
     assert corpus.clamp0 is not None
-    packed, plain = _both(amd, q, corpus)
-    assert torch.equal(packed, plain)
-    assert _close(packed.numpy(), _oracle(qs, ps, batch_size=7))
+    short_hint, plain = _both(amd, q, corpus)
+    assert torch.equal(short_hint, plain)
+    assert _close(short_hint.numpy(), _oracle(qs, ps, batch_size=7))
     lit_p, lit_b = _both(amd, q, corpus, ref_bf16=True)
     assert torch.equal(lit_p, lit_b)
     want = mo.score_multi_vector([x.float().numpy() for x in qs], [x.float().numpy() for x in ps], batch_size=7, mode="bf16ref")
@@ -126,21 +113,21 @@ def test_block_padding_clamp_flags_and_the_literal_tier(amd):
 
 def test_documents_without_rows_and_runs_longer_than_the_offset_window(amd):
     # empty documents inside a block (the reference scores them 0 under its zero padding; -inf cannot occur through the drop-in) and a
-    # run of 150 of them: the cursors leave the 64-document offset window and take the direct loads
+    # run of 150 of them: producer and consumer skip them without a chunk
     g = torch.Generator().manual_seed(5)
     d_lens = [40, 0, 0, 64, 1, 0] * 20 + [0] * 150 + [33, 0, 96] * 30 + [0, 0, 0]
     qs, ps = _rows(g, [32] * 48), _rows(g, d_lens)
     dev = torch.device("cuda:0")
     corpus, q = amd.pack_passages(ps, dev, batch_size=len(ps)), amd.pack_queries(qs, dev)
-    packed, plain = _both(amd, q, corpus)
-    assert torch.equal(packed, plain)
-    assert _close(packed.numpy(), _oracle(qs, ps, batch_size=len(ps)))
+    short_hint, plain = _both(amd, q, corpus)
+    assert torch.equal(short_hint, plain)
+    assert _close(short_hint.numpy(), _oracle(qs, ps, batch_size=len(ps)))
     # without block semantics an empty document is a max over nothing: -inf for a query with tokens
     raw = dataclasses.replace(corpus, clamp0=None)
-    packed, plain = _both(amd, q, raw)
-    assert torch.equal(packed, plain)
+    short_hint, plain = _both(amd, q, raw)
+    assert torch.equal(short_hint, plain)
     empty = torch.tensor(d_lens) == 0
-    assert torch.isinf(packed[:, empty]).all() and (packed[:, empty] < 0).all() and torch.isfinite(packed[:, ~empty]).all()
+    assert torch.isinf(short_hint[:, empty]).all() and (short_hint[:, empty] < 0).all() and torch.isfinite(short_hint[:, ~empty]).all()
 
 
 def test_float16_and_many_query_blocks_with_the_convoy(amd):
@@ -149,10 +136,10 @@ def test_float16_and_many_query_blocks_with_the_convoy(amd):
     qs, ps = _rows(g, q_lens, torch.float16), _rows(g, torch.randint(20, 140, (4000,), generator=g).tolist(), torch.float16)
     dev = torch.device("cuda:0")
     corpus, q = amd.pack_passages(ps, dev, batch_size=None), amd.pack_queries(qs, dev)
-    packed, plain = _both(amd, q, corpus)
-    assert torch.equal(packed, plain)
+    short_hint, plain = _both(amd, q, corpus)
+    assert torch.equal(short_hint, plain)
     sub = list(range(0, 1000, 97))
-    assert _close(packed[sub][:, :300].numpy(), _truth([qs[i] for i in sub], ps[:300]))
+    assert _close(short_hint[sub][:, :300].numpy(), _truth([qs[i] for i in sub], ps[:300]))
 
 
 def test_a_corpus_slice_with_absolute_offsets(amd):

@@ -12,7 +12,10 @@ tag = os.environ.get("AB_TAG", "default")
 for doc_len in (64, 343, 1024):
     n_docs = (4 << 30) // (doc_len * 256)
     corpus = bench.make_shard(n_docs, doc_len, dev, seed=5)
-    for qname, lens in (("1000 x 32", [32] * 1000), ("1000 x U{12..48}", bench.parse_regime("1000xr12-48", 32)[1])):
+    qsets = [("1000 x 32", [32] * 1000), ("1000 x U{12..48}", bench.parse_regime("1000xr12-48", 32)[1])]
+    if os.environ.get("AB_MORE") == "1":       # the ten-unit form, and the pair / four-wave / one-block forms (they share K1b's producer and consumer)
+        qsets += [("1000 x 40", [40] * 1000)] + ([(f"{n} x 32", [32] * n) for n in (10, 16, 32, 64)] if doc_len != 343 else [])
+    for qname, lens in qsets:
         q = amd.pack_queries(bench.make_query_list(lens, seed=sum(lens) + doc_len), dev)
         scores = torch.empty((len(lens), n_docs), dtype=torch.float32, device=dev)
         amd.maxsim_scores(q, corpus, out=scores)
