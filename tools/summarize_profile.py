@@ -101,6 +101,12 @@ def main(src, dst_prefix):
     if bench:
         out["bench_line_under_trace"] = bench
         cfg = bench["config"]
+        if not bench.get("regimes"):
+            # round 6: the stdout line is compact; the per-regime kernel times sit in bench_detail.json (the copy the last pass of
+            # tools/prof.sh left in gpurun_out/)
+            dp = os.path.join(os.path.dirname(os.path.abspath(src)), "bench_detail.json")
+            if os.path.exists(dp):
+                bench = dict(bench, regimes=json.load(open(dp)).get("regimes", []))
         regs = [(cfg["n_queries"], cfg["n_queries"] * cfg.get("q_len", 32), bench["roofline"]["kernel_ms"])] + \
                [(r["n_queries"], r.get("q_tokens", r["n_queries"] * 32), r["kernel_ms"]) for r in bench.get("regimes", [])]
         for nq, ntok, ms in regs:
