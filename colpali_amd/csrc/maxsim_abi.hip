@@ -380,7 +380,7 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
         // ... or no slower AND the only one whose blocks are all resident at once (32 CUs per XCD on MI355X: one document range per
         // XCD, held together by the convoy, every corpus byte read from HBM once).  1000 queries x 40 tokens: 40 blocks of 64 units
         // run as four ranges x five rounds and read the corpus TWICE (PMC: 66.5 GB for 33.3 GB); 32 blocks of 80 units read it once
-        // in the same time (99.3 vs 99.4-99.8 ms, profiles/r06_logs/ab_short_docs_packed.log section 6)
+        // in the same time (99.3 vs 99.4-99.8 ms, profiles/r06_logs/ab_short_docs_packed.log section 7)
         const bool single_round10 = b10.size() - 1 <= 32 && b8.size() - 1 > 32;
         if (11 * c10 < 10 * c8 || (c10 <= c8 && single_round10)) {
             p.maxu = 10;
