@@ -154,3 +154,21 @@ def test_a_corpus_slice_with_absolute_offsets(amd):
                                clamp0=None)
     got = amd.maxsim_scores(q, part).cpu()
     assert torch.equal(got, whole[:, lo:hi])
+
+
+@pytest.mark.parametrize("n_q", [8, 10, 16, 20, 32])
+def test_pair_and_four_wave_forms_on_tiny_documents(amd, n_q):
+    # the pair form's chunk is one slab (a tail of <= 16 rows: its second wave requests nothing, ring of four chunks = a two-chunk
+    # request history), the four-wave forms' two slabs (<= 32 rows: waves 2 and 3 request nothing); runs of tiny documents make
+    # every pattern of requested / skipped shares in the history
+    g = torch.Generator().manual_seed(900 + n_q)
+    d_lens = ([1, 5, 16, 17, 20, 32, 33, 40, 48, 49, 64, 65, 9, 3] * 30)[: 400]
+    perm = torch.randperm(len(d_lens), generator=g).tolist()
+    d_lens = [d_lens[i] for i in perm] + [7] * 40 + [16] * 40 + [17] * 40 + [33] * 40
+    qs, ps = _rows(g, [32] * n_q), _rows(g, d_lens)
+    dev = torch.device("cuda:0")
+    corpus, q = amd.pack_passages(ps, dev, batch_size=None), amd.pack_queries(qs, dev)
+    got = amd.maxsim_scores(q, corpus).cpu()
+    assert _close(got.numpy(), _truth(qs, ps))
+    one = amd.maxsim_scores(amd.pack_queries(qs[:1], dev), corpus).cpu()        # K1s, which requests every slab
+    assert torch.equal(one[0], got[0])
