@@ -72,14 +72,17 @@ def test_slab_edges_against_oracle_and_bitwise_against_k1b(amd, n_q, lq, ragged)
 
 
 def _truth(qs, ps):
-    """sum over tokens of the max over the passage's own rows, float64 (no block padding: batch_size=None packing)"""
-    out = np.empty((len(qs), len(ps)), np.float64)
-    P = [p.double() for p in ps]
-    for i, q in enumerate(qs):
-        qd = q.double()
-        for j, p in enumerate(P):
-            out[i, j] = (qd @ p.T).max(dim=1).values.sum().item()
-    return out
+    """sum over tokens of the max over the passage's own rows, float64 (no block padding: batch_size=None packing); one product per
+    passage against all query tokens, token sums per query by index_add"""
+    Q = torch.cat([q.double() for q in qs])
+    owner = torch.repeat_interleave(torch.arange(len(qs)), torch.tensor([q.shape[0] for q in qs]))
+    out = torch.zeros((len(qs), len(ps)), dtype=torch.float64)
+    for j, p in enumerate(ps):
+        if p.shape[0] == 0:
+            out[:, j] = float("-inf")
+            continue
+        out[:, j].index_add_(0, owner, (Q @ p.double().T).max(dim=1).values)
+    return out.numpy()
 
 
 @pytest.mark.parametrize("doc_len", [64, 32, 96, 17])
