@@ -1,4 +1,8 @@
 // K1bK -- K1b's eight-wave form for SHORT documents (pooled pages, 64-row documents): several documents per chunk.
+// STATUS (round 6): built, bit-identical to K1b (tests/test_gpu_short_docs.py against a measurement build with MSIM_BATCH_PACKED=1),
+// and 4-9 % SLOWER than K1b at 64 / 343 rows -- compiled into measurement builds only (make ab / make trace), never shipped.
+// Its phase trace (tools/trace_batch.py, profiles/r06_logs/ab_short_docs_packed.log): the chunk barrier it saves is worth ~350 cycles
+// per document; a document end costs ~1000 (lane groups combined on the VALU), the requests of a full chunk 1200-1600.
 // Same arithmetic and the same bits as K1b (colpali_engine/utils/processing_utils.py:179; the maxima are exact whatever the order,
 // the token sums run in reduce_query_tokens' order).
 //

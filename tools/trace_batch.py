@@ -31,6 +31,6 @@ for nq in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,16,32,256")
         if n == 0:
             continue
         tot = sum(int(t[w, i]) for i in range(6))
-        names = (("vmcnt+convoy", "barrier", "issue", "token sums", "slabs", "doc ends") if doc_len <= 512 and os.environ.get("MSIM_BATCH_PACKED") != "0"
+        names = (("vmcnt+convoy", "barrier", "issue", "token sums", "slabs", "doc ends") if os.environ.get("MSIM_BATCH_PACKED") == "1"
                  else ("vmcnt", "convoy", "barrier", "issue", "slabs", "epilogue"))       # K1bK (several documents per chunk) / K1b
         print(f"  wave {w}: chunks {n:6d}  " + "  ".join(f"{nm} {int(t[w, i]) / n:7.1f}" for i, nm in enumerate(names)) + f"  total {tot / n:8.1f}  (sum {tot} ticks)")
