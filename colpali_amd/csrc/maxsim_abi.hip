@@ -381,7 +381,9 @@ int flat_plan(const HostQ &hq, int n_q, FlatPlan &p) {
         // XCD, held together by the convoy, every corpus byte read from HBM once).  1000 queries x 40 tokens: 40 blocks of 64 units
         // run as four ranges x five rounds and read the corpus TWICE (PMC: 66.5 GB for 33.3 GB); 32 blocks of 80 units read it once
         // in the same time (99.3 vs 99.4-99.8 ms, profiles/r06_logs/ab_short_docs_packed.log section 7)
-        const bool single_round10 = b10.size() - 1 <= 32 && b8.size() - 1 > 32;
+        // (a one-round plan takes as long as its heaviest wave whatever the number of blocks: only when the round is full, 31 or 32
+        // blocks -- with 28 ten-unit blocks four CUs per XCD idle and the eight-unit plan's sub-ranges win by 13 %)
+        const bool single_round10 = b10.size() - 1 <= 32 && b10.size() - 1 >= 31 && b8.size() - 1 > 32;
         if (11 * c10 < 10 * c8 || (c10 <= c8 && single_round10)) {
             p.maxu = 10;
             p.blk_q0.swap(b10);

@@ -385,6 +385,7 @@ def test_the_launch_plan_is_the_ladder_design_md_describes():
     assert plan(n_q=32, lq=32) == (1, 8, 8, 1, 8) and plan(n_q=40, lq=32) == (1, 8, 10, 1, 10)
     assert plan(n_q=1000, lq=32) == (1, 8, 8, 32, 8)                                                # 32 blocks: one round of an XCD's CUs
     assert plan(n_q=1000, lq=40) == (1, 8, 10, 32, 10) and plan(n_q=1000, lq=20) == (1, 8, 8, 20, 8)     # 40 blocks of 64 units would take two rounds and read the corpus twice: 32 ten-unit blocks, one round
+    assert plan(n_q=1200, lq=32) == (1, 8, 8, 38, 8) and plan(n_q=1280, lq=32) == (1, 8, 10, 32, 10)   # ... only when that round is full: 30 ten-unit blocks would idle two CUs per XCD
     assert plan(n_q=80, lq=32) == (1, 8, 8, 3, 7)      # three blocks of 27/27/26 queries: 7 units on the heaviest wave (round 3's 32-token
     #                                                     tiles made that 4 tiles = 8 units, and two ten-unit blocks won: 3 x 7 < 1.1 x 2 x 10 now)
     assert plan(n_q=9, lq=8) == (1, 2, 8, 1, 3)                                                     # more than 8 queries never go to K1s
