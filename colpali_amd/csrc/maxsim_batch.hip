@@ -170,9 +170,10 @@ __global__ __launch_bounds__(NW * 64, (MAXU <= 5 ? 3 : 2)) void maxsim_batch_ker
     };
     p_open();
     int p_slot = 0;
-    // A share of a chunk that lies wholly past the document's end is NOT requested (round 6): an LDS-DMA instruction costs its wave ~100 cycles whether or not its rows exist -- with 64-row
-    // documents waves 4..7 spent 700 cycles per document fetching zeros that nobody reads (slabs past the end are never computed, and
-    // the rows of a tail slab past the end are masked after the MFMA: what the ring holds there does not matter)
+    // A share of a chunk that lies wholly past the document's end is NOT requested (round 6): an LDS-DMA instruction costs its wave
+    // ~100 cycles whether or not its rows exist -- with 64-row documents waves 4..7 spent 700 cycles per document fetching zeros that
+    // nobody reads (slabs past the end are never computed, and the rows of a tail slab past the end are masked after the MFMA: what
+    // the ring holds there does not matter)
     unsigned p_hist = 0;                                     // bit k: the produce() k calls ago made its four requests (wave-uniform)
     auto produce = [&]() -> bool {
         p_hist <<= 1;
